@@ -1,0 +1,144 @@
+/*
+ * silero_vad_hip.h -- C ABI of the MI355X (gfx950) Silero-VAD v6 inference engine.
+ *
+ * The reference has no C ABI for this path: its boundary is a duck-typed Python model object
+ * (TorchScript VADRNNJITMerge, or OnnxWrapper over ONNX Runtime).  The entry points below are
+ * what a binding for that object has to call; each cites the reference interface it replaces
+ * (paths relative to the reference repo; "JIT!/" = TorchScript source inside
+ * src/silero_vad/data/silero_vad.jit).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer marked "dev" is a DEVICE pointer on the
+ *     engine's GPU (HBM-resident), everything else is host memory;
+ *   - the caller owns all I/O buffers; the engine owns only its packed weights and scratch;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous with respect to the host unless stated otherwise;
+ *   - one engine per GPU; an engine is not thread-safe (the reference model object is not
+ *     either: src/silero_vad/utils_vad.py:51-92 mutates _state/_context per call);
+ *   - all arithmetic is fp32; sample rates 16000 (chunk N=512, context
+ *     C=64) and 8000 (N=256, C=32).
+ */
+#ifndef SILERO_VAD_HIP_H
+#define SILERO_VAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vad_engine vad_engine;
+
+enum vad_status {
+    VAD_OK = 0,
+    VAD_ERR_ARG = 1,        /* null pointer / negative size                                    */
+    VAD_ERR_SAMPLE_RATE = 2,/* sr not in {8000, 16000}   (vad_annotator.py:95)                 */
+    VAD_ERR_WEIGHTS = 3,    /* malformed weight container / missing tensor                     */
+    VAD_ERR_NO_DEVICE = 4,  /* no HIP device, or not a gfx950 part                             */
+    VAD_ERR_HIP = 5,        /* a HIP runtime call failed; see vad_last_error()                  */
+    VAD_ERR_ALLOC = 6,      /* scratch allocation failed                                        */
+    VAD_ERR_CAPTURE = 7,    /* scratch would have to grow while the stream is being captured    */
+    VAD_ERR_OPTION = 8      /* unknown option name/value                                        */
+};
+
+/* ---- lifetime --------------------------------------------------------------------------------
+ * Replaces load_silero_vad()/init_jit_model (src/silero_vad/model.py:6-36,
+ * src/silero_vad/utils_vad.py:194-198): parses the SVADW001 weight container
+ * (tools/export_weights.py; state_dict of silero_vad.jit), re-packs it into MFMA fragment order
+ * and uploads it to `device`.                                                                  */
+int  vad_create(const void *weights, size_t nbytes, int device, vad_engine **out);
+void vad_destroy(vad_engine *e);
+const char *vad_strerror(int status);
+const char *vad_last_error(const vad_engine *e);   /* detail text of the last failing call */
+int  vad_device(const vad_engine *e);
+
+/* Geometry of a sample rate (returns VAD_ERR_SAMPLE_RATE otherwise).
+ * chunk: 512|256 (utils_vad.py:60), context: 64|32 (utils_vad.py:66).                           */
+int  vad_geometry(int sr, int *chunk, int *context);
+
+/* Options (strings so that bindings need no enum mirror):
+ *   "impl"      = "mfma" (default, the product path) | "reference" (slow all-VALU kernels kept
+ *                 as an on-device A/B for tests; never the default)
+ *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)           */
+int  vad_set_option(vad_engine *e, const char *name, const char *value);
+
+/* ---- the hot path ----------------------------------------------------------------------------
+ * One step for B independent streams: the functional form of VADRNNJITMerge.forward
+ * (JIT!/vad/model/vad_annotator.py:14-90) == the ONNX graph I/O used by OnnxWrapper.__call__
+ * (src/silero_vad/utils_vad.py:57-92, session.run at :80-82):
+ *     x1 = cat(ctx, pcm);  prob, state' = net(x1, state);  ctx' = x1[:, -C:]
+ *   pcm    dev [B][N]   fp32 in [-1,1], row stride `ld` floats
+ *   ctx    dev [B][C]   in/out  (zeros after a reset)
+ *   state  dev [2][B][128] in/out  (h stacked on c; zeros after a reset)
+ *   prob   dev [B]      out                                                                     */
+int  vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ctx, float *state,
+              float *prob, void *stream);
+
+/* T = ceil(L / N) lock-step steps for B streams: VADRNNJITMerge.audio_forward
+ * (JIT!/vad/model/vad_annotator.py:128-156; ONNX twin utils_vad.py:94-110) with the carried
+ * state made explicit (pass zeroed ctx/state for the reference's reset-then-run behaviour).
+ * A last partial chunk is right-padded with zeros, as the reference does (:141-148).
+ *   pcm    dev [B][L]   row stride `ld`
+ *   probs  dev [B][T]   row stride `ldp`                                                        */
+int  vad_forward_audio(vad_engine *e, int sr, int B, long L, const float *pcm, long ld,
+                       float *ctx, float *state, float *probs, long ldp, void *stream);
+
+/* Same, 16-bit PCM in HBM; samples are scaled by 1/32768 on load, the convention of the
+ * reference's non-Python clients (examples/cpp/wav.h:113-118, examples/onnx_sequence/run.py:119). */
+int  vad_forward_audio_i16(vad_engine *e, int sr, int B, long L, const int16_t *pcm, long ld,
+                           float *ctx, float *state, float *probs, long ldp, void *stream);
+
+/* Pre-size the engine-owned scratch for (sr, B, T) so that later calls allocate nothing (needed
+ * before capturing vad_step/vad_forward_audio into a hipGraph).  Synchronous.                    */
+int  vad_reserve(vad_engine *e, int sr, int B, long T);
+size_t vad_scratch_bytes(const vad_engine *e);
+
+/* With option profile=1 the engine brackets its kernels with hipEvents on the caller's stream
+ * (no host synchronisation at record time).  This call waits for them and returns the GPU time in
+ * ms SUMMED over all vad_step/vad_forward_audio calls since the previous query (`calls` of them):
+ * front = framing + STFT + encoder + input-gate GEMM kernel, rec = LSTM recurrence + head kernel. */
+int  vad_kernel_times(vad_engine *e, float *front_ms, float *rec_ms, long *calls);
+
+/* ---- post-processing on the host ----------------------------------------------------------------
+ * The hysteresis segmenter of get_speech_timestamps (src/silero_vad/utils_vad.py:338-450) as a
+ * native routine (C++ twin in the reference: examples/cpp/silero-vad-onnx.cpp:196-389).
+ * Field names and defaults are those of the Python signature (utils_vad.py:212-227).             */
+typedef struct vad_segment_params {
+    double threshold;                    /* 0.5   (double: Python compares in double)       */
+    double neg_threshold;                /* < 0 => max(threshold - 0.15, 0.01)  (:342-343)  */
+    int    sampling_rate;                /* 8000 | 16000 (already decimated)                */
+    int    min_speech_duration_ms;       /* 250                                             */
+    double max_speech_duration_s;        /* +inf                                            */
+    int    min_silence_duration_ms;      /* 100                                             */
+    int    speech_pad_ms;                /* 30                                              */
+    int    min_silence_at_max_speech_ms; /* 98                                              */
+    int    use_max_poss_sil_at_max_speech; /* 1                                             */
+} vad_segment_params;
+
+typedef struct vad_segment { int64_t start, end; } vad_segment;   /* sample indices */
+
+void vad_segment_params_default(vad_segment_params *p, int sampling_rate);
+
+/* probs[n] -> speech segments of an audio of `audio_len` samples.  Writes at most `cap`
+ * segments to `out`; returns the number of segments found (may exceed cap), <0 on bad args.      */
+long vad_segment_probs(const float *probs, long n, long audio_len, const vad_segment_params *p,
+                       vad_segment *out, long cap);
+
+/* ---- test / bring-up hooks (not part of the drop-in surface) -------------------------------------
+ * Host-only: size and contents of the packed weight images the kernels consume, so CPU tests can
+ * check the fragment packing without a GPU.  which: 0 = frontend GEMM stream, 1 = recurrent
+ * W_hh image, 2 = small tables (biases, head, window, twiddles).                                  */
+long vad_debug_packed_floats(const vad_engine *e, int sr, int which);
+int  vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n);
+/* Host-only engine for the hooks above (no device needed).                                       */
+int  vad_create_host_only(const void *weights, size_t nbytes, vad_engine **out);
+/* Device: run the frontend only and return the LSTM input-gate pre-activations
+ * gx[B][T][512] = W_ih * enc(stft(x)) + b_ih + b_hh  (row-major, gate order i,f,g,o).            */
+int  vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, long ld,
+                        const float *ctx, float *gx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SILERO_VAD_HIP_H */

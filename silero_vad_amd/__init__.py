@@ -1,0 +1,11 @@
+"""MI355X-native Silero-VAD v6 inference engine: hand-written HIP kernels for gfx950 behind a
+C ABI (include/silero_vad_hip.h), with the reference package's Python surface on top.
+
+    from silero_vad_amd import load_silero_vad, get_speech_timestamps, VADIterator
+"""
+from .engine import Engine, HipSileroVAD, load_silero_vad  # noqa: F401
+from .timestamps import (VADIterator, collect_chunks, drop_chunks, get_speech_timestamps,  # noqa: F401
+                         read_audio, segment_probs)
+from .sharding import shard_range, gather_to_rank0, batch_speech_timestamps  # noqa: F401
+
+__version__ = "0.1.0"

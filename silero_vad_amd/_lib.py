@@ -1,0 +1,84 @@
+"""ctypes binding of include/silero_vad_hip.h (the in-tree libsilero_vad_hip.so).
+
+The product path has no CPU fallback: if the shared library is missing this module raises at
+import of the symbols, and `Engine(...)` raises if no gfx950 device can be opened.
+"""
+import ctypes
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int16, c_int64,
+                    c_long, c_size_t, c_void_p)
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libsilero_vad_hip.so"
+WEIGHTS_PATH = PKG / "data" / "silero_vad_v6.weights"
+
+VAD_OK = 0
+STATUS_NAMES = {1: "ARG", 2: "SAMPLE_RATE", 3: "WEIGHTS", 4: "NO_DEVICE", 5: "HIP", 6: "ALLOC",
+                7: "CAPTURE", 8: "OPTION"}
+
+
+class SegmentParams(Structure):
+    _fields_ = [("threshold", c_double), ("neg_threshold", c_double), ("sampling_rate", c_int),
+                ("min_speech_duration_ms", c_int), ("max_speech_duration_s", c_double),
+                ("min_silence_duration_ms", c_int), ("speech_pad_ms", c_int),
+                ("min_silence_at_max_speech_ms", c_int), ("use_max_poss_sil_at_max_speech", c_int)]
+
+
+class Segment(Structure):
+    _fields_ = [("start", c_int64), ("end", c_int64)]
+
+
+# every symbol include/silero_vad_hip.h declares: name -> (restype, argtypes)
+f32p, i16p = POINTER(c_float), POINTER(c_int16)
+SYMBOLS = {
+    "vad_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
+    "vad_destroy": (None, [c_void_p]),
+    "vad_strerror": (c_char_p, [c_int]),
+    "vad_last_error": (c_char_p, [c_void_p]),
+    "vad_device": (c_int, [c_void_p]),
+    "vad_geometry": (c_int, [c_int, POINTER(c_int), POINTER(c_int)]),
+    "vad_set_option": (c_int, [c_void_p, c_char_p, c_char_p]),
+    "vad_step": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vad_forward_audio": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p, c_void_p,
+                                  c_void_p, c_long, c_void_p]),
+    "vad_forward_audio_i16": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p,
+                                      c_void_p, c_void_p, c_long, c_void_p]),
+    "vad_reserve": (c_int, [c_void_p, c_int, c_int, c_long]),
+    "vad_scratch_bytes": (c_size_t, [c_void_p]),
+    "vad_kernel_times": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_long)]),
+    "vad_segment_params_default": (None, [POINTER(SegmentParams), c_int]),
+    "vad_segment_probs": (c_long, [f32p, c_long, c_long, POINTER(SegmentParams), POINTER(Segment), c_long]),
+    "vad_debug_packed_floats": (c_long, [c_void_p, c_int, c_int]),
+    "vad_debug_packed_copy": (c_int, [c_void_p, c_int, c_int, f32p, c_long]),
+    "vad_create_host_only": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "vad_debug_frontend": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raises OSError/AttributeError if it or a symbol is missing."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise OSError(f"{LIB_PATH} not built: run `python __graft_entry__.py` (hipcc, gfx950)")
+        handle = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+class VadError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = lib().vad_strerror(status).decode()
+        super().__init__(f"{msg}{': ' + detail if detail else ''} [VAD_ERR_{STATUS_NAMES.get(status, status)}]")
+
+
+def check(handle, status):
+    if status != VAD_OK:
+        detail = lib().vad_last_error(handle).decode() if handle else ""
+        raise VadError(status, detail)

@@ -1,0 +1,59 @@
+// device_api.hpp -- launcher declarations shared by engine.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace vad {
+
+// device pointers to the canonical (un-packed) tensors of one net, for impl="reference"
+struct RefNet {
+    const float *basis;
+    const float *ew[4], *eb[4];
+    const float *w_ih, *w_hh, *b_ih, *b_hh, *w_out, *b_out;
+};
+
+__device__ __forceinline__ float load_pcm(const float *p) { return *p; }
+__device__ __forceinline__ float load_pcm(const int16_t *p) { return (float)(*p) * (1.0f / 32768.0f); }
+
+template <typename PcmT>
+hipError_t launch_ref_forward(const RefNet &w, int sr, int B, long L, const PcmT *pcm, long ld,
+                              float *ctx, float *state, float *probs, long ldp, hipStream_t s);
+
+// ---- product path --------------------------------------------------------------------------------
+// Frontend: PCM -> in-wave FFT magnitude -> 4 conv blocks -> W_ih GEMM, fp32 MFMA.
+//   one wave = 16 chunks (16 streams x one time step); gx is written in MFMA D-fragment order
+//   gx[stream_tile][t][mblock 32][lane 64][4]   (stream_tile = 16 consecutive streams)
+// Also writes ctx_out[b][C] = last C samples of the (zero padded) input of every stream.
+struct FrontArgs {
+    const float *wfront;     // packed GEMM stream (layout.hpp)
+    const float *tables;     // biases, window, twiddles
+    const void *pcm;         // [B][L] float or int16, rows 16-byte aligned
+    const void *tail;        // [B][N] zero padded copy of the last chunk when L % N != 0, else null
+    long ld, L, T;           // row stride (elements), samples per stream, chunks per stream
+    long t0, nt;             // time slab [t0, t0 + nt) processed by this launch
+    const float *ctx_in;     // [B][C] context of chunk 0 (read when t == 0)
+    float *ctx_out;          // [B][C] written by the waves that own t == T-1 (may alias ctx_in)
+    float *gx;               // scratch, tile-major, indexed with slab-relative t
+    int B;
+};
+template <typename PcmT>
+hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s);
+
+// Recurrence: persistent over the slab's time steps; W_hh pinned in VGPRs, h exchanged through
+// LDS, LSTM pointwise + head fused.  One workgroup (8 waves) per 16 streams.
+struct RecArgs {
+    const float *whh;        // packed recurrent image
+    const float *tables;
+    const float *gx;
+    float *state;            // [2][B][128] in/out
+    float *probs;            // [B][ldp]
+    long ldp, t0, nt;
+    int B;
+};
+hipError_t launch_rec(int sr, const RecArgs &a, hipStream_t s);
+
+// gx (fragment order) -> row-major [B][T][512] for vad_debug_frontend
+hipError_t launch_unpack_gx(const float *gx, float *out, int B, long T, hipStream_t s);
+
+}  // namespace vad

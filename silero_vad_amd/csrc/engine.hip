@@ -1,0 +1,440 @@
+// engine.hip -- the C ABI (include/silero_vad_hip.h): engine lifetime, scratch, kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/silero_vad_hip.h"
+#include "device_api.hpp"
+#include "layout.hpp"
+#include "weights.hpp"
+
+struct vad_engine {
+    vad::Weights weights;
+    bool host_only = false;
+    int device = -1;
+    std::string err;
+    bool impl_reference = false;
+    bool profile = false;
+
+    // device images
+    uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
+    vad::RefNet ref[2] = {};
+    float *d_front[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
+
+    // scratch
+    float *d_gx = nullptr;
+    size_t gx_floats = 0;
+    float *d_ctx_new = nullptr;
+    size_t ctx_floats = 0;
+    void *d_tail = nullptr;                         // [B][N] zero padded last chunk (L % N != 0)
+    size_t tail_bytes = 0;
+    void *d_realign = nullptr;                      // aligned copy of a misaligned input (rare)
+    size_t realign_bytes = 0;
+    long slab_steps = 0;                            // time steps per gx slab for the last reserve
+
+    // profiling: 3 events per (call, slab), read back lazily by vad_kernel_times
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    long prof_calls = 0;
+};
+
+namespace {
+
+constexpr size_t kMaxGxBytes = 6ull << 30;         // cap of the gx scratch; longer inputs are slabbed
+
+int fail(vad_engine *e, int code, const std::string &msg) {
+    if (e) e->err = msg;
+    return code;
+}
+int hip_fail(vad_engine *e, hipError_t rc, const char *what) {
+    return fail(e, VAD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(rc));
+}
+#define HIP_TRY(e, call)                                           \
+    do {                                                           \
+        hipError_t rc__ = (call);                                  \
+        if (rc__ != hipSuccess) return hip_fail(e, rc__, #call);   \
+    } while (0)
+
+int net_index(int sr) { return sr == 16000 ? 0 : sr == 8000 ? 1 : -1; }
+
+long slab_for(int B, long T) {
+    const long nst = (B + 15) / 16;
+    const size_t per_step = (size_t)nst * 32 * 256 * sizeof(float);   // gx bytes per time step
+    long s = (long)std::max<size_t>(1, kMaxGxBytes / per_step);
+    return std::min(s, T);
+}
+
+int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
+    const long nst = (B + 15) / 16;
+    const long slab = slab_for(B, T);
+    const size_t need_gx = (size_t)nst * slab * 32 * 256;
+    const size_t need_ctx = (size_t)B * (sr == 16000 ? 64 : 32);
+    const size_t need_tail = (size_t)B * (sr == 16000 ? 512 : 256) * sizeof(float);
+    if (need_gx > e->gx_floats || need_ctx > e->ctx_floats || need_tail > e->tail_bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(e, VAD_ERR_CAPTURE, "scratch must grow during stream capture; call vad_reserve first");
+        HIP_TRY(e, hipDeviceSynchronize());
+        if (need_gx > e->gx_floats) {
+            if (e->d_gx) (void)hipFree(e->d_gx);
+            e->d_gx = nullptr;
+            e->gx_floats = 0;
+            if (hipMalloc((void **)&e->d_gx, need_gx * sizeof(float)) != hipSuccess)
+                return fail(e, VAD_ERR_ALLOC, "cannot allocate gx scratch");
+            e->gx_floats = need_gx;
+        }
+        if (need_ctx > e->ctx_floats) {
+            if (e->d_ctx_new) (void)hipFree(e->d_ctx_new);
+            e->d_ctx_new = nullptr;
+            e->ctx_floats = 0;
+            if (hipMalloc((void **)&e->d_ctx_new, need_ctx * sizeof(float)) != hipSuccess)
+                return fail(e, VAD_ERR_ALLOC, "cannot allocate context scratch");
+            e->ctx_floats = need_ctx;
+        }
+        if (need_tail > e->tail_bytes) {
+            if (e->d_tail) (void)hipFree(e->d_tail);
+            e->d_tail = nullptr;
+            e->tail_bytes = 0;
+            if (hipMalloc(&e->d_tail, need_tail) != hipSuccess)
+                return fail(e, VAD_ERR_ALLOC, "cannot allocate tail scratch");
+            e->tail_bytes = need_tail;
+        }
+    }
+    e->slab_steps = slab;
+    return VAD_OK;
+}
+
+template <typename PcmT>
+int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld, float *ctx,
+                 float *state, float *probs, long ldp, void *stream_v) {
+    if (!e) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    const int ni = net_index(sr);
+    if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000]");
+    if (B < 0 || L < 0 || (B > 0 && L > 0 && (!pcm || !ctx || !state || !probs)) || ld < L)
+        return fail(e, VAD_ERR_ARG, "bad argument");
+    if (B == 0 || L == 0) return VAD_OK;
+    const int N = sr == 16000 ? 512 : 256, C = N / 8;
+    const long T = (L + N - 1) / N;
+    if (ldp < T) return fail(e, VAD_ERR_ARG, "ldp < T");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(e, hipSetDevice(e->device));
+
+    if (e->impl_reference) {
+        HIP_TRY(e, vad::launch_ref_forward<PcmT>(e->ref[ni], sr, B, L, pcm, ld, ctx, state, probs, ldp, stream));
+        return VAD_OK;
+    }
+
+    if (((size_t)ctx & 15) || ((size_t)state & 15))
+        return fail(e, VAD_ERR_ARG, "ctx and state must be 16-byte aligned");
+    int rc = ensure_scratch(e, sr, B, T, stream);
+    if (rc) return rc;
+    // The kernels use 16-byte vector loads: rows must be 16-byte aligned.  A misaligned input (odd
+    // row stride with B > 1, or an offset view) is copied once into aligned scratch.
+    const size_t esz = sizeof(PcmT);
+    if (((size_t)pcm & 15) || (B > 1 && (ld * esz) % 16)) {
+        const long ldA = (L + 15) / 16 * 16;
+        const size_t need = (size_t)B * ldA * esz;
+        if (need > e->realign_bytes) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return fail(e, VAD_ERR_CAPTURE, "misaligned input needs scratch during capture");
+            HIP_TRY(e, hipDeviceSynchronize());
+            if (e->d_realign) (void)hipFree(e->d_realign);
+            e->d_realign = nullptr;
+            e->realign_bytes = 0;
+            if (hipMalloc(&e->d_realign, need) != hipSuccess)
+                return fail(e, VAD_ERR_ALLOC, "cannot allocate realign scratch");
+            e->realign_bytes = need;
+        }
+        HIP_TRY(e, hipMemcpy2DAsync(e->d_realign, ldA * esz, pcm, ld * esz, L * esz, B,
+                                    hipMemcpyDeviceToDevice, stream));
+        pcm = reinterpret_cast<const PcmT *>(e->d_realign);
+        ld = ldA;
+    }
+    const void *tail = nullptr;
+    if (L % N) {
+        const long rem = L - (T - 1) * N;
+        HIP_TRY(e, hipMemsetAsync(e->d_tail, 0, (size_t)B * N * esz, stream));
+        HIP_TRY(e, hipMemcpy2DAsync(e->d_tail, N * esz, pcm + (T - 1) * N, ld * esz, rem * esz, B,
+                                    hipMemcpyDeviceToDevice, stream));
+        tail = e->d_tail;
+    }
+    const long slab = e->slab_steps;
+    const bool prof = e->profile;
+    if (prof) e->prof_calls++;
+    for (long t0 = 0; t0 < T; t0 += slab) {
+        const long nt = std::min(slab, T - t0);
+        vad::FrontArgs fa{};
+        fa.wfront = e->d_front[ni];
+        fa.tables = e->d_tables[ni];
+        fa.pcm = pcm;
+        fa.tail = tail;
+        fa.ld = ld; fa.L = L; fa.T = T; fa.t0 = t0; fa.nt = nt;
+        fa.ctx_in = ctx;
+        fa.ctx_out = e->d_ctx_new;
+        fa.gx = e->d_gx;
+        fa.B = B;
+        vad::RecArgs ra{};
+        ra.whh = e->d_whh[ni];
+        ra.tables = e->d_tables[ni];
+        ra.gx = e->d_gx;
+        ra.state = state;
+        ra.probs = probs;
+        ra.ldp = ldp; ra.t0 = t0; ra.nt = nt; ra.B = B;
+        hipEvent_t *ev = nullptr;
+        if (prof) {
+            while (e->ev_pool.size() < e->ev_used + 3) {
+                hipEvent_t x;
+                HIP_TRY(e, hipEventCreate(&x));
+                e->ev_pool.push_back(x);
+            }
+            ev = &e->ev_pool[e->ev_used];
+            e->ev_used += 3;
+            HIP_TRY(e, hipEventRecord(ev[0], stream));
+        }
+        HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
+        if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
+        HIP_TRY(e, vad::launch_rec(sr, ra, stream));
+        if (prof) HIP_TRY(e, hipEventRecord(ev[2], stream));
+    }
+    HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return VAD_OK;
+}
+
+int upload(vad_engine *e, float **dst, const std::vector<float> &src) {
+    HIP_TRY(e, hipMalloc((void **)dst, src.size() * sizeof(float)));
+    HIP_TRY(e, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    return VAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vad_strerror(int status) {
+    switch (status) {
+        case VAD_OK: return "ok";
+        case VAD_ERR_ARG: return "invalid argument";
+        case VAD_ERR_SAMPLE_RATE: return "unsupported sampling rate (supported: 8000, 16000)";
+        case VAD_ERR_WEIGHTS: return "malformed weight container";
+        case VAD_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
+        case VAD_ERR_HIP: return "HIP runtime error";
+        case VAD_ERR_ALLOC: return "device allocation failed";
+        case VAD_ERR_CAPTURE: return "scratch growth during stream capture";
+        case VAD_ERR_OPTION: return "unknown option";
+        default: return "unknown status";
+    }
+}
+
+const char *vad_last_error(const vad_engine *e) { return e ? e->err.c_str() : "null engine"; }
+int vad_device(const vad_engine *e) { return e ? e->device : -1; }
+
+int vad_geometry(int sr, int *chunk, int *context) {
+    if (net_index(sr) < 0) return VAD_ERR_SAMPLE_RATE;
+    if (chunk) *chunk = sr == 16000 ? 512 : 256;
+    if (context) *context = sr == 16000 ? 64 : 32;
+    return VAD_OK;
+}
+
+int vad_create_host_only(const void *weights, size_t nbytes, vad_engine **out) {
+    if (!out) return VAD_ERR_ARG;
+    *out = nullptr;
+    vad_engine *e = new (std::nothrow) vad_engine();
+    if (!e) return VAD_ERR_ALLOC;
+    const std::string err = e->weights.load(weights, nbytes);
+    if (!err.empty()) {
+        delete e;
+        return VAD_ERR_WEIGHTS;
+    }
+    e->host_only = true;
+    *out = e;
+    return VAD_OK;
+}
+
+int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out) {
+    if (!out) return VAD_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return VAD_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return VAD_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VAD_ERR_NO_DEVICE;
+    vad_engine *e = nullptr;
+    int rc = vad_create_host_only(weights, nbytes, &e);
+    if (rc) return rc;
+    e->host_only = false;
+    e->device = device;
+    auto bail = [&](int code) {
+        vad_destroy(e);
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(VAD_ERR_HIP);
+    for (int ni = 0; ni < 2; ++ni) {
+        if (upload(e, &e->d_front[ni], e->weights.packed[ni].front)) return bail(VAD_ERR_HIP);
+        if (upload(e, &e->d_whh[ni], e->weights.packed[ni].whh)) return bail(VAD_ERR_HIP);
+        if (upload(e, &e->d_tables[ni], e->weights.packed[ni].tables)) return bail(VAD_ERR_HIP);
+    }
+    // canonical tensors for impl=reference
+    const auto &blob = e->weights.blob;
+    if (hipMalloc((void **)&e->d_blob, blob.size()) != hipSuccess) return bail(VAD_ERR_ALLOC);
+    if (hipMemcpy(e->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(VAD_ERR_HIP);
+    for (int ni = 0; ni < 2; ++ni) {
+        const vad::NetTensors &t = e->weights.net[ni];
+        auto dev = [&](const float *p) {
+            return reinterpret_cast<const float *>(e->d_blob + ((const uint8_t *)p - blob.data()));
+        };
+        vad::RefNet &r = e->ref[ni];
+        r.basis = dev(t.basis);
+        for (int l = 0; l < 4; ++l) { r.ew[l] = dev(t.ew[l]); r.eb[l] = dev(t.eb[l]); }
+        r.w_ih = dev(t.w_ih); r.w_hh = dev(t.w_hh); r.b_ih = dev(t.b_ih); r.b_hh = dev(t.b_hh);
+        r.w_out = dev(t.w_out); r.b_out = dev(t.b_out);
+    }
+    *out = e;
+    return VAD_OK;
+}
+
+void vad_destroy(vad_engine *e) {
+    if (!e) return;
+    if (!e->host_only && e->device >= 0) {
+        (void)hipSetDevice(e->device);
+        (void)hipDeviceSynchronize();
+        for (int ni = 0; ni < 2; ++ni) {
+            if (e->d_front[ni]) (void)hipFree(e->d_front[ni]);
+            if (e->d_whh[ni]) (void)hipFree(e->d_whh[ni]);
+            if (e->d_tables[ni]) (void)hipFree(e->d_tables[ni]);
+        }
+        if (e->d_blob) (void)hipFree(e->d_blob);
+        if (e->d_gx) (void)hipFree(e->d_gx);
+        if (e->d_ctx_new) (void)hipFree(e->d_ctx_new);
+        if (e->d_tail) (void)hipFree(e->d_tail);
+        if (e->d_realign) (void)hipFree(e->d_realign);
+        for (auto &ev : e->ev_pool) (void)hipEventDestroy(ev);
+    }
+    delete e;
+}
+
+int vad_set_option(vad_engine *e, const char *name, const char *value) {
+    if (!e || !name || !value) return VAD_ERR_ARG;
+    const std::string n(name), v(value);
+    if (n == "impl") {
+        if (v == "mfma") e->impl_reference = false;
+        else if (v == "reference") e->impl_reference = true;
+        else return fail(e, VAD_ERR_OPTION, "impl must be mfma|reference");
+        return VAD_OK;
+    }
+    if (n == "profile") {
+        e->profile = (v == "1");
+        e->ev_used = 0;
+        e->prof_calls = 0;
+        return VAD_OK;
+    }
+    return fail(e, VAD_ERR_OPTION, "unknown option " + n);
+}
+
+int vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ctx, float *state,
+             float *prob, void *stream) {
+    const int N = sr == 16000 ? 512 : 256;
+    return forward_impl<float>(e, sr, B, N, pcm, ld, ctx, state, prob, 1, stream);
+}
+
+int vad_forward_audio(vad_engine *e, int sr, int B, long L, const float *pcm, long ld, float *ctx,
+                      float *state, float *probs, long ldp, void *stream) {
+    return forward_impl<float>(e, sr, B, L, pcm, ld, ctx, state, probs, ldp, stream);
+}
+
+int vad_forward_audio_i16(vad_engine *e, int sr, int B, long L, const int16_t *pcm, long ld,
+                          float *ctx, float *state, float *probs, long ldp, void *stream) {
+    return forward_impl<int16_t>(e, sr, B, L, pcm, ld, ctx, state, probs, ldp, stream);
+}
+
+int vad_reserve(vad_engine *e, int sr, int B, long T) {
+    if (!e) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    if (net_index(sr) < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "bad sr");
+    if (B <= 0 || T <= 0) return fail(e, VAD_ERR_ARG, "bad argument");
+    HIP_TRY(e, hipSetDevice(e->device));
+    return ensure_scratch(e, sr, B, T, nullptr);
+}
+
+size_t vad_scratch_bytes(const vad_engine *e) {
+    return e ? (e->gx_floats + e->ctx_floats) * sizeof(float) : 0;
+}
+
+int vad_kernel_times(vad_engine *e, float *front_ms, float *rec_ms, long *calls) {
+    if (!e) return VAD_ERR_ARG;
+    if (e->ev_used == 0) return fail(e, VAD_ERR_OPTION, "no timings: set option profile=1 before the calls");
+    HIP_TRY(e, hipSetDevice(e->device));
+    float f = 0.f, r = 0.f;
+    for (size_t i = 0; i + 2 < e->ev_used + 0 && i + 2 < e->ev_pool.size(); i += 3) {
+        float a = 0.f, b = 0.f;
+        HIP_TRY(e, hipEventSynchronize(e->ev_pool[i + 2]));
+        HIP_TRY(e, hipEventElapsedTime(&a, e->ev_pool[i], e->ev_pool[i + 1]));
+        HIP_TRY(e, hipEventElapsedTime(&b, e->ev_pool[i + 1], e->ev_pool[i + 2]));
+        f += a;
+        r += b;
+    }
+    if (front_ms) *front_ms = f;
+    if (rec_ms) *rec_ms = r;
+    if (calls) *calls = e->prof_calls;
+    e->ev_used = 0;
+    e->prof_calls = 0;
+    return VAD_OK;
+}
+
+long vad_debug_packed_floats(const vad_engine *e, int sr, int which) {
+    const int ni = net_index(sr);
+    if (!e || ni < 0) return -1;
+    const vad::PackedNet &p = e->weights.packed[ni];
+    return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size()
+         : which == 2 ? (long)p.tables.size() : -1;
+}
+
+int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n) {
+    const int ni = net_index(sr);
+    if (!e || ni < 0 || !dst) return VAD_ERR_ARG;
+    const vad::PackedNet &p = e->weights.packed[ni];
+    const std::vector<float> *v = which == 0 ? &p.front : which == 1 ? &p.whh : which == 2 ? &p.tables : nullptr;
+    if (!v || n != (long)v->size()) return VAD_ERR_ARG;
+    std::memcpy(dst, v->data(), v->size() * sizeof(float));
+    return VAD_OK;
+}
+
+int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, long ld,
+                       const float *ctx, float *gx, void *stream_v) {
+    if (!e) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    const int ni = net_index(sr);
+    if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "bad sr");
+    if (B <= 0 || L <= 0 || !pcm || !ctx || !gx) return fail(e, VAD_ERR_ARG, "bad argument");
+    const int N = sr == 16000 ? 512 : 256;
+    const long T = (L + N - 1) / N;
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(e, hipSetDevice(e->device));
+    int rc = ensure_scratch(e, sr, B, T, stream);
+    if (rc) return rc;
+    if (e->slab_steps < T) return fail(e, VAD_ERR_ARG, "debug frontend: input too long");
+    if (L % N || ((size_t)pcm & 15) || (ld * sizeof(float)) % 16 || ((size_t)ctx & 15))
+        return fail(e, VAD_ERR_ARG, "debug frontend: whole chunks and 16-byte aligned rows only");
+    vad::FrontArgs fa{};
+    fa.wfront = e->d_front[ni];
+    fa.tables = e->d_tables[ni];
+    fa.pcm = pcm;
+    fa.ld = ld; fa.L = L; fa.T = T; fa.t0 = 0; fa.nt = T;
+    fa.ctx_in = ctx;
+    fa.ctx_out = nullptr;
+    fa.gx = e->d_gx;
+    fa.B = B;
+    HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
+    HIP_TRY(e, vad::launch_unpack_gx(e->d_gx, gx, B, T, stream));
+    return VAD_OK;
+}
+
+}  // extern "C"

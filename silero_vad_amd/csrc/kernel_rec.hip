@@ -1,0 +1,133 @@
+// kernel_rec.hip -- the only time-sequential part of the path: the W_hh half of the LSTM cell,
+// the LSTM pointwise update and the ReLU -> 1x1 conv -> sigmoid head
+// (reference: aten::lstm_cell, JIT!/torch/nn/modules/rnn.py:69, gate order i,f,g,o;
+//  JIT!/vad/model/vad_annotator.py:170-187; head JIT!/torch/nn/modules/container/___torch_mangle_7.py).
+//
+// Persistent-RNN layout for gfx950:
+//   * one workgroup = 8 waves = 16 streams, looping over the slab's time steps;
+//   * wave w owns hidden units [16w, 16w+16) and therefore the gate rows {128q + 16w + i}: its
+//     slice of W_hh (4 gates x 32 k-steps = 128 MFMA A fragments) stays in 128 VGPRs for the whole
+//     launch -- W_hh (256 KiB) never leaves the register file of the CU;
+//   * per step: acc = gx_t (the frontend wrote it in exactly this D-fragment order), then
+//     128 x v_mfma_f32_16x16x4_f32 against h_{t-1}; the pointwise LSTM update is lane-local (a lane
+//     holds i,f,g,o of the same 4 units); h_t goes to a double-buffered 8 KiB LDS image that is
+//     the next step's B operand for all 8 waves (chain layout, layout.hpp); ONE barrier per step;
+//   * the head's 128-term dot product is reduced lane -> wave (2 shuffles) -> workgroup (LDS).
+#include <hip/hip_runtime.h>
+
+#include "device_api.hpp"
+#include "layout.hpp"
+
+namespace vad {
+namespace {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_f(float x) {
+    // 1 / (1 + e^-x), e^-x = 2^(-x log2 e); v_exp_f32 / v_rcp_f32 are 1-ulp ops
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_f(float x) {
+    // tanh x = 2 sigmoid(2x) - 1 loses relative accuracy near 0 only at the 1e-7 absolute level
+    return fmaf(2.0f, sigmoid_f(2.0f * x), -1.0f);
+}
+
+template <int NTAB_WOUT, int NTAB_BOUT>
+__global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
+    __shared__ __attribute__((aligned(16))) float hbuf[2][8 * 256];   // [buf][wave][lane][4]
+    __shared__ float pbuf[2][8 * 16];                                  // [buf][wave][stream]
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const long st = blockIdx.x;
+    const long b = st * 16 + j;
+    const bool valid = b < a.B;
+    const long bc = valid ? b : a.B - 1;
+
+    // W_hh slice -> registers: A[q][kg] holds k-steps 4kg..4kg+3 of gate q
+    f32x4 A[4][8];
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.whh) + (size_t)w * 4 * 8 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) A[q][kg] = src[(q * 8 + kg) * 64];
+    }
+    const f32x4 wo = *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * w + 4 * g);
+    const float bo = a.tables[NTAB_BOUT];
+
+    // state: lane (g, j) holds units 16w + 4g + r of stream j
+    const size_t soff = (size_t)bc * 128 + 16 * w + 4 * g;
+    f32x4 h = *reinterpret_cast<const f32x4 *>(a.state + soff);
+    f32x4 c = *reinterpret_cast<const f32x4 *>(a.state + (size_t)a.B * 128 + soff);
+    *reinterpret_cast<f32x4 *>(&hbuf[0][(w * 64 + lane) * 4]) = h;
+
+    const f32x4 *gx = reinterpret_cast<const f32x4 *>(a.gx) + ((size_t)st * a.nt * 32) * 64 + lane;
+    f32x4 gnext[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gnext[q] = gx[(size_t)(8 * q + w) * 64];
+    __syncthreads();
+
+    for (long t = 0; t < a.nt; ++t) {
+        const int cur = (int)(t & 1);
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = gnext[q];
+        if (t + 1 < a.nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gnext[q] = gx[((size_t)(t + 1) * 32 + 8 * q + w) * 64];
+        }
+        // gates += W_hh h_{t-1}
+        const f32x4 *hb = reinterpret_cast<const f32x4 *>(&hbuf[cur][0]) + lane;
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+            const f32x4 hv = hb[kg * 64];                    // units 16kg + 4g + r of stream j
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q][kg][r], hv[r], acc[q], 0, 0, 0);
+        }
+        // pointwise LSTM + head partial
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = sigmoid_f(acc[0][r]), fg = sigmoid_f(acc[1][r]);
+            const float gg = tanh_f(acc[2][r]), og = sigmoid_f(acc[3][r]);
+            const float cn = fmaf(fg, c[r], ig * gg);
+            c[r] = cn;
+            h[r] = og * tanh_f(cn);
+            part = fmaf(wo[r], fmaxf(h[r], 0.f), part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        *reinterpret_cast<f32x4 *>(&hbuf[cur ^ 1][(w * 64 + lane) * 4]) = h;
+        if (g == 0) pbuf[cur][w * 16 + j] = part;
+        __syncthreads();
+        if (w == 0 && g == 0) {
+            float p = bo;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) p += pbuf[cur][ww * 16 + j];
+            if (valid) a.probs[(size_t)b * a.ldp + a.t0 + t] = sigmoid_f(p);
+        }
+    }
+    if (valid) {
+        *reinterpret_cast<f32x4 *>(a.state + soff) = h;
+        *reinterpret_cast<f32x4 *>(a.state + (size_t)a.B * 128 + soff) = c;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_rec(int sr, const RecArgs &a, hipStream_t s) {
+    if (a.B <= 0 || a.nt <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((a.B + 15) / 16);
+    if (sr == 16000)
+        hipLaunchKernelGGL((rec_kernel<vadl::tab16.w_out, vadl::tab16.b_out>), dim3(grid), dim3(512), 0, s, a);
+    else
+        hipLaunchKernelGGL((rec_kernel<vadl::tab8.w_out, vadl::tab8.b_out>), dim3(grid), dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace vad

@@ -1,0 +1,139 @@
+// kernels_ref.hip -- impl="reference": slow, obviously-correct all-VALU kernels kept as an
+// on-device A/B for the MFMA path (tests only; never the default).  One workgroup per stream,
+// time loop inside, canonical (un-packed) weights, dense DFT-basis STFT exactly as the reference
+// computes it (JIT!/vad/utils/pytorch_stft.py:17-34).
+#include <hip/hip_runtime.h>
+
+#include "device_api.hpp"
+
+namespace vad {
+
+template <int N, int C, int F, int K>
+__device__ void ref_chunk(const RefNet &w, const float *xp, float *sm, float *h, float *c,
+                          float *prob_out) {
+    constexpr int H = F / 2;
+    float *mag = sm;                 // [K][4]
+    float *a0 = mag + 132 * 4;       // [128][4]
+    float *a1 = a0 + 128 * 4;        // [64][2]
+    float *a2 = a1 + 64 * 2;         // [64]
+    float *a3 = a2 + 64;             // [128]
+    float *gates = a3 + 128;         // [512]
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    for (int idx = tid; idx < K * 4; idx += nt) {
+        const int k = idx >> 2, m = idx & 3;
+        const float *br = w.basis + (size_t)k * F, *bi = w.basis + (size_t)(K + k) * F;
+        float re = 0.f, im = 0.f;
+        for (int n = 0; n < F; ++n) {
+            const float v = xp[m * H + n];
+            re = fmaf(br[n], v, re);
+            im = fmaf(bi[n], v, im);
+        }
+        mag[k * 4 + m] = sqrtf(re * re + im * im);
+    }
+    __syncthreads();
+
+    const float *in = mag;
+    float *outs[4] = {a0, a1, a2, a3};
+    const int cin[4] = {K, 128, 64, 64}, cout[4] = {128, 64, 64, 128}, st[4] = {1, 2, 2, 1};
+    int T = 4;
+    for (int l = 0; l < 4; ++l) {
+        const int To = (T - 1) / st[l] + 1;
+        for (int idx = tid; idx < cout[l] * To; idx += nt) {
+            const int o = idx / To, u = idx % To;
+            const float *wr = w.ew[l] + (size_t)o * cin[l] * 3;
+            float acc = w.eb[l][o];
+            for (int tau = 0; tau < 3; ++tau) {
+                const int v = u * st[l] + tau - 1;
+                if (v < 0 || v >= T) continue;
+                for (int i = 0; i < cin[l]; ++i) acc = fmaf(wr[i * 3 + tau], in[i * T + v], acc);
+            }
+            outs[l][o * To + u] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        in = outs[l];
+        T = To;
+    }
+
+    for (int r = tid; r < 512; r += nt) {
+        const float *wi = w.w_ih + (size_t)r * 128, *wh = w.w_hh + (size_t)r * 128;
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < 128; ++j) {
+            a = fmaf(wi[j], a3[j], a);
+            b = fmaf(wh[j], h[j], b);
+        }
+        gates[r] = (a + w.b_ih[r]) + (b + w.b_hh[r]);
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int j = tid;
+        const float ig = 1.f / (1.f + expf(-gates[j])), fg = 1.f / (1.f + expf(-gates[128 + j]));
+        const float gg = tanhf(gates[256 + j]), og = 1.f / (1.f + expf(-gates[384 + j]));
+        const float cn = fg * c[j] + ig * gg;
+        c[j] = cn;
+        h[j] = og * tanhf(cn);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float p = w.b_out[0];
+        for (int j = 0; j < 128; ++j) p = fmaf(w.w_out[j], fmaxf(h[j], 0.f), p);
+        *prob_out = 1.f / (1.f + expf(-p));
+    }
+    __syncthreads();
+}
+
+template <int N, int C, int F, int K, typename PcmT>
+__global__ void __launch_bounds__(256)
+ref_forward_kernel(RefNet w, const PcmT *pcm, long ld, long L, long T, float *ctx, float *state,
+                   int B, float *probs, long ldp) {
+    __shared__ float xp[N + 2 * C];
+    __shared__ float sm[132 * 4 + 128 * 4 + 64 * 2 + 64 + 128 + 512];
+    __shared__ float h[128], c[128];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 128) {
+        h[tid] = state[(size_t)b * 128 + tid];
+        c[tid] = state[(size_t)B * 128 + (size_t)b * 128 + tid];
+    }
+    if (tid < C) xp[tid] = ctx[(size_t)b * C + tid];
+    __syncthreads();
+    for (long t = 0; t < T; ++t) {
+        for (int i = tid; i < N; i += blockDim.x) {
+            const long s = t * N + i;
+            xp[C + i] = s < L ? load_pcm(pcm + (size_t)b * ld + s) : 0.f;
+        }
+        __syncthreads();
+        if (tid < C) xp[C + N + tid] = xp[C + N - 2 - tid];        // right reflect pad
+        __syncthreads();
+        ref_chunk<N, C, F, K>(w, xp, sm, h, c, probs + (size_t)b * ldp + t);
+        if (tid < C) xp[tid] = xp[N + tid];                         // ctx = last C samples of x1
+        __syncthreads();
+    }
+    if (tid < 128) {
+        state[(size_t)b * 128 + tid] = h[tid];
+        state[(size_t)B * 128 + (size_t)b * 128 + tid] = c[tid];
+    }
+    if (tid < C) ctx[(size_t)b * C + tid] = xp[tid];
+}
+
+template <typename PcmT>
+hipError_t launch_ref_forward(const RefNet &w, int sr, int B, long L, const PcmT *pcm, long ld,
+                              float *ctx, float *state, float *probs, long ldp, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (sr == 16000) {
+        const long T = (L + 511) / 512;
+        hipLaunchKernelGGL((ref_forward_kernel<512, 64, 256, 129, PcmT>), dim3(B), dim3(256), 0, s, w,
+                           pcm, ld, L, T, ctx, state, B, probs, ldp);
+    } else {
+        const long T = (L + 255) / 256;
+        hipLaunchKernelGGL((ref_forward_kernel<256, 32, 128, 65, PcmT>), dim3(B), dim3(256), 0, s, w,
+                           pcm, ld, L, T, ctx, state, B, probs, ldp);
+    }
+    return hipGetLastError();
+}
+
+template hipError_t launch_ref_forward<float>(const RefNet &, int, int, long, const float *, long,
+                                              float *, float *, float *, long, hipStream_t);
+template hipError_t launch_ref_forward<int16_t>(const RefNet &, int, int, long, const int16_t *,
+                                                long, float *, float *, float *, long, hipStream_t);
+
+}  // namespace vad

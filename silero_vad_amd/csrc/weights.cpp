@@ -1,0 +1,155 @@
+// weights.cpp -- container parser + MFMA-fragment packer (host only).
+#include "weights.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace vad {
+namespace {
+
+struct Rec {            // one table entry of the container, 100 bytes, little endian
+    char name[64];
+    uint32_t ndim, dims[4];
+    uint64_t offset, count;
+};
+
+const float *find(const std::vector<uint8_t> &blob, const std::string &name, size_t expect,
+                  std::string &err) {
+    uint32_t n;
+    std::memcpy(&n, blob.data() + 8, 4);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint8_t *p = blob.data() + 80 + (size_t)i * 100;
+        if (80 + (size_t)(i + 1) * 100 > blob.size()) break;
+        if (std::strncmp((const char *)p, name.c_str(), 64) != 0) continue;
+        uint64_t off, cnt;
+        std::memcpy(&off, p + 84, 8);
+        std::memcpy(&cnt, p + 92, 8);
+        if (cnt != expect || off % 4 != 0 || off + cnt * 4 > blob.size()) {
+            err = "tensor " + name + " has unexpected size";
+            return nullptr;
+        }
+        return reinterpret_cast<const float *>(blob.data() + off);
+    }
+    err = "tensor " + name + " missing";
+    return nullptr;
+}
+
+bool bind(const std::vector<uint8_t> &blob, const std::string &prefix, const vadl::Geo &g,
+          NetTensors &t, std::string &err) {
+    const int cin[4] = {g.K, 128, 64, 64}, cout[4] = {128, 64, 64, 128};
+    auto get = [&](const std::string &n, size_t cnt) { return find(blob, prefix + "." + n, cnt, err); };
+    if (!(t.basis = get("stft.forward_basis_buffer", (size_t)2 * g.K * g.F))) return false;
+    for (int l = 0; l < 4; ++l) {
+        const std::string e = "encoder." + std::to_string(l) + ".reparam_conv.";
+        if (!(t.ew[l] = get(e + "weight", (size_t)cout[l] * cin[l] * 3))) return false;
+        if (!(t.eb[l] = get(e + "bias", (size_t)cout[l]))) return false;
+    }
+    if (!(t.w_ih = get("decoder.rnn.weight_ih", 4 * 128 * 128))) return false;
+    if (!(t.w_hh = get("decoder.rnn.weight_hh", 4 * 128 * 128))) return false;
+    if (!(t.b_ih = get("decoder.rnn.bias_ih", 4 * 128))) return false;
+    if (!(t.b_hh = get("decoder.rnn.bias_hh", 4 * 128))) return false;
+    if (!(t.w_out = get("decoder.decoder.2.weight", 128))) return false;
+    if (!(t.b_out = get("decoder.decoder.2.bias", 1))) return false;
+    return true;
+}
+
+// channel carried by k-step s in lane group g of a chain-layout activation (layout.hpp)
+inline int chain_chan(int s, int g) { return 16 * (s / 4) + 4 * g + (s % 4); }
+
+// dst = [kgroup][mblock][lane][4]; w(row, s, g) returns the weight that multiplies whatever lane
+// group g supplies at k-step s, for output row `row` (or 0 if nothing is supplied).
+template <class F>
+void pack_segment(float *dst, int M, int KS, F w) {
+    const int KG = (KS + 3) / 4;
+    for (int kg = 0; kg < KG; ++kg)
+        for (int m = 0; m < M; ++m)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int s = 4 * kg + r, g = lane >> 4, i = lane & 15;
+                    dst[(((size_t)kg * M + m) * 64 + lane) * 4 + r] = s < KS ? w(16 * m + i, s, g) : 0.f;
+                }
+}
+
+void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
+    using namespace vadl;
+    const int Q = g.Q, K = g.K;
+    p.geo = g;
+    p.front.assign((size_t)front_floats(Q), 0.f);
+    for (int tau = 0; tau < 3; ++tau) {
+        // encoder 0: input in mag layout
+        pack_segment(p.front.data() + seg_offset(E0T0 + tau, Q), 8, Q + 1, [&](int row, int s, int gg) {
+            int bin;
+            if (s < Q) bin = 4 * s + kResidue[gg];
+            else if (gg == 0) bin = 4 * Q;
+            else return 0.f;
+            return t.ew[0][((size_t)row * K + bin) * 3 + tau];
+        });
+        // encoder 1: 128 -> 64
+        pack_segment(p.front.data() + seg_offset(E1T0 + tau, Q), 4, 32, [&](int row, int s, int gg) {
+            return t.ew[1][((size_t)row * 128 + chain_chan(s, gg)) * 3 + tau];
+        });
+    }
+    for (int tau = 1; tau < 3; ++tau)   // encoder 2: tap 0 only ever sees the left zero pad
+        pack_segment(p.front.data() + seg_offset(E2T1 + tau - 1, Q), 4, 16, [&](int row, int s, int gg) {
+            return t.ew[2][((size_t)row * 64 + chain_chan(s, gg)) * 3 + tau];
+        });
+    // encoder 3: T_in = 1, only the centre tap sees data
+    pack_segment(p.front.data() + seg_offset(E3T1, Q), 8, 16, [&](int row, int s, int gg) {
+        return t.ew[3][((size_t)row * 64 + chain_chan(s, gg)) * 3 + 1];
+    });
+    for (int q = 0; q < 4; ++q)         // W_ih, one gate (128 rows) per segment
+        pack_segment(p.front.data() + seg_offset(IH0 + q, Q), 8, 32, [&](int row, int s, int gg) {
+            return t.w_ih[((size_t)(128 * q + row)) * 128 + chain_chan(s, gg)];
+        });
+
+    // recurrent image [wave][gate][kgroup][lane][4]
+    p.whh.assign((size_t)whh_floats(), 0.f);
+    for (int w = 0; w < 8; ++w)
+        for (int q = 0; q < 4; ++q)
+            for (int kg = 0; kg < 8; ++kg)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int gg = lane >> 4, i = lane & 15;
+                        p.whh[((((size_t)w * 4 + q) * 8 + kg) * 64 + lane) * 4 + r] =
+                            t.w_hh[(size_t)(128 * q + 16 * w + i) * 128 + chain_chan(4 * kg + r, gg)];
+                    }
+
+    // tables
+    const Tab tb = make_tab(g.F, Q);
+    p.tables.assign((size_t)tb.total, 0.f);
+    float *T = p.tables.data();
+    std::memcpy(T + tb.b_e0, t.eb[0], 128 * 4);
+    std::memcpy(T + tb.b_e1, t.eb[1], 64 * 4);
+    std::memcpy(T + tb.b_e2, t.eb[2], 64 * 4);
+    std::memcpy(T + tb.b_e3, t.eb[3], 128 * 4);
+    for (int r = 0; r < 512; ++r) T[tb.b_g + r] = t.b_ih[r] + t.b_hh[r];
+    std::memcpy(T + tb.w_out, t.w_out, 128 * 4);
+    T[tb.b_out] = t.b_out[0];
+    std::memcpy(T + tb.window, t.basis, (size_t)g.F * 4);   // basis row 0 = w[n] * cos(0)
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int gg = 0; gg < 4; ++gg)
+        for (int q = 0; q < Q; ++q) {
+            const double a1 = two_pi * kResidue[gg] * q / (4.0 * Q);
+            T[tb.tw1 + (gg * Q + q) * 2 + 0] = (float)std::cos(a1);
+            T[tb.tw1 + (gg * Q + q) * 2 + 1] = (float)-std::sin(a1);
+            const double a2 = two_pi * (4 * q + kResidue[gg]) / (8.0 * Q);
+            T[tb.tw2 + (gg * Q + q) * 2 + 0] = (float)std::cos(a2);
+            T[tb.tw2 + (gg * Q + q) * 2 + 1] = (float)-std::sin(a2);
+        }
+}
+
+}  // namespace
+
+std::string Weights::load(const void *data, size_t nbytes) {
+    if (!data || nbytes < 80 || std::memcmp(data, "SVADW001", 8) != 0)
+        return "not an SVADW001 weight container";
+    blob.assign((const uint8_t *)data, (const uint8_t *)data + nbytes);
+    std::string err;
+    if (!bind(blob, "_model", vadl::geo16, net[0], err)) return err;
+    if (!bind(blob, "_model_8k", vadl::geo8, net[1], err)) return err;
+    pack_net(net[0], vadl::geo16, packed[0]);
+    pack_net(net[1], vadl::geo8, packed[1]);
+    return "";
+}
+
+}  // namespace vad

@@ -1,0 +1,310 @@
+"""Lane-accurate numpy emulation of the gfx950 wave programs in silero_vad_amd/csrc
+(kernel_front.hip, kernel_rec.hip).
+
+Purpose: the authoring container has no GPU, and the two error-prone parts of the MFMA design --
+the host-side fragment packing (weights.cpp) and the index algebra of the in-wave FFT / register
+chaining -- are pure data-layout questions.  This module executes the SAME program the kernels
+execute, on arrays of shape [64] (one value per lane), reading the SAME packed images through the
+C ABI (vad_debug_packed_copy), so CPU tests can pin them against the oracle.
+
+Every function mirrors a device function of the same name.
+"""
+import numpy as np
+
+f32 = np.float32
+LANE = np.arange(64)
+G = LANE >> 4
+J = LANE & 15
+P_RES = np.array([0, 2, 1, 3])
+
+
+def bitrev(x, bits):
+    r = 0
+    for i in range(bits):
+        r |= ((x >> i) & 1) << (bits - 1 - i)
+    return r
+
+
+def shfl_xor(v, m):
+    return v[LANE ^ m]
+
+
+def mfma_16x16x4(a, b, acc):
+    """v_mfma_f32_16x16x4_f32: A[i][k] = a[16k+i], B[k][j] = b[16k+j]; D[4g+r][j] in acc[r][16g+j]."""
+    A = a.reshape(4, 16).T            # [i][k]
+    Bm = b.reshape(4, 16)             # [k][j]
+    D = (A.astype(np.float64) @ Bm.astype(np.float64)).astype(f32)   # [16 rows][16 cols]
+    out = acc.copy()
+    for r in range(4):
+        out[r] += D[4 * G + r, J]
+    return out
+
+
+class Tab:
+    def __init__(self, F, Q):
+        o = 0
+        self.b_e0 = o; o += 128
+        self.b_e1 = o; o += 64
+        self.b_e2 = o; o += 64
+        self.b_e3 = o; o += 128
+        self.b_g = o; o += 512
+        self.w_out = o; o += 128
+        self.b_out = o; o += 4
+        self.window = o; o += F
+        self.tw1 = o; o += 4 * Q * 2
+        self.tw2 = o; o += 4 * Q * 2
+        self.total = o
+
+
+SEG_NAMES = ["E0T0", "E0T1", "E0T2", "E1T0", "E1T1", "E1T2", "E2T1", "E2T2", "E3T1",
+             "IH0", "IH1", "IH2", "IH3"]
+
+
+def seg_mblocks(s):
+    return 8 if s <= 2 else 4 if s <= 7 else 8
+
+
+def seg_ksteps(s, Q):
+    return Q + 1 if s <= 2 else 32 if s <= 5 else 16 if s <= 8 else 32
+
+
+def seg_offset(s, Q):
+    o = 0
+    for i in range(s):
+        o += ((seg_ksteps(i, Q) + 3) // 4) * seg_mblocks(i) * 256
+    return o
+
+
+class FrontEmu:
+    def __init__(self, sr, front, tables):
+        self.Q = 32 if sr == 16000 else 16
+        self.front = front
+        self.tab = tables
+        self.tb = Tab(8 * self.Q, self.Q)
+        assert len(tables) == self.tb.total
+        assert len(front) == seg_offset(13, self.Q)
+
+    # ---- load_slice<V>: x [16][18Q] (ctx | chunk), returns s [2Q][64] ---------------------------
+    def load_slice(self, x, V):
+        Q = self.Q
+        SL = 2 * Q
+        s = np.zeros((SL, 64), f32)
+        sigma = 2 * V + G
+        sg = np.minimum(sigma, 8) if V == 3 else sigma
+        for lane in range(64):
+            s[:, lane] = x[J[lane], SL * sg[lane]: SL * sg[lane] + SL]
+        if V == 3:
+            rev = G == 3
+            extra = x[J, 16 * Q - 1]
+            for i in range(SL // 2 - 1):
+                k = SL - 2 - i
+                lo, hi = s[i].copy(), s[k].copy()
+                s[i] = np.where(rev, hi, lo)
+                s[k] = np.where(rev, lo, hi)
+            s[SL - 1] = np.where(rev, extra, s[SL - 1])
+        return s
+
+    def fft_inlane(self, re, im):
+        Q = self.Q
+        cos32 = np.cos(2 * np.pi * np.arange(16) / 32).astype(f32)
+        sin32 = np.sin(2 * np.pi * np.arange(16) / 32).astype(f32)
+        n = Q
+        while n >= 2:
+            half = n // 2
+            for b0 in range(0, Q, n):
+                for jx in range(half):
+                    i0, i1 = b0 + jx, b0 + jx + half
+                    ar, ai, br, bi = re[i0].copy(), im[i0].copy(), re[i1].copy(), im[i1].copy()
+                    re[i0], im[i0] = ar + br, ai + bi
+                    dr, di = ar - br, ai - bi
+                    tw = jx * (32 // n)
+                    if tw == 0:
+                        re[i1], im[i1] = dr, di
+                    elif tw == 8:
+                        re[i1], im[i1] = di, -dr
+                    else:
+                        c, sn = cos32[tw], sin32[tw]
+                        re[i1] = dr * c + di * sn
+                        im[i1] = di * c - dr * sn
+            n //= 2
+
+    def fft_pass(self, x, V):
+        Q, tb, T = self.Q, self.tb, self.tab
+        SL = 2 * Q
+        s = self.load_slice(x, V)
+        re = np.zeros((Q, 64), f32)
+        im = np.zeros((Q, 64), f32)
+        for lane_g in range(4):
+            m = G == lane_g
+            w = T[tb.window + SL * lane_g: tb.window + SL * lane_g + SL]
+            for k in range(SL // 4):
+                re[2 * k][m] = s[4 * k][m] * w[4 * k]
+                im[2 * k][m] = s[4 * k + 1][m] * w[4 * k + 1]
+                re[2 * k + 1][m] = s[4 * k + 2][m] * w[4 * k + 2]
+                im[2 * k + 1][m] = s[4 * k + 3][m] * w[4 * k + 3]
+        sgnA = np.where(G < 2, 1, -1).astype(f32)
+        sgnB = np.where(G & 1, -1, 1).astype(f32)
+        tw1 = T[tb.tw1: tb.tw1 + 4 * Q * 2].reshape(4, Q, 2)
+        for q in range(Q):
+            xr, xi = re[q], im[q]
+            pr, pi = shfl_xor(xr, 32), shfl_xor(xi, 32)
+            xr, xi = sgnA * xr + pr, sgnA * xi + pi
+            g3 = G == 3
+            xr, xi = np.where(g3, xi, xr), np.where(g3, -xr, xi)
+            qr, qi = shfl_xor(xr, 16), shfl_xor(xi, 16)
+            xr, xi = sgnB * xr + qr, sgnB * xi + qi
+            c, sn = tw1[G, q, 0], tw1[G, q, 1]
+            re[q] = xr * c - xi * sn
+            im[q] = xr * sn + xi * c
+        self.fft_inlane(re, im)
+        LG = Q.bit_length() - 1
+        tw2 = T[tb.tw2: tb.tw2 + 4 * Q * 2].reshape(4, Q, 2)
+        X = np.zeros((Q + 1, 64), f32)
+        for k in range(Q):
+            ur, ui = re[bitrev(k, LG)], im[bitrev(k, LG)]
+            ks, kr = bitrev((Q - k) % Q, LG), bitrev(Q - 1 - k, LG)
+            xr, xi = shfl_xor(re[kr], 16), shfl_xor(im[kr], 16)
+            pr = np.where(G >= 2, xr, re[kr])
+            pi = np.where(G >= 2, xi, im[kr])
+            pr = np.where(G == 0, re[ks], pr)
+            pi = np.where(G == 0, im[ks], pi)
+            ar, ai = ur + pr, ui - pi
+            dr, di = ui + pi, pr - ur
+            c, sn = tw2[G, k, 0], tw2[G, k, 1]
+            yr = ar + (dr * c - di * sn)
+            yi = ai + (dr * sn + di * c)
+            X[k] = f32(0.5) * np.sqrt(yr * yr + yi * yi)
+        X[Q] = np.where(G == 0, np.abs(re[0] - im[0]), 0)
+        return X
+
+    # ---- gemm_seg: acc [M][4][64] += A_seg * B, bfun(s) -> [64] -----------------------------------
+    def gemm_seg(self, acc, bfun, seg):
+        Q = self.Q
+        M, KS = seg_mblocks(seg), seg_ksteps(seg, Q)
+        base = seg_offset(seg, Q)
+        for kg in range((KS + 3) // 4):
+            for m in range(M):
+                blk = self.front[base + (kg * M + m) * 256: base + (kg * M + m + 1) * 256].reshape(64, 4)
+                for ks in range(4):
+                    if kg * 4 + ks < KS:
+                        acc[m] = mfma_16x16x4(blk[:, ks], bfun(kg * 4 + ks), acc[m])
+
+    def init_bias(self, M, off):
+        acc = np.zeros((M, 4, 64), f32)
+        for m in range(M):
+            for r in range(4):
+                acc[m, r] = self.tab[off + 16 * m + 4 * G + r]
+        return acc
+
+    def run(self, x):
+        """x [16][18Q] -> dict(mag X0..X3 in mag layout, gx [32][4][64] D-fragment order)."""
+        tb = self.tb
+        X = [self.fft_pass(x, v) for v in range(4)]
+        E0T0, E0T1, E0T2, E1T0, E1T1, E1T2, E2T1, E2T2, E3T1, IH0 = range(10)
+        chain = lambda A: (lambda s: A[s >> 2, s & 3])
+        relu = lambda A: np.maximum(A, 0)
+        Y = self.init_bias(8, tb.b_e0)
+        self.gemm_seg(Y, lambda s: X[0][s], E0T1)
+        self.gemm_seg(Y, lambda s: X[1][s], E0T2)
+        Y = relu(Y)
+        Z0 = self.init_bias(4, tb.b_e1)
+        self.gemm_seg(Z0, chain(Y), E1T1)
+        Y = self.init_bias(8, tb.b_e0)
+        self.gemm_seg(Y, lambda s: X[0][s], E0T0)
+        self.gemm_seg(Y, lambda s: X[1][s], E0T1)
+        self.gemm_seg(Y, lambda s: X[2][s], E0T2)
+        Y = relu(Y)
+        self.gemm_seg(Z0, chain(Y), E1T2)
+        Z1 = self.init_bias(4, tb.b_e1)
+        self.gemm_seg(Z1, chain(Y), E1T0)
+        Y = self.init_bias(8, tb.b_e0)
+        self.gemm_seg(Y, lambda s: X[1][s], E0T0)
+        self.gemm_seg(Y, lambda s: X[2][s], E0T1)
+        self.gemm_seg(Y, lambda s: X[3][s], E0T2)
+        Y = relu(Y)
+        self.gemm_seg(Z1, chain(Y), E1T1)
+        Y = self.init_bias(8, tb.b_e0)
+        self.gemm_seg(Y, lambda s: X[2][s], E0T0)
+        self.gemm_seg(Y, lambda s: X[3][s], E0T1)
+        Y = relu(Y)
+        self.gemm_seg(Z1, chain(Y), E1T2)
+        Z0, Z1 = relu(Z0), relu(Z1)
+        V = self.init_bias(4, tb.b_e2)
+        self.gemm_seg(V, chain(Z0), E2T1)
+        self.gemm_seg(V, chain(Z1), E2T2)
+        V = relu(V)
+        Fe = self.init_bias(8, tb.b_e3)
+        self.gemm_seg(Fe, chain(V), E3T1)
+        Fe = relu(Fe)
+        gx = np.zeros((32, 4, 64), f32)
+        for q in range(4):
+            Gq = self.init_bias(8, tb.b_g + 128 * q)
+            self.gemm_seg(Gq, chain(Fe), IH0 + q)
+            gx[8 * q: 8 * q + 8] = Gq
+        return {"X": X, "feat": Fe, "gx": gx}
+
+
+def mag_from_layout(X, Q):
+    """mag-layout registers X[v] ([Q+1][64]) -> dense [16 chunks][4Q+1 bins]."""
+    out = np.zeros((16, 4 * Q + 1), f32)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for s in range(Q):
+            out[j, 4 * s + P_RES[g]] = X[s, lane]
+        if g == 0:
+            out[j, 4 * Q] = X[Q, lane]
+    return out
+
+
+def chain_to_dense(A):
+    """chain-layout [NB][4][64] -> [16 cols][16 NB channels]."""
+    NB = A.shape[0]
+    out = np.zeros((16, 16 * NB), f32)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for blk in range(NB):
+            for r in range(4):
+                out[j, 16 * blk + 4 * g + r] = A[blk, r, lane]
+    return out
+
+
+def sigmoid_f(x):
+    return (f32(1) / (f32(1) + np.exp2(f32(-1.4426950408889634) * x))).astype(f32)
+
+
+def tanh_f(x):
+    return (f32(2) * sigmoid_f(f32(2) * x) - f32(1)).astype(f32)
+
+
+def rec_step(whh, tables, tb, gx, h, c):
+    """kernel_rec.hip, one step, one 16-stream tile.
+    gx [32][4][64] (D order), h/c [16 streams][128]  ->  prob [16], h', c'."""
+    hbuf = np.zeros((8, 64, 4), f32)          # [wave][lane][r] = h[unit 16w + 4g + r][stream j]
+    for w in range(8):
+        for r in range(4):
+            hbuf[w, :, r] = h[J, 16 * w + 4 * G + r]
+    hn, cn = np.zeros_like(h), np.zeros_like(c)
+    part_all = np.zeros((8, 16), f32)
+    W = whh.reshape(8, 4, 8, 64, 4)
+    for w in range(8):
+        acc = [gx[8 * q + w].copy() for q in range(4)]
+        for kg in range(8):
+            hv = hbuf[kg]
+            for r in range(4):
+                for q in range(4):
+                    acc[q] = mfma_16x16x4(W[w, q, kg, :, r], hv[:, r], acc[q])
+        part = np.zeros(64, f32)
+        for r in range(4):
+            cl = c[J, 16 * w + 4 * G + r]
+            ig, fg = sigmoid_f(acc[0][r]), sigmoid_f(acc[1][r])
+            gg, og = tanh_f(acc[2][r]), sigmoid_f(acc[3][r])
+            cnew = fg * cl + ig * gg
+            hnew = og * tanh_f(cnew)
+            cn[J, 16 * w + 4 * G + r] = cnew
+            hn[J, 16 * w + 4 * G + r] = hnew
+            part = part + tables[tb.w_out + 16 * w + 4 * G + r] * np.maximum(hnew, 0)
+        part = part + shfl_xor(part, 16)
+        part = part + shfl_xor(part, 32)
+        part_all[w] = part[:16]
+    p = tables[tb.b_out] + part_all.sum(0)
+    return sigmoid_f(p.astype(f32)), hn, cn

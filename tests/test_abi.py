@@ -1,0 +1,90 @@
+"""The C-ABI shared library on a machine WITHOUT a GPU: it loads, exports every symbol the header
+declares, and its host-only entry points behave (no compute calls here)."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def header_functions():
+    text = (ROOT / "include" / "silero_vad_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vad_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound(built):
+    from silero_vad_amd import _lib
+    names = header_functions()
+    assert len(names) >= 18
+    handle = ctypes.CDLL(str(_lib.LIB_PATH))
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in the header but not exported"
+    assert sorted(_lib.SYMBOLS) == names, "python binding and header disagree"
+    _lib.lib()
+
+
+def test_strerror_and_geometry(built):
+    from silero_vad_amd import _lib
+    L = _lib.lib()
+    assert L.vad_strerror(0) == b"ok"
+    for code in range(1, 9):
+        assert L.vad_strerror(code) not in (b"ok", b"unknown status")
+    c, x = ctypes.c_int(), ctypes.c_int()
+    assert L.vad_geometry(16000, ctypes.byref(c), ctypes.byref(x)) == 0 and (c.value, x.value) == (512, 64)
+    assert L.vad_geometry(8000, ctypes.byref(c), ctypes.byref(x)) == 0 and (c.value, x.value) == (256, 32)
+    assert L.vad_geometry(44100, None, None) == 2
+
+
+def test_weights_container_errors(built):
+    from silero_vad_amd import _lib
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    assert L.vad_create_host_only(b"garbage" * 40, 280, ctypes.byref(h)) == 3       # VAD_ERR_WEIGHTS
+    blob = bytearray(_lib.WEIGHTS_PATH.read_bytes())
+    blob[100:110] = b"corrupted!"                                                    # break a tensor name
+    assert L.vad_create_host_only(bytes(blob), len(blob), ctypes.byref(h)) == 3
+    good = _lib.WEIGHTS_PATH.read_bytes()
+    assert L.vad_create_host_only(good, len(good), ctypes.byref(h)) == 0
+    # a host-only engine refuses device work loudly
+    assert L.vad_reserve(h, 16000, 4, 4) == 4                                        # VAD_ERR_NO_DEVICE
+    assert b"host-only" in L.vad_last_error(h)
+    assert L.vad_set_option(h, b"impl", b"bogus") == 8
+    assert L.vad_set_option(h, b"impl", b"reference") == 0
+    L.vad_destroy(h)
+
+
+def test_no_gpu_means_loud_failure(built):
+    """The product path has no CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from silero_vad_amd import _lib, load_silero_vad
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        load_silero_vad()
+    good = _lib.WEIGHTS_PATH.read_bytes()
+    h = ctypes.c_void_p()
+    assert _lib.lib().vad_create(good, len(good), 0, ctypes.byref(h)) == 4           # VAD_ERR_NO_DEVICE
+
+
+def test_packed_image_sizes(built):
+    from silero_vad_amd import _lib
+    L = _lib.lib()
+    good = _lib.WEIGHTS_PATH.read_bytes()
+    h = ctypes.c_void_p()
+    assert L.vad_create_host_only(good, len(good), ctypes.byref(h)) == 0
+    # 16 kHz frontend stream: E0 3x(9 kg x 8 mb) + E1 3x(8x4) + E2 2x(4x4) + E3 (4x8) + IH 4x(8x8) KiB
+    assert L.vad_debug_packed_floats(h, 16000, 0) == (3 * 72 + 3 * 32 + 2 * 16 + 32 + 4 * 64) * 256
+    assert L.vad_debug_packed_floats(h, 8000, 0) == (3 * 40 + 3 * 32 + 2 * 16 + 32 + 4 * 64) * 256
+    assert L.vad_debug_packed_floats(h, 16000, 1) == 128 * 512
+    n = L.vad_debug_packed_floats(h, 16000, 1)
+    whh = np.empty(n, np.float32)
+    assert L.vad_debug_packed_copy(h, 16000, 1, whh.ctypes.data_as(_lib.f32p), n) == 0
+    # the packed recurrent image is a permutation of W_hh
+    from oracle.weights import read_container
+    w = read_container(good)["_model.decoder.rnn.weight_hh"]
+    assert np.array_equal(np.sort(whh), np.sort(w.ravel()))
+    L.vad_destroy(h)

@@ -1,0 +1,322 @@
+"""Parity tests proper: the HIP path, called through the C ABI (silero_vad_amd/_lib.py), against
+  (1) golden vectors recorded from the reference's TorchScript model (tests/golden/),
+  (2) the CPU oracle on the same seeded inputs,
+  (3) size-independent properties at BASELINE.json's full batch (4096 streams).
+Tolerance: |dp| <= 1e-4 on speech probabilities (BASELINE.json north_star; the reference's own
+cross-runtime check uses the same bound, examples/openvino/verify.py:167) and identical segments.
+Everything here needs a real MI355X:  python -m pytest tests -m gpu
+"""
+import ctypes
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import SRS, kat_segments, state_err, synthetic_audio
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # the contract
+TIGHT = 2e-5        # what fp32 in a different summation order actually delivers; regression guard
+
+
+@pytest.fixture(scope="module")
+def model(built):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (there is no CPU fallback to silently pass on)")
+    from silero_vad_amd import load_silero_vad
+    m = load_silero_vad(device=0)
+    assert m.engine._h, "native engine not created"
+    return m
+
+
+def chunk_of(sr):
+    return 512 if sr == 16000 else 256
+
+
+def rolled_rows(wav, B, L, stride=7919):
+    return np.stack([np.roll(wav, -b * stride)[:L] for b in range(B)])
+
+
+def run_engine(model, rows, sr, state=None, ctx=None):
+    eng = model.engine
+    dev = model.device
+    x = torch.as_tensor(rows).to(dev)
+    B = x.shape[0]
+    n = chunk_of(sr)
+    ctx_t = torch.zeros((B, n // 8), device=dev) if ctx is None else torch.as_tensor(ctx).to(dev).clone()
+    st_t = torch.zeros((2, B, 128), device=dev) if state is None else torch.as_tensor(state).to(dev).clone()
+    probs = eng.forward_audio(x.contiguous(), sr, ctx_t, st_t)
+    torch.cuda.synchronize()
+    return probs.cpu().numpy(), ctx_t.cpu().numpy(), st_t.cpu().numpy()
+
+
+# ---- (0) the slow on-device reference implementation, then the MFMA frontend in isolation ---------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_impl_reference_matches_oracle(model, oracle, golden, tag):
+    sr, g = SRS[tag], golden[tag]
+    B, T, L, stride = (int(v) for v in g["batch_meta"])
+    rows = rolled_rows(g["wav"], B, L, stride)
+    model.engine.set_option("impl", "reference")
+    try:
+        probs, ctx, st = run_engine(model, rows, sr)
+    finally:
+        model.engine.set_option("impl", "mfma")
+    want, wctx, wst = oracle.forward_audio(rows, sr)
+    assert np.abs(probs - want).max() < TIGHT
+    assert np.abs(probs - g["probs_batch"]).max() < TIGHT
+    assert state_err(st, wst) < TOL and np.array_equal(ctx, wctx)
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_frontend_gate_preactivations(model, oracle, golden, tag):
+    """STFT + encoder + W_ih GEMM (kernel_front.hip) against the oracle's encoder output pushed
+    through W_ih in float64."""
+    from oracle.weights import read_container
+    from silero_vad_amd import _lib
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    B, T = 19, 5
+    rows = rolled_rows(g["wav"], B, T * n, 5003)
+    x = torch.from_numpy(rows).to(model.device)
+    ctx = torch.zeros((B, n // 8), device=model.device)
+    gx = model.engine.debug_frontend(x, sr, ctx).cpu().numpy()            # [B][T][512]
+    w = read_container(_lib.WEIGHTS_PATH.read_bytes())
+    pre = "_model" if sr == 16000 else "_model_8k"
+    w_ih = w[pre + ".decoder.rnn.weight_ih"].astype(np.float64)
+    bias = (w[pre + ".decoder.rnn.bias_ih"] + w[pre + ".decoder.rnn.bias_hh"]).astype(np.float64)
+    C = n // 8
+    for t in range(T):
+        prev = rows[:, t * n - C: t * n] if t else np.zeros((B, C), np.float32)
+        x1 = np.concatenate([prev, rows[:, t * n:(t + 1) * n]], 1)
+        _, _, st = oracle.step(x1, np.zeros((2, B, 128), np.float32), sr, stages=True)
+        want = st["enc3"][:, :, 0].astype(np.float64) @ w_ih.T + bias
+        err = np.abs(gx[:, t] - want).max()
+        assert err < 1e-4 * max(1.0, np.abs(want).max()), (t, err)
+
+
+# ---- (1) golden vectors from the reference ----------------------------------------------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_wav_protocol_and_segments(model, golden, tag):
+    from silero_vad_amd import get_speech_timestamps
+    sr, g = SRS[tag], golden[tag]
+    wav = torch.from_numpy(g["wav"])
+    probs = model.audio_forward(wav, sr).numpy()[0]
+    err = np.abs(probs - g["probs_wav"]).max()
+    assert err < TOL, err
+    assert err < TIGHT, f"within contract but looser than expected: {err}"
+    assert state_err(model._state.cpu().numpy(), g["state_wav"]) < TOL
+    assert np.array_equal(model._context.cpu().numpy(), g["ctx_wav"])
+    # decision margins: how far the closest probability is from the thresholds
+    margin = min(np.abs(g["probs_wav"] - 0.5).min(), np.abs(g["probs_wav"] - 0.35).min())
+    assert margin > 10 * err
+    assert len(kat_segments(probs)) == {"16k": 29, "8k": 79}[tag]        # published known answers
+    info = golden["segments"][tag]["timestamps"]
+    for name, rec in info.items():
+        kw = dict(rec["kwargs"])
+        kw.setdefault("sampling_rate", sr)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = get_speech_timestamps(wav, model, **kw)
+        assert got == rec["out"], f"{tag}/{name}: segments differ from the reference"
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_synth_protocol_per_chunk_calls(model, golden, tag):
+    """examples/openvino/verify.py protocol through the stateful model(chunk, sr) boundary."""
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    syn = torch.from_numpy(synthetic_audio(sr, np.random.default_rng(42)))
+    model.reset_states()
+    probs = [model(syn[s:s + n], sr).item() for s in range(0, (len(syn) // n) * n, n)]
+    assert np.abs(np.asarray(probs, np.float32) - g["probs_synth"]).max() < TIGHT
+    assert state_err(model._state.cpu().numpy(), g["state_synth"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_noise_protocol_explicit_state(model, golden, tag):
+    """examples/onnx_sequence/run.py:159-216 protocol: random initial state, probs AND final state."""
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    noise = (np.random.default_rng(17 + sr).standard_normal(round(8.0 * sr)) * 0.03).astype(np.float32)
+    L = (len(noise) // n) * n
+    probs, _, st = run_engine(model, noise[None, :L], sr, state=g["state_noise_init"])
+    assert np.abs(probs[0] - g["probs_noise"]).max() < TIGHT
+    assert state_err(st, g["state_noise_final"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_batch_ragged_audio_forward(model, golden, tag):
+    sr, g = SRS[tag], golden[tag]
+    B, T, L, stride = (int(v) for v in g["batch_meta"])
+    rows = rolled_rows(g["wav"], B, L, stride)
+    probs = model.audio_forward(torch.from_numpy(rows), sr).numpy()
+    assert probs.shape == (B, T)
+    assert np.abs(probs - g["probs_batch"]).max() < TIGHT
+    assert state_err(model._state.cpu().numpy(), g["state_batch"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_vad_iterator_events(model, golden, tag):
+    from silero_vad_amd import VADIterator
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    wav = torch.from_numpy(g["wav"][: 600 * n])
+    rec = golden["segments"][tag]["iterator"]["default"]
+    it = VADIterator(model, sampling_rate=sr)
+    ev = [e for s in range(0, len(wav), n) if (e := it(wav[s:s + n]))]
+    limit = 600 * n
+    want = [e for e in rec["events"] if list(e.values())[0] <= limit]
+    assert ev[:len(want) - 1] == want[:len(want) - 1]
+    assert len(ev) >= len(want) - 1 and len(ev) > 4
+
+
+# ---- (2) oracle on seeded inputs: shapes and entry points the goldens do not cover -------------------
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (16, 1), (17, 3), (33, 9), (64, 4)])
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_batch_shapes_vs_oracle(model, oracle, golden, tag, B, T):
+    sr = SRS[tag]
+    n = chunk_of(sr)
+    rows = rolled_rows(golden[tag]["wav"], B, T * n, 3571)
+    rng = np.random.default_rng(B * 100 + T)
+    st0 = (rng.standard_normal((2, B, 128)) * 0.3).astype(np.float32)
+    cx0 = (rng.standard_normal((B, n // 8)) * 0.05).astype(np.float32)
+    probs, ctx, st = run_engine(model, rows, sr, state=st0, ctx=cx0)
+    want, wctx, wst = oracle.forward_audio(rows, sr, ctx=cx0, state=st0)
+    assert np.abs(probs - want).max() < TIGHT
+    assert state_err(st, wst) < TOL
+    assert np.array_equal(ctx, wctx)
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_step_chain_equals_forward_audio(model, oracle, golden, tag):
+    sr = SRS[tag]
+    n = chunk_of(sr)
+    B, T = 5, 40
+    rows = rolled_rows(golden[tag]["wav"], B, T * n, 9001)
+    model.reset_states()
+    per_step = np.concatenate([model(torch.from_numpy(rows[:, t * n:(t + 1) * n]), sr).cpu().numpy()
+                               for t in range(T)], 1)
+    whole = model.audio_forward(torch.from_numpy(rows), sr).numpy()
+    want = oracle.audio_forward(rows, sr)
+    assert np.abs(per_step - want).max() < TIGHT and np.abs(whole - want).max() < TIGHT
+    assert np.abs(per_step - whole).max() < 1e-6        # same kernels, same order of operations
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_carried_state_across_calls(model, golden, tag):
+    """ctx/state written by one call feed the next: 8 chunks == 4 + 4 (exercises ctx_out and the
+    in-place state update, and the zero-padded tail chunk)."""
+    sr = SRS[tag]
+    n = chunk_of(sr)
+    B = 7
+    rows = rolled_rows(golden[tag]["wav"], B, 8 * n - 37, 6007)
+    whole, ctx_w, st_w = run_engine(model, rows, sr)
+    a, ctx_a, st_a = run_engine(model, rows[:, :4 * n], sr)
+    b, ctx_b, st_b = run_engine(model, rows[:, 4 * n:], sr, state=st_a, ctx=ctx_a)
+    assert np.array_equal(np.concatenate([a, b], 1), whole)
+    assert np.array_equal(st_b, st_w) and np.array_equal(ctx_b, ctx_w)
+    tail = np.concatenate([rows[:, -(n // 8 - 37):], np.zeros((B, 37), np.float32)], 1) \
+        if n // 8 > 37 else None
+    if tail is not None:
+        assert np.array_equal(ctx_w, tail)              # context = last C samples of the PADDED chunk
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_int16_ingest(model, golden, tag):
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    B, L = 4, 50 * n + 5
+    rows_i = np.stack([np.roll(g["pcm_i16"], -b * 4001)[:L] for b in range(B)])
+    p_i, c_i, s_i = run_engine(model, rows_i, sr)
+    p_f, c_f, s_f = run_engine(model, rows_i.astype(np.float32) / 32768.0, sr)
+    assert np.array_equal(p_i, p_f) and np.array_equal(s_i, s_f) and np.array_equal(c_i, c_f)
+
+
+def test_misaligned_rows_are_handled(model, oracle, golden):
+    sr, n = 16000, 512
+    B, L = 3, 6 * n + 3                                   # odd row stride -> rows not 16-B aligned
+    rows = rolled_rows(golden["16k"]["wav"], B, L, 1237)
+    big = torch.zeros((B, L + 1), device=model.device)
+    view = big[:, 1:]                                     # offset view: base pointer misaligned too
+    view.copy_(torch.from_numpy(rows))
+    ctx = torch.zeros((B, 64), device=model.device)
+    st = torch.zeros((2, B, 128), device=model.device)
+    from silero_vad_amd._lib import check, lib
+    T = (L + n - 1) // n
+    probs = torch.empty((B, T), device=model.device)
+    check(model.engine._h, lib().vad_forward_audio(model.engine._h, sr, B, L, view.data_ptr(), view.stride(0),
+                                                   ctx.data_ptr(), st.data_ptr(), probs.data_ptr(), T, None))
+    torch.cuda.synchronize()
+    want, _, _ = oracle.forward_audio(rows, sr)
+    assert np.abs(probs.cpu().numpy() - want).max() < TIGHT
+
+
+def test_c_abi_error_paths(model):
+    from silero_vad_amd._lib import VadError, lib
+    eng = model.engine
+    x = torch.zeros((2, 512), device=model.device)
+    ctx = torch.zeros((2, 64), device=model.device)
+    st = torch.zeros((2, 2, 128), device=model.device)
+    out = torch.zeros((2, 1), device=model.device)
+    with pytest.raises(VadError, match="SAMPLE_RATE"):
+        eng.forward_audio(x, 44100, ctx, st)
+    with pytest.raises(VadError, match="OPTION"):
+        eng.set_option("impl", "nope")
+    rc = lib().vad_forward_audio(eng._h, 16000, 2, 512, x.data_ptr(), 512, ctx.data_ptr() + 4, st.data_ptr(),
+                                 out.data_ptr(), 1, None)
+    assert rc == 1 and b"aligned" in lib().vad_last_error(eng._h)
+    # empty work is a no-op
+    assert lib().vad_forward_audio(eng._h, 16000, 0, 512, None, 512, None, None, None, 1, None) == 0
+    assert lib().vad_forward_audio(eng._h, 16000, 2, 0, x.data_ptr(), 0, ctx.data_ptr(), st.data_ptr(),
+                                   out.data_ptr(), 0, None) == 0
+
+
+# ---- (3) full-size properties (BASELINE.json config[1]/[2]: 4096 streams) -----------------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_full_batch_properties(model, oracle, golden, tag):
+    sr = SRS[tag]
+    n = chunk_of(sr)
+    B, T = 4096, 24
+    wav = torch.from_numpy(golden[tag]["wav"]).to(model.device)
+    idx = (torch.arange(B, device=model.device)[:, None] * 7919 + torch.arange(T * n, device=model.device)[None]) % len(wav)
+    x = wav[idx].contiguous()                             # stream b = circular read from offset b*7919
+
+    def run(inp):
+        ctx = torch.zeros((inp.shape[0], n // 8), device=model.device)
+        st = torch.zeros((2, inp.shape[0], 128), device=model.device)
+        p = model.engine.forward_audio(inp, sr, ctx, st)
+        torch.cuda.synchronize()
+        return p, st
+
+    p1, s1 = run(x)
+    p2, s2 = run(x)
+    assert torch.equal(p1, p2) and torch.equal(s1, s2)                    # deterministic
+    perm = torch.randperm(B, device=model.device, generator=torch.Generator(model.device).manual_seed(1))
+    p3, s3 = run(x[perm].contiguous())
+    assert torch.equal(p3, p1[perm]) and torch.equal(s3, s1[:, perm])     # streams are independent
+    assert torch.isfinite(p1).all() and (p1 >= 0).all() and (p1 <= 1).all()
+    sub = slice(0, 64)                                                    # parity subset vs the oracle
+    want, _, wst = oracle.forward_audio(x[sub].cpu().numpy(), sr)
+    assert np.abs(p1[sub].cpu().numpy() - want).max() < TIGHT
+    assert state_err(s1[:, sub].cpu().numpy(), wst) < TOL
+    far = slice(4000, 4032)
+    want, _, _ = oracle.forward_audio(x[far].cpu().numpy(), sr)
+    assert np.abs(p1[far].cpu().numpy() - want).max() < TIGHT
+    assert float((p1 > 0.5).float().mean()) > 0.3                         # real speech: not a saturated test
+
+
+def test_profile_option_reports_kernel_times(model, golden):
+    eng = model.engine
+    x = torch.from_numpy(rolled_rows(golden["16k"]["wav"], 64, 16 * 512)).to(model.device)
+    ctx = torch.zeros((64, 64), device=model.device)
+    st = torch.zeros((2, 64, 128), device=model.device)
+    eng.set_option("profile", "1")
+    try:
+        eng.forward_audio(x, 16000, ctx, st)
+        eng.forward_audio(x, 16000, ctx, st)
+        f, r, calls = eng.kernel_times()
+    finally:
+        eng.set_option("profile", "0")
+    assert f > 0 and r > 0 and calls == 2

@@ -1,0 +1,64 @@
+"""Lane-accurate emulation (tests/emu_wave.py) of the MFMA wave programs, run on the packed weight
+images the C++ packer really produces, against activations recorded from the reference model.
+Pins -- without a GPU -- the fragment packing, the K-permutation ("chain layout") trick, the
+4-lane cooperative FFT algebra and the persistent-RNN data flow."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import emu_wave as E
+from conftest import SRS, state_err
+
+
+@pytest.fixture(scope="module")
+def packed(built):
+    from silero_vad_amd import _lib
+    L = _lib.lib()
+    blob = _lib.WEIGHTS_PATH.read_bytes()
+    h = ctypes.c_void_p()
+    assert L.vad_create_host_only(blob, len(blob), ctypes.byref(h)) == 0
+    out = {}
+    for sr in (16000, 8000):
+        for which in range(3):
+            n = L.vad_debug_packed_floats(h, sr, which)
+            a = np.empty(n, np.float32)
+            assert L.vad_debug_packed_copy(h, sr, which, a.ctypes.data_as(_lib.f32p), n) == 0
+            out[sr, which] = a
+    L.vad_destroy(h)
+    return out
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_wave_program_matches_reference_activations(packed, golden, tag):
+    sr, g = SRS[tag], golden[tag]
+    emu = E.FrontEmu(sr, packed[sr, 0], packed[sr, 2])
+    out = emu.run(g["stage_x"])
+    Q = emu.Q
+    mag = np.stack([E.mag_from_layout(out["X"][v], Q) for v in range(4)], -1)       # [16][K][4]
+    ref = g["stage_mag"]
+    assert np.abs(mag - ref).max() < 2e-6 * max(1.0, np.abs(ref).max()) + 2e-6
+    feat = E.chain_to_dense(out["feat"])
+    ref = g["stage_enc3"][:, :, 0]
+    assert np.abs(feat - ref).max() < 3e-5
+    prob, hn, cn = E.rec_step(packed[sr, 1], packed[sr, 2], emu.tb, out["gx"],
+                              g["stage_state_in"][0], g["stage_state_in"][1])
+    assert np.abs(prob - g["stage_prob"][:, 0]).max() < 1e-5
+    assert state_err(np.stack([hn, cn]), g["stage_state_out"]) < 2e-5
+
+
+def test_mfma_emulation_is_transpose_detecting():
+    """Asymmetric operands: a swapped A/B or row/col map in the emulator would not reproduce A @ B."""
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((16, 4)).astype(np.float32)
+    B = rng.standard_normal((4, 16)).astype(np.float32)
+    a = np.zeros(64, np.float32)
+    b = np.zeros(64, np.float32)
+    for lane in range(64):
+        a[lane] = A[lane & 15, lane >> 4]
+        b[lane] = B[lane >> 4, lane & 15]
+    acc = E.mfma_16x16x4(a, b, np.zeros((4, 64), np.float32))
+    D = A @ B
+    for lane in range(64):
+        for r in range(4):
+            assert abs(acc[r, lane] - D[4 * (lane >> 4) + r, lane & 15]) < 1e-5

@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: stream sharding + host-side gather with the gloo backend, world_size 2.
+The per-rank engine is replaced by a stand-in built on the CPU oracle (tests may use the oracle;
+the product never does) -- what is under test is the partition/gather logic, which has no
+data-path collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_shard_range_partitions():
+    from silero_vad_amd import shard_range
+    for n in (0, 1, 7, 8, 4096, 4099):
+        for w in (1, 2, 3, 8):
+            got = [i for r in range(w) for i in shard_range(n, w, r)]
+            assert got == list(range(n))
+            sizes = [len(shard_range(n, w, r)) for r in range(w)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+class OracleModel:
+    """Stand-in engine for CPU tests: model protocol + audio_forward_device over the oracle."""
+
+    def __init__(self):
+        from oracle import Oracle
+        self.o = Oracle()
+
+    def reset_states(self):
+        self.o.reset_states()
+
+    def __call__(self, x, sr):
+        return torch.from_numpy(self.o(x.numpy(), sr))
+
+    def audio_forward_device(self, x, sr):
+        return torch.from_numpy(self.o.audio_forward(x.numpy(), sr))
+
+
+def _audios():
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "audio_16k.npz"))["pcm"]
+    wav = gold.astype(np.float32) / 32768.0
+    lens = [40000, 40000, 25000, 40000, 33333, 25000, 16000]
+    return [torch.from_numpy(wav[i * 50000: i * 50000 + n].copy()) for i, n in enumerate(lens)]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from silero_vad_amd import batch_speech_timestamps
+    res = batch_speech_timestamps(_audios(), OracleModel(), rank=rank, world_size=world, threshold=0.4)
+    if rank == 0:
+        q.put(res)
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_matches_single_process(built):
+    from silero_vad_amd import batch_speech_timestamps, get_speech_timestamps
+    audios = _audios()
+    single = batch_speech_timestamps(audios, OracleModel(), threshold=0.4)
+    direct = [get_speech_timestamps(a, OracleModel(), threshold=0.4) for a in audios]
+    assert single == direct
+    assert sum(len(s) for s in single) > 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert got == single
