@@ -82,13 +82,15 @@ class Engine:
         fn = lib().vad_forward_audio if pcm.dtype == torch.float32 else lib().vad_forward_audio_i16
         if pcm.dtype not in (torch.float32, torch.int16):
             raise TypeError(f"pcm dtype must be float32 or int16, got {pcm.dtype}")
-        check(self._h, fn(self._h, sr, B, L, pcm.data_ptr(), pcm.stride(0), ctx.data_ptr(),
-                          state.data_ptr(), probs.data_ptr(), probs.stride(0), self._stream()))
+        ld = pcm.stride(0) if B > 1 else L          # a size-1 dim may carry any stride (e.g. 0)
+        ldp = probs.stride(0) if B > 1 else T
+        check(self._h, fn(self._h, sr, B, L, pcm.data_ptr(), ld, ctx.data_ptr(),
+                          state.data_ptr(), probs.data_ptr(), ldp, self._stream()))
         return probs
 
     def step(self, pcm, sr, ctx, state, prob):
         B = pcm.shape[0]
-        check(self._h, lib().vad_step(self._h, sr, B, pcm.data_ptr(), pcm.stride(0), ctx.data_ptr(),
+        check(self._h, lib().vad_step(self._h, sr, B, pcm.data_ptr(), pcm.stride(0) if B > 1 else pcm.shape[1], ctx.data_ptr(),
                                       state.data_ptr(), prob.data_ptr(), self._stream()))
         return prob
 
@@ -96,7 +98,7 @@ class Engine:
         B, L = pcm.shape
         n = 512 if sr == 16000 else 256
         gx = torch.empty((B, L // n, 512), dtype=torch.float32, device=pcm.device)
-        check(self._h, lib().vad_debug_frontend(self._h, sr, B, L, pcm.data_ptr(), pcm.stride(0),
+        check(self._h, lib().vad_debug_frontend(self._h, sr, B, L, pcm.data_ptr(), pcm.stride(0) if B > 1 else L,
                                                 ctx.data_ptr(), gx.data_ptr(), self._stream()))
         return gx
 
