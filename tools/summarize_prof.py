@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/prof/<pass>/...) into small tracked files
+under profiles/: per-kernel duration stats and per-kernel PMC means.
+
+    python tools/summarize_prof.py gpurun_out/prof profiles/r01
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+
+def short(name):
+    for key in ("front_kernel", "rec_kernel", "ref_forward_kernel", "unpack_gx"):
+        if key in name:
+            return name[name.index(key):].split("(")[0]
+    return None
+
+
+def main(src, dst_prefix):
+    src = Path(src)
+    out = {"kernel_trace": {}, "pmc": {}}
+    lines = ["# rocprofv3 summary (" + dst_prefix + ")", ""]
+    for f in glob.glob(str(src / "trace" / "**" / "*_kernel_stats.csv"), recursive=True):
+        lines += ["## --kernel-trace --stats (engine kernels only)", "",
+                  "| kernel | calls | avg ms | min ms | max ms | % of GPU time |", "|---|---|---|---|---|---|"]
+        for r in csv.DictReader(open(f)):
+            k = short(r["Name"])
+            if not k:
+                continue
+            out["kernel_trace"][k] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                      "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
+                                      "pct": float(r["Percentage"])}
+            t = out["kernel_trace"][k]
+            lines.append(f"| {k} | {t['calls']} | {t['avg_ms']:.4f} | {t['min_ms']:.4f} | {t['max_ms']:.4f} | {t['pct']:.2f} |")
+        lines.append("")
+    for f in sorted(glob.glob(str(src / "*" / "**" / "*_counter_collection.csv"), recursive=True)):
+        agg = collections.defaultdict(list)
+        meta = {}
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not k:
+                continue
+            agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            meta[k] = {x: r[x] for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
+                                         "Scratch_Size", "Grid_Size", "Workgroup_Size")}
+        for (k, c), v in sorted(agg.items()):
+            out["pmc"].setdefault(k, {})[c] = sum(v) / len(v)
+        for k, m in meta.items():
+            out.setdefault("dispatch", {})[k] = m
+    if out["pmc"]:
+        lines += ["## --pmc passes (mean per dispatch)", "", "| kernel | counter | mean |", "|---|---|---|"]
+        for k, cs in out["pmc"].items():
+            for c, v in cs.items():
+                lines.append(f"| {k} | {c} | {v:.6g} |")
+        lines.append("")
+    for log in sorted(src.glob("*.log")):
+        for line in open(log, errors="ignore"):
+            if line.startswith('{"metric"'):
+                d = json.loads(line)
+                out.setdefault("bench_lines", {})[log.stem] = {k: d[k] for k in ("value", "ms_per_step", "kernel_ms")}
+    if "bench_lines" in out:
+        lines += ["## bench.py line printed inside each profiled run (hipEvent timing, same process)", ""]
+        for k, v in out["bench_lines"].items():
+            lines.append(f"- {k}: {json.dumps(v)}")
+        lines.append("")
+    Path(dst_prefix + "_summary.md").write_text("\n".join(lines))
+    Path(dst_prefix + "_summary.json").write_text(json.dumps(out, indent=1))
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
