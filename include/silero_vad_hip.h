@@ -125,6 +125,17 @@ void vad_segment_params_default(vad_segment_params *p, int sampling_rate);
 long vad_segment_probs(const float *probs, long n, long audio_len, const vad_segment_params *p,
                        vad_segment *out, long cap);
 
+/* The same scan for many independent streams (one row of probs per stream, row stride `ldp`,
+ * n_chunks[i] valid entries, audio of audio_len[i] samples): what a corpus run does after
+ * vad_forward_audio (the reference fans this out as one Python process per file,
+ * examples/parallel_example.ipynb cells 5, 7).  Stream i's segments go to
+ * out[i * cap_per_stream ...], their number (may exceed cap_per_stream) to counts[i].  Streams are
+ * split over `threads` host threads (<= 0: all hardware threads).  Returns the total number of
+ * segments, <0 on bad arguments.                                                                */
+long vad_segment_probs_batch(const float *probs, long ldp, long n_streams, const long *n_chunks,
+                             const long *audio_len, const vad_segment_params *p, vad_segment *out,
+                             long cap_per_stream, long *counts, int threads);
+
 /* ---- test / bring-up hooks (not part of the drop-in surface) -------------------------------------
  * Host-only: size and contents of the packed weight images the kernels consume, so CPU tests can
  * check the fragment packing without a GPU.  which: 0 = frontend GEMM stream, 1 = recurrent

@@ -48,6 +48,9 @@ SYMBOLS = {
     "vad_kernel_times": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_long)]),
     "vad_segment_params_default": (None, [POINTER(SegmentParams), c_int]),
     "vad_segment_probs": (c_long, [f32p, c_long, c_long, POINTER(SegmentParams), POINTER(Segment), c_long]),
+    "vad_segment_probs_batch": (c_long, [f32p, c_long, c_long, POINTER(c_long), POINTER(c_long),
+                                         POINTER(SegmentParams), POINTER(Segment), c_long,
+                                         POINTER(c_long), c_int]),
     "vad_debug_packed_floats": (c_long, [c_void_p, c_int, c_int]),
     "vad_debug_packed_copy": (c_int, [c_void_p, c_int, c_int, f32p, c_long]),
     "vad_create_host_only": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../include/silero_vad_hip.h"
@@ -179,4 +180,40 @@ extern "C" long vad_segment_probs(const float *probs, long n, long audio_len,
     const long m = (long)segs.size();
     for (long i = 0; i < std::min(m, cap); ++i) out[i] = segs[(size_t)i];
     return m;
+}
+
+// Many streams at once: probs[i * ldp + t], t < n_chunks[i]; stream i's segments are written to
+// out[i * cap_per_stream ...] and their number (may exceed cap_per_stream) to counts[i].  Streams
+// are independent, so they are split over `threads` host threads (<= 0: hardware concurrency).
+extern "C" long vad_segment_probs_batch(const float *probs, long ldp, long n_streams,
+                                        const long *n_chunks, const long *audio_len,
+                                        const vad_segment_params *p, vad_segment *out,
+                                        long cap_per_stream, long *counts, int threads) {
+    if (!p || n_streams < 0 || ldp < 0 || cap_per_stream < 0) return -1;
+    if (n_streams > 0 && (!probs || !n_chunks || !audio_len || !counts)) return -1;
+    if (cap_per_stream > 0 && !out) return -1;
+    if (p->sampling_rate != 8000 && p->sampling_rate != 16000) return -2;
+    for (long i = 0; i < n_streams; ++i)
+        if (n_chunks[i] < 0 || n_chunks[i] > ldp || audio_len[i] < 0) return -1;
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = (int)std::max<long>(1, std::min<long>(nt, n_streams / 64 + 1));
+    auto work = [&](long lo, long hi) {
+        for (long i = lo; i < hi; ++i)
+            counts[i] = vad_segment_probs(probs + i * ldp, n_chunks[i], audio_len[i], p,
+                                          out ? out + i * cap_per_stream : nullptr, cap_per_stream);
+    };
+    if (nt == 1) {
+        work(0, n_streams);
+    } else {
+        std::vector<std::thread> pool;
+        const long per = (n_streams + nt - 1) / nt;
+        for (int k = 0; k < nt; ++k) {
+            const long lo = k * per, hi = std::min(n_streams, lo + per);
+            if (lo < hi) pool.emplace_back(work, lo, hi);
+        }
+        for (auto &th : pool) th.join();
+    }
+    long total = 0;
+    for (long i = 0; i < n_streams; ++i) total += counts[i];
+    return total;
 }

@@ -39,29 +39,57 @@ def gather_to_rank0(obj, group=None):
 
 def batch_speech_timestamps(audios: Sequence[torch.Tensor], model, sampling_rate: int = 16000,
                             rank: int = 0, world_size: int = 1, **kwargs) -> List[list]:
-    """`get_speech_timestamps` over many recordings: this rank processes its shard, equal-length
-    recordings going through the GPU as one lock-step batch; rank 0 receives every result in input
-    order (other ranks get None).  kwargs are those of get_speech_timestamps."""
-    from .timestamps import get_speech_timestamps, segment_probs
+    """`get_speech_timestamps` over many recordings (the reference's pattern is one worker process
+    per file, examples/parallel_example.ipynb cells 5, 7): this rank processes its contiguous
+    shard -- recordings of any lengths are bucketed into lock-step GPU batches by
+    `streams.ragged_probs` and segmented by the native batch scanner -- and rank 0 receives every
+    result in input order (other ranks get None).  kwargs are those of get_speech_timestamps."""
+    import warnings
 
-    mine = shard_range(len(audios), world_size, rank)
+    from .streams import chunk_size, ragged_probs, segment_probs_batch
+    from .timestamps import get_speech_timestamps
+
+    mine = list(shard_range(len(audios), world_size, rank))
     results = {}
-    by_len = {}
-    for i in mine:
-        by_len.setdefault(len(audios[i]), []).append(i)
+    scan_kw = {k: kwargs[k] for k in kwargs if k not in ("return_seconds", "time_resolution",
+                                                         "visualize_probs", "progress_tracking_callback",
+                                                         "window_size_samples")}
     fast = getattr(model, "audio_forward_device", None)
-    plain = {k: kwargs[k] for k in kwargs if k not in ("return_seconds", "time_resolution",
-                                                       "visualize_probs", "progress_tracking_callback",
-                                                       "window_size_samples")}
-    for length, idxs in by_len.items():
-        if fast is None or len(idxs) == 1 or kwargs.get("return_seconds") or sampling_rate > 16000:
-            for i in idxs:
-                results[i] = get_speech_timestamps(audios[i], model, sampling_rate=sampling_rate, **kwargs)
-            continue
-        batch = torch.stack([torch.as_tensor(audios[i], dtype=torch.float32) for i in idxs])
-        probs = fast(batch, sampling_rate).cpu()
-        for row, i in enumerate(idxs):
-            results[i] = segment_probs(probs[row], length, sampling_rate, **plain)
+    if fast is None or kwargs.get("visualize_probs") or kwargs.get("progress_tracking_callback"):
+        for i in mine:
+            results[i] = get_speech_timestamps(audios[i], model, sampling_rate=sampling_rate, **kwargs)
+    elif mine:
+        step, sr = 1, sampling_rate
+        if sr > 16000 and sr % 16000 == 0:                 # utils_vad.py:301-307
+            step, sr = sr // 16000, 16000
+            warnings.warn('Sampling rate is a multiply of 16000, casting to 16000 manually!')
+        n = chunk_size(sr)
+        local = []
+        for i in mine:
+            a = audios[i] if torch.is_tensor(audios[i]) else torch.as_tensor(audios[i])
+            while a.dim() > 1 and a.shape[0] == 1:
+                a = a.squeeze(0)
+            local.append(a[::step] if step > 1 else a)
+        probs = ragged_probs(local, model, sr)
+        lens = [int(a.shape[0]) for a in local]
+        T = max((len(p) for p in probs), default=0)
+        table = torch.zeros((len(local), max(T, 1)), dtype=torch.float32)
+        for r, p in enumerate(probs):
+            table[r, : len(p)] = p
+        segs = segment_probs_batch(table, [(m + n - 1) // n for m in lens], lens, sr, **scan_kw)
+        seconds, res = kwargs.get("return_seconds", False), kwargs.get("time_resolution", 1)
+        for r, i in enumerate(mine):
+            out = segs[r]
+            if seconds:                                    # utils_vad.py:442-446
+                total = lens[r] / sr
+                for seg in out:
+                    seg["start"] = max(round(seg["start"] / sr, res), 0)
+                    seg["end"] = min(round(seg["end"] / sr, res), total)
+            elif step > 1:                                 # utils_vad.py:447-450
+                for seg in out:
+                    seg["start"] *= step
+                    seg["end"] *= step
+            results[i] = out
     gathered = gather_to_rank0(results)
     if gathered is None:
         return None

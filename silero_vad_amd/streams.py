@@ -1,0 +1,310 @@
+"""Many streams at once: the two callers BASELINE.json's configs name on top of the engine.
+
+* ``ragged_probs`` / ``RaggedPlan`` -- offline corpora (configs[3]).  ``audio_forward`` assumes
+  equal-length rows (JIT!/vad/model/vad_annotator.py:141-148); real corpora are ragged.  The
+  network is causal (a chunk's probability depends only on samples up to the end of that chunk,
+  and the reference right-pads the last partial chunk with zeros, :141-148), so a recording that
+  is right-padded with zeros to its bucket's length yields bit-identical probabilities for its
+  own ceil(len / N) chunks.  The plan sorts recordings by length and cuts buckets so that padding
+  waste and bytes per GPU call stay bounded; each bucket is one lock-step ``vad_forward_audio``
+  call fed from pinned host staging (int16 halves the PCIe bytes).
+
+* ``StreamPool`` -- live streams (configs[4]).  Per-stream LSTM state and context stay resident
+  in HBM (the resumable unit of the reference model object, vad_annotator.py:7-8,72,87); one
+  hipGraph-captured ``vad_step`` serves every open stream per 32 ms tick; streams are opened and
+  closed by slot, a fresh slot starting from zero state like ``reset_states()`` (:157-162).
+
+* ``BatchVADIterator`` -- the reference's streaming event logic (``VADIterator``,
+  src/silero_vad/utils_vad.py:507-549) for all slots of a pool at once, vectorised on the host.
+"""
+import ctypes
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib
+
+
+def chunk_size(sr: int) -> int:
+    if sr not in (8000, 16000):
+        raise ValueError("Supported sampling rates: [8000, 16000] (or multiply of 16000)")
+    return 512 if sr == 16000 else 256
+
+
+# ---- offline: ragged corpora ------------------------------------------------------------------------
+class RaggedPlan:
+    """Buckets of recording indices, each processed as one lock-step batch.
+
+    ``lengths`` in samples.  A bucket holds recordings whose zero-padding to the bucket's longest
+    member wastes at most ``max_waste`` of the bucket's samples, and at most ``max_bytes`` of
+    staged PCM (``itemsize`` bytes per sample)."""
+
+    def __init__(self, lengths: Sequence[int], max_waste: float = 0.15, max_bytes: int = 1 << 30,
+                 itemsize: int = 4):
+        self.lengths = [int(n) for n in lengths]
+        order = sorted((i for i, n in enumerate(self.lengths) if n > 0),
+                       key=lambda i: self.lengths[i], reverse=True)
+        self.empty = [i for i, n in enumerate(self.lengths) if n <= 0]
+        self.buckets: List[List[int]] = []
+        cur, cur_max, cur_sum = [], 0, 0
+        for i in order:                                   # descending: bucket max = its first member
+            n = self.lengths[i]
+            if cur:
+                padded = cur_max * (len(cur) + 1)
+                waste = 1.0 - (cur_sum + n) / padded
+                if waste > max_waste or padded * itemsize > max_bytes:
+                    self.buckets.append(cur)
+                    cur, cur_max, cur_sum = [], 0, 0
+            if not cur:
+                cur_max = n
+            cur.append(i)
+            cur_sum += n
+        if cur:
+            self.buckets.append(cur)
+
+    def padded_samples(self) -> int:
+        return sum(self.lengths[b[0]] * len(b) for b in self.buckets)
+
+    def real_samples(self) -> int:
+        return sum(n for n in self.lengths if n > 0)
+
+
+def _stage(audios, idxs, width, dtype, pinned):
+    """Pack recordings `idxs` into one zero-padded [len(idxs), width] host tensor."""
+    host = torch.zeros((len(idxs), width), dtype=dtype, pin_memory=pinned)
+    for row, i in enumerate(idxs):
+        a = audios[i]
+        a = a if torch.is_tensor(a) else torch.as_tensor(a)
+        if a.dim() != 1:
+            raise ValueError("More than one dimension in audio. Are you trying to process audio with 2 channels?")
+        if dtype == torch.int16 and a.dtype != torch.int16:
+            raise TypeError("mixed int16 / float recordings in one call")
+        host[row, : a.shape[0]] = a.to(dtype)
+    return host
+
+
+def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
+                 max_bytes: int = 1 << 30, plan: RaggedPlan = None) -> List[torch.Tensor]:
+    """Speech probabilities of many recordings of different lengths.
+
+    Returns one 1-D CPU float tensor per recording (ceil(len / N) entries), bit-identical to
+    ``model.audio_forward(audio[None], sr)[0]`` on that recording alone.  ``audios`` may be float
+    tensors in [-1, 1] or int16 PCM (all of one kind).  `model` needs ``audio_forward_device``
+    (HipSileroVAD); H2D copies of bucket k+1 overlap the kernels of bucket k."""
+    n = chunk_size(sampling_rate)
+    as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
+    dtype = torch.int16 if as_i16 else torch.float32
+    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
+    plan = plan or RaggedPlan(lengths, max_waste, max_bytes, 2 if as_i16 else 4)
+    out: List[torch.Tensor] = [torch.empty(0)] * len(audios)
+    fast = model.audio_forward_device
+    dev = getattr(model, "device", None)
+    on_gpu = dev is not None and torch.device(dev).type == "cuda"
+    copy_stream = torch.cuda.Stream(dev) if on_gpu else None
+    staged = None
+
+    def stage(k):
+        idxs = plan.buckets[k]
+        host = _stage(audios, idxs, plan.lengths[idxs[0]], dtype, on_gpu)
+        if not on_gpu:
+            return host, None
+        with torch.cuda.stream(copy_stream):
+            d = host.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        return (host, d), ev
+
+    pending = []
+    if plan.buckets:
+        staged = stage(0)
+    for k, idxs in enumerate(plan.buckets):
+        cur, ev = staged
+        staged = stage(k + 1) if k + 1 < len(plan.buckets) else None
+        if on_gpu:
+            torch.cuda.current_stream(dev).wait_event(ev)
+            x = cur[1]
+            x.record_stream(torch.cuda.current_stream(dev))
+        else:
+            x = cur
+        probs = fast(x, sampling_rate)
+        pending.append((idxs, probs))
+    for idxs, probs in pending:
+        p = probs.cpu()
+        for row, i in enumerate(idxs):
+            out[i] = p[row, : (lengths[i] + n - 1) // n].clone()
+    return out
+
+
+def segment_probs_batch(probs: torch.Tensor, n_chunks, audio_lengths, sampling_rate=16000, threshold=0.5,
+                        neg_threshold=None, min_speech_duration_ms=250,
+                        max_speech_duration_s=float("inf"), min_silence_duration_ms=100,
+                        speech_pad_ms=30, min_silence_at_max_speech=98,
+                        use_max_poss_sil_at_max_speech=True, threads=0) -> List[list]:
+    """`timestamps.segment_probs` for every row of probs[B, T] in one native call (host threads)."""
+    probs = torch.as_tensor(probs, dtype=torch.float32).contiguous().cpu()
+    B, T = probs.shape
+    p = _lib.SegmentParams()
+    lib().vad_segment_params_default(ctypes.byref(p), int(sampling_rate))
+    p.threshold = float(threshold)
+    p.neg_threshold = -1.0 if neg_threshold is None else float(neg_threshold)
+    p.min_speech_duration_ms = int(min_speech_duration_ms)
+    p.max_speech_duration_s = float(max_speech_duration_s)
+    p.min_silence_duration_ms = int(min_silence_duration_ms)
+    p.speech_pad_ms = int(speech_pad_ms)
+    p.min_silence_at_max_speech_ms = int(min_silence_at_max_speech)
+    p.use_max_poss_sil_at_max_speech = 1 if use_max_poss_sil_at_max_speech else 0
+    nck = np.ascontiguousarray(n_chunks, dtype=np.int64)
+    alen = np.ascontiguousarray(audio_lengths, dtype=np.int64)
+    if nck.shape != (B,) or alen.shape != (B,):
+        raise ValueError("n_chunks and audio_lengths need one entry per row of probs")
+    cap = T // 2 + 2
+    segs = np.zeros((B, cap, 2), dtype=np.int64)
+    counts = np.zeros(B, dtype=np.int64)
+    lp = ctypes.POINTER(ctypes.c_long)
+    rc = lib().vad_segment_probs_batch(
+        ctypes.cast(probs.data_ptr(), _lib.f32p) if B * T else None, T, B,
+        nck.ctypes.data_as(lp), alen.ctypes.data_as(lp), ctypes.byref(p),
+        ctypes.cast(segs.ctypes.data, ctypes.POINTER(_lib.Segment)), cap, counts.ctypes.data_as(lp),
+        int(threads))
+    if rc < 0:
+        raise ValueError("vad_segment_probs_batch: bad arguments" if rc == -1 else
+                         "Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates")
+    return [[{"start": int(s), "end": int(e)} for s, e in segs[i, : counts[i]]] for i in range(B)]
+
+
+# ---- live streams --------------------------------------------------------------------------------------
+class StreamPool:
+    """`capacity` concurrently live streams on one GPU, one `tick` per 32 ms chunk.
+
+    tick(chunks[capacity, N]) -> probs[capacity] (a CUDA tensor that is overwritten by the next
+    tick).  Rows of closed slots are computed too (lock-step batch) and ignored.  With
+    `graph=True` the step is captured once into a hipGraph and replayed; the input is then copied
+    into a fixed staging buffer first."""
+
+    def __init__(self, engine, sampling_rate: int = 16000, capacity: int = 8192, graph: bool = True):
+        self.engine = engine
+        self.sr = int(sampling_rate)
+        self.n = chunk_size(self.sr)
+        self.capacity = int(capacity)
+        self.device = torch.device("cuda", engine.device)
+        with torch.cuda.device(self.device):
+            self.ctx = torch.zeros((self.capacity, self.n // 8), device=self.device)
+            self.state = torch.zeros((2, self.capacity, 128), device=self.device)
+            self.pcm = torch.zeros((self.capacity, self.n), device=self.device)
+            self.prob = torch.zeros((self.capacity,), device=self.device)
+        self.open_mask = np.zeros(self.capacity, dtype=bool)
+        self._free = list(range(self.capacity - 1, -1, -1))
+        self._graph = None
+        engine.reserve(self.sr, self.capacity, 1)
+        if graph:
+            self._capture()
+
+    def _launch(self):
+        self.engine.step(self.pcm, self.sr, self.ctx, self.state, self.prob)
+
+    def _capture(self):
+        with torch.cuda.device(self.device):
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self._launch()                             # warm-up outside capture (lazy module load)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch()
+            self.ctx.zero_()                               # the warm-up step advanced them
+            self.state.zero_()
+            self._graph = g
+
+    # -- slots ---------------------------------------------------------------------------------------
+    def open(self) -> int:
+        """Admit a stream: returns its slot; the slot starts from zero state/context."""
+        if not self._free:
+            raise RuntimeError("StreamPool is full")
+        s = self._free.pop()
+        self.ctx[s].zero_()
+        self.state[:, s].zero_()
+        self.open_mask[s] = True
+        return s
+
+    def close(self, slot: int):
+        if not self.open_mask[slot]:
+            raise ValueError(f"slot {slot} is not open")
+        self.open_mask[slot] = False
+        self._free.append(int(slot))
+
+    def reset(self, slot: int):
+        self.ctx[slot].zero_()
+        self.state[:, slot].zero_()
+
+    # -- the tick --------------------------------------------------------------------------------------
+    def tick(self, chunks: torch.Tensor) -> torch.Tensor:
+        if chunks.shape != (self.capacity, self.n):
+            raise ValueError(f"expected chunks of shape {(self.capacity, self.n)}, got {tuple(chunks.shape)}")
+        with torch.cuda.device(self.device):
+            self.pcm.copy_(chunks, non_blocking=True)
+            self.tick_staged()
+        return self.prob
+
+    def tick_staged(self):
+        """One step over whatever `self.pcm` holds (for callers that write the staging buffer
+        themselves, e.g. a device-side audio source)."""
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._launch()
+        return self.prob
+
+
+class BatchVADIterator:
+    """`VADIterator` (src/silero_vad/utils_vad.py:458-549) for every slot of a lock-step batch.
+
+    feed(probs[B]) advances all streams by one chunk and returns the list of events of this tick as
+    (slot, {'start': n}) / (slot, {'end': n}) -- the same numbers the reference iterator emits for
+    that stream (`current_sample` counts chunk ENDS, exit threshold fixed at threshold - 0.15,
+    positions shifted back by one window, :526-547)."""
+
+    def __init__(self, batch: int, threshold: float = 0.5, sampling_rate: int = 16000,
+                 min_silence_duration_ms: int = 100, speech_pad_ms: int = 30):
+        if sampling_rate not in (8000, 16000):
+            raise ValueError("VADIterator does not support sampling rates other than [8000, 16000]")
+        self.threshold = threshold
+        self.sampling_rate = sampling_rate
+        self.window = chunk_size(sampling_rate)
+        self.min_silence_samples = sampling_rate * min_silence_duration_ms / 1000
+        self.speech_pad_samples = sampling_rate * speech_pad_ms / 1000
+        self.triggered = np.zeros(batch, dtype=bool)
+        self.temp_end = np.zeros(batch, dtype=np.int64)
+        self.current_sample = np.zeros(batch, dtype=np.int64)
+
+    def reset(self, slot=None):
+        sl = slice(None) if slot is None else slot
+        self.triggered[sl] = False
+        self.temp_end[sl] = 0
+        self.current_sample[sl] = 0
+
+    def feed(self, probs, active=None):
+        p = np.asarray(probs.detach().cpu() if torch.is_tensor(probs) else probs, dtype=np.float32).astype(np.float64)
+        act = np.ones(p.shape[0], dtype=bool) if active is None else np.asarray(active, dtype=bool)
+        win = self.window
+        self.current_sample[act] += win
+        loud = (p >= self.threshold) & act
+        self.temp_end[loud & (self.temp_end != 0)] = 0
+        starts = loud & ~self.triggered
+        self.triggered[starts] = True
+        events = []
+        for s in np.flatnonzero(starts):
+            events.append((int(s), {"start": int(max(0, self.current_sample[s] - self.speech_pad_samples - win))}))
+        quiet = act & ~starts & self.triggered & (p < self.threshold - 0.15)
+        first = quiet & (self.temp_end == 0)
+        self.temp_end[first] = self.current_sample[first]
+        ends = quiet & ((self.current_sample - self.temp_end) >= self.min_silence_samples)
+        for s in np.flatnonzero(ends):
+            events.append((int(s), {"end": int(self.temp_end[s] + self.speech_pad_samples - win)}))
+        self.temp_end[ends] = 0
+        self.triggered[ends] = False
+        events.sort(key=lambda e: e[0])
+        return events

@@ -320,3 +320,66 @@ def test_profile_option_reports_kernel_times(model, golden):
     finally:
         eng.set_option("profile", "0")
     assert f > 0 and r > 0 and calls == 2
+
+
+# ---- (4) callers either side of the path: live streams (hipGraph) and ragged corpora -------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_streaming_step_in_hip_graph(model, oracle, golden, tag):
+    """BASELINE configs[4]: persistent per-stream state in HBM, one hipGraph-captured vad_step per
+    tick; streams join late / are reset mid-way.  Every slot must follow the oracle run of ITS OWN
+    audio from its own start."""
+    from silero_vad_amd import StreamPool
+    sr = SRS[tag]
+    n = chunk_of(sr)
+    cap, T = 100, 12                                      # capacity deliberately not a multiple of 16
+    rows = rolled_rows(golden[tag]["wav"], cap, T * n, 2711)
+    pool = StreamPool(model.engine, sr, capacity=cap, graph=True)
+    assert pool._graph is not None
+    eager = StreamPool(model.engine, sr, capacity=cap, graph=False)
+    join = {s: (0 if s < 66 else 4) for s in range(cap)}  # slots 66.. are admitted at tick 4
+    got = np.zeros((cap, T), np.float32)
+    for t in range(T):
+        for s in range(cap):                              # open() hands out slots 0, 1, 2, ...
+            if join[s] == t:
+                assert pool.open() == s and eager.open() == s
+        x = torch.from_numpy(rows[:, t * n:(t + 1) * n]).to(model.device)
+        p = pool.tick(x).clone()
+        q = eager.tick(x).clone()
+        assert torch.equal(p, q)                          # graph replay == eager launch
+        got[:, t] = p.cpu().numpy()
+    torch.cuda.synchronize()
+    for s in (0, 1, 17, 65, 66, 80, 99):
+        t0 = join[s]
+        want, _, wst = oracle.forward_audio(rows[s:s + 1, t0 * n:], sr)
+        assert np.abs(got[s, t0:] - want[0]).max() < TIGHT, s
+        assert state_err(pool.state[:, s:s + 1].cpu().numpy(), wst) < TOL
+    pool.close(3)
+    assert pool.open() == 3 and float(pool.state[:, 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_ragged_corpus_equals_single_recording_runs(model, golden, tag):
+    """configs[3] plumbing: recordings of different lengths bucketed into lock-step batches give
+    bit-identical probabilities and identical segments to one-recording-at-a-time calls."""
+    from silero_vad_amd import batch_speech_timestamps, get_speech_timestamps, ragged_probs
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    rng = np.random.default_rng(9)
+    lens = [int(v) for v in rng.integers(n // 2, 60 * n, size=40)] + [n, n + 1, 37 * n]
+    starts = rng.integers(0, len(g["wav"]) - 60 * n, size=len(lens))
+    for kind in ("f32", "i16"):
+        src = g["wav"] if kind == "f32" else g["pcm_i16"]
+        audios = [torch.from_numpy(src[s:s + m].copy()) for s, m in zip(starts, lens)]
+        got = ragged_probs(audios, model, sr, max_waste=0.2, max_bytes=1 << 20)
+        for a, p in zip(audios, got):
+            want = model.audio_forward(a[None], sr)[0]
+            assert torch.equal(p, want)
+    audios = [torch.from_numpy(g["wav"][s:s + m].copy()) for s, m in zip(starts, lens)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        batch = batch_speech_timestamps(audios, model, sampling_rate=sr, threshold=0.45)
+        single = [get_speech_timestamps(a, model, sampling_rate=sr, threshold=0.45) for a in audios]
+        batch_s = batch_speech_timestamps(audios, model, sampling_rate=sr, return_seconds=True)
+        single_s = [get_speech_timestamps(a, model, sampling_rate=sr, return_seconds=True) for a in audios]
+    assert batch == single and batch_s == single_s
+    assert sum(len(s) for s in single) > 10
