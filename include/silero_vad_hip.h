@@ -60,7 +60,9 @@ int  vad_geometry(int sr, int *chunk, int *context);
 /* Options (strings so that bindings need no enum mirror):
  *   "impl"      = "mfma" (default, the product path) | "reference" (slow all-VALU kernels kept
  *                 as an on-device A/B for tests; never the default)
- *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)           */
+ *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)
+ *   "trace_ptr" = device address (bring-up only): builds compiled with -DVAD_TRACE=1 write 16
+ *                 int64 phase timestamps per frontend workgroup there; normal builds ignore it  */
 int  vad_set_option(vad_engine *e, const char *name, const char *value);
 
 /* ---- the hot path ----------------------------------------------------------------------------
@@ -135,6 +137,16 @@ long vad_segment_probs(const float *probs, long n, long audio_len, const vad_seg
 long vad_segment_probs_batch(const float *probs, long ldp, long n_streams, const long *n_chunks,
                              const long *audio_len, const vad_segment_params *p, vad_segment *out,
                              long cap_per_stream, long *counts, int threads);
+
+/* ---- host-side ingest ---------------------------------------------------------------------------------
+ * Pack n recordings of different lengths (lens[i] samples of elem_size 2 = int16 or 4 = float32 at
+ * rows[i]) into one zero-padded row-major [n][width] batch at dst (typically pinned host memory that
+ * is then copied to the GPU and handed to vad_forward_audio[_i16]).  Zero padding on the right is what
+ * the reference does to a recording's last chunk (src/silero_vad/utils_vad.py:326-327); the network
+ * is causal, so padding further does not change the recording's own probabilities.  The copy is
+ * split over `threads` host threads (<= 0: up to 32).                                              */
+int  vad_stage_rows(const void *const *rows, const long *lens, long n, long width, size_t elem_size,
+                    void *dst, int threads);
 
 /* ---- test / bring-up hooks (not part of the drop-in surface) -------------------------------------
  * Host-only: size and contents of the packed weight images the kernels consume, so CPU tests can

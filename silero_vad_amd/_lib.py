@@ -4,12 +4,14 @@ The product path has no CPU fallback: if the shared library is missing this modu
 import of the symbols, and `Engine(...)` raises if no gfx950 device can be opened.
 """
 import ctypes
+import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int16, c_int64,
                     c_long, c_size_t, c_void_p)
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libsilero_vad_hip.so"
+# SILERO_VAD_AMD_LIB selects another build of the SAME library (tools/variants.py A/B kernels)
+LIB_PATH = Path(os.environ.get("SILERO_VAD_AMD_LIB") or PKG / "libsilero_vad_hip.so")
 WEIGHTS_PATH = PKG / "data" / "silero_vad_v6.weights"
 
 VAD_OK = 0
@@ -51,6 +53,7 @@ SYMBOLS = {
     "vad_segment_probs_batch": (c_long, [f32p, c_long, c_long, POINTER(c_long), POINTER(c_long),
                                          POINTER(SegmentParams), POINTER(Segment), c_long,
                                          POINTER(c_long), c_int]),
+    "vad_stage_rows": (c_int, [POINTER(c_void_p), POINTER(c_long), c_long, c_long, c_size_t, c_void_p, c_int]),
     "vad_debug_packed_floats": (c_long, [c_void_p, c_int, c_int]),
     "vad_debug_packed_copy": (c_int, [c_void_p, c_int, c_int, f32p, c_long]),
     "vad_create_host_only": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),

@@ -36,6 +36,7 @@ struct FrontArgs {
     float *ctx_out;          // [B][C] written by the waves that own t == T-1 (may alias ctx_in)
     float *gx;               // scratch, tile-major, indexed with slab-relative t
     int B;
+    long long *trace;        // bring-up only (VAD_TRACE builds): 16 slots per workgroup, else null
 };
 template <typename PcmT>
 hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s);

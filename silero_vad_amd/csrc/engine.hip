@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -20,6 +21,7 @@ struct vad_engine {
     std::string err;
     bool impl_reference = false;
     bool profile = false;
+    long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
 
     // device images
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
@@ -180,6 +182,7 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
         fa.ctx_out = e->d_ctx_new;
         fa.gx = e->d_gx;
         fa.B = B;
+        fa.trace = e->trace;
         vad::RecArgs ra{};
         ra.whh = e->d_whh[ni];
         ra.tables = e->d_tables[ni];
@@ -328,6 +331,10 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         if (v == "mfma") e->impl_reference = false;
         else if (v == "reference") e->impl_reference = true;
         else return fail(e, VAD_ERR_OPTION, "impl must be mfma|reference");
+        return VAD_OK;
+    }
+    if (n == "trace_ptr") {                          // bring-up only; ignored by normal builds
+        e->trace = reinterpret_cast<long long *>(std::strtoull(value, nullptr, 0));
         return VAD_OK;
     }
     if (n == "profile") {

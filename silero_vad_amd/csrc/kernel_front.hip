@@ -35,7 +35,22 @@ namespace {
 using f32x4 = float __attribute__((ext_vector_type(4)));
 using u32x4 = unsigned __attribute__((ext_vector_type(4)));
 
-constexpr int kRingSlotFloats = 2048;   // 8 KiB: one k-group of an 8-row-block segment
+// ---- build-time knobs (tools/variants.py builds A/B variants; the defaults are the product) -------
+#ifndef VAD_SLOT_BLOCKS
+#define VAD_SLOT_BLOCKS 24       // 1-KiB blocks per ring slot (one unit = up to this many blocks)
+#endif
+#ifndef VAD_STAGGER
+#define VAD_STAGGER 0            // x 8128 cycles of start delay for odd wave slots (first workgroups)
+#endif
+#ifndef VAD_TRACE
+#define VAD_TRACE 0              // 1: workgroups write phase timestamps to FrontArgs::trace (tools/trace_front.py)
+#endif
+#ifndef VAD_ABLATE
+#define VAD_ABLATE 0             // timing experiments only (wrong results): 1 no barriers, 2 no FFT
+#endif                           // math, 4 no PCM loads, 8 no weight-ring loads
+
+constexpr int kSlotBlocks = VAD_SLOT_BLOCKS;
+constexpr int kRingSlotFloats = kSlotBlocks * 256;   // one unit: whole k-groups of one segment
 
 // W_32^j = cos - i sin, j < 16 (fp32-rounded from double)
 __device__ constexpr float kCos32[16] = {1.0f, 0.98078525f, 0.9238795f, 0.8314696f, 0.70710677f,
@@ -69,46 +84,107 @@ struct Ring {
     float *slots;            // LDS, 2 x kRingSlotFloats
     const float *wfront;     // global
     int unit;                // units consumed so far (wave-uniform)
+#if VAD_TRACE
+    long long wait = 0, span = 0, last = 0;   // cycles at unit barriers / between them (bring-up trace)
+#endif
 };
 
-template <int M>
-__device__ __forceinline__ void ring_issue(const Ring &r, long goff, int slot, const Lane &ln) {
-    // M blocks of 1 KiB; wave w copies blocks w, w+4.  LDS destination = wave-uniform base + lane*16.
-#pragma unroll
-    for (int blk = 0; blk < M; blk += 4) {
-        const int bb = blk + ln.wave;
-        const float *src = r.wfront + goff + (long)bb * 256 + ln.lane * 4;
-        float *dst = r.slots + slot * kRingSlotFloats + bb * 256;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    }
+// k-groups per ring unit for a segment of M row blocks, and the size of a segment's first unit
+constexpr int unit_kgroups(int M) { return kSlotBlocks / M; }
+constexpr int first_unit_blocks(int M, int KS) {
+    const int kg = (KS + 3) / 4, ug = unit_kgroups(M);
+    return M * (kg < ug ? kg : ug);
 }
 
-// One segment = KG k-groups of M row blocks.  acc[m] += A_seg[m][:, k] * B[k][:]  for all k-steps.
-// bfun(s) must return the B-operand register of k-step s (compile-time s).
-// NEXT_M / next_off describe the unit that follows this segment in program order (prefetch).
-template <int M, int KS, int NEXT_M, class BF>
+template <int BLOCKS>
+__device__ __forceinline__ void ring_issue(const Ring &r, long goff, int slot, const Lane &ln) {
+    // BLOCKS blocks of 1 KiB; wave w copies blocks w, w+4, ...  LDS destination = M0 (wave-uniform
+    // base) + lane*16, the layout global_load_lds requires.
+    //
+    // The LDS-DMA is issued from inline asm ON PURPOSE: while the compiler knows of a pending
+    // global_load_lds it degrades every `s_waitcnt lgkmcnt(N)` to lgkmcnt(0), which serialises the
+    // ds_read -> MFMA pipeline of gemm_seg (one exposed LDS latency per 8 MFMAs).  The ring's own
+    // protocol orders the DMA instead: ring_wait() = s_waitcnt vmcnt(0) before the unit's barrier.
+    static_assert(BLOCKS % 4 == 0 && BLOCKS <= kSlotBlocks, "unit must be whole 4-block groups");
+    if (VAD_ABLATE & 8) return;
+    const float *gbase = r.wfront + goff + (long)ln.wave * 256;           // wave-uniform
+    const unsigned voff = ln.lane * 16;                                    // bytes
+    const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float *)(r.slots + slot * kRingSlotFloats))
+                           + (unsigned)ln.wave * 1024u;
+#pragma unroll
+    for (int blk = 0; blk < BLOCKS; blk += 4) {
+        const float *src = gbase + (long)blk * 256;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lbase + (unsigned)blk * 1024u);
+        unsigned keep_m0;                      // M0 is restored: the compiler may keep its own value there
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep_m0)
+                     : "v"(voff), "s"(src), "s"(dst)
+                     : "memory");
+    }
+}
+// All of this wave's ring DMA has landed in LDS (and everything else it had in flight on vmcnt).
+__device__ __forceinline__ void ring_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// One segment = KG k-groups of M row blocks, streamed as units of up to unit_kgroups(M) k-groups.
+// acc[m] += A_seg[m][:, k] * B[k][:]  for all k-steps.  bfun(s) must return the B-operand register of
+// k-step s (compile-time s).  NEXT_BLOCKS / next_off describe the first unit of the segment that
+// follows in program order (prefetch; 0 = none).
+template <int M, int KS, int NEXT_BLOCKS, class BF>
 __device__ __forceinline__ void gemm_seg(f32x4 (&acc)[M], BF bfun, Ring &ring, long seg_off,
                                          long next_off, const Lane &ln) {
-    constexpr int KG = (KS + 3) / 4;
+    constexpr int KG = (KS + 3) / 4, UG = unit_kgroups(M), NU = (KG + UG - 1) / UG;
+    static_assert(UG >= 1, "slot smaller than one k-group");
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) {
-        __syncthreads();     // unit `ring.unit` has landed for every wave; the other slot is free
+    for (int u = 0; u < NU; ++u) {
+#if VAD_TRACE
+        const long long ta = __builtin_readcyclecounter();
+        if (ring.last) ring.span += ta - ring.last;
+#endif
+        ring_wait();
+        if (!(VAD_ABLATE & 1)) __syncthreads();   // unit `ring.unit` landed for every wave; other slot free
+#if VAD_TRACE
+        ring.last = __builtin_readcyclecounter();
+        ring.wait += ring.last - ta;
+#endif
         const int slot = ring.unit & 1;
-        if (kg + 1 < KG) ring_issue<M>(ring, seg_off + (long)(kg + 1) * M * 256, slot ^ 1, ln);
-        else if (NEXT_M > 0) ring_issue<(NEXT_M > 0 ? NEXT_M : 4)>(ring, next_off, slot ^ 1, ln);
+        constexpr int TAIL = (KG % UG == 0) ? UG : KG % UG;     // k-groups in the segment's last unit
+        if (u + 1 < NU) {
+            const long off = seg_off + (long)(u + 1) * UG * M * 256;
+            if (u + 2 < NU) ring_issue<M * UG>(ring, off, slot ^ 1, ln);
+            else ring_issue<M * TAIL>(ring, off, slot ^ 1, ln);
+        } else if (NEXT_BLOCKS > 0) {
+            ring_issue<(NEXT_BLOCKS > 0 ? NEXT_BLOCKS : 4)>(ring, next_off, slot ^ 1, ln);
+        }
+        // The unit is consumed as "steps" of two row blocks x 4 k-steps (8 MFMAs).  The A fragments of
+        // step i+1 are read from LDS BEFORE the MFMAs of step i are issued (explicit double buffer;
+        // the sched_barrier keeps the compiler from sinking the reads back down): a lone wave then
+        // keeps the matrix pipe busy without exposing the LDS latency once per 8 MFMAs.
         const f32x4 *A = reinterpret_cast<const f32x4 *>(ring.slots + slot * kRingSlotFloats) + ln.lane;
+        const int nk = (KG - u * UG) < UG ? (KG - u * UG) : UG;        // k-groups in this unit
+        const int nsteps = nk * (M / 2);
+        f32x4 c0 = A[0], c1 = A[64];
 #pragma unroll
-        for (int mp = 0; mp < M; mp += 2) {
-            const f32x4 a0 = A[(mp + 0) * 64];
-            const f32x4 a1 = A[(mp + 1) * 64];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (kg * 4 + ks < KS) {
-                    const float bv = bfun(kg * 4 + ks);
-                    acc[mp + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], bv, acc[mp + 0], 0, 0, 0);
-                    acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], bv, acc[mp + 1], 0, 0, 0);
+        for (int st = 0; st < UG * (M / 2); ++st) {
+            if (st < nsteps) {
+                f32x4 n0 = c0, n1 = c1;
+                if (st + 1 < nsteps) {
+                    n0 = A[(2 * (st + 1)) * 64];
+                    n1 = A[(2 * (st + 1) + 1) * 64];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                const int kg = u * UG + st / (M / 2), mp = 2 * (st % (M / 2));
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (kg * 4 + ks < KS) {
+                        const float bv = bfun(kg * 4 + ks);
+                        acc[mp + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[ks], bv, acc[mp + 0], 0, 0, 0);
+                        acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[ks], bv, acc[mp + 1], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = n0;
+                c1 = n1;
             }
         }
         ring.unit++;
@@ -170,7 +246,26 @@ __device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a
         if (sg > 0) src = trow + SL * (sg - 1);
         esrc = trow + (N - SL - 1);
     }
-    if (V == 0 && ln.t == 0 && ln.g == 0) load_vec<SL>(a.ctx_in + (size_t)ln.b * SL, s);
+    if (VAD_ABLATE & 16) {
+        // timing experiment: same instruction count and bytes, but every instruction reads 1 KiB of
+        // ONE row (lane l <- 16 B at l*16), i.e. perfectly coalesced
+        const PcmT *r0 = reinterpret_cast<const PcmT *>(a.pcm) + (size_t)(ln.st * 16) * a.ld + (long)SL * 8 * ln.t;
+#pragma unroll
+        for (int k = 0; k < SL / 4; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(r0) + (size_t)(k & 15) * a.ld + ln.lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
+        }
+    } else if (VAD_ABLATE & 32) {
+        // timing experiment: the 4 lanes of a chunk read one contiguous 64-B segment per instruction
+        const float *rr = reinterpret_cast<const float *>(row) + (long)SL * 8 * ln.t;
+#pragma unroll
+        for (int k = 0; k < SL / 4; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(rr + 16 * k + 4 * ln.g + 128 * V);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
+        }
+    } else if (V == 0 && ln.t == 0 && ln.g == 0) load_vec<SL>(a.ctx_in + (size_t)ln.b * SL, s);
     else load_vec<SL>(src, s);
     if (V == 3) {
         // context for the next call = last C = 2Q samples of the (zero padded) last chunk = slice 8
@@ -197,8 +292,20 @@ __device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a
 }
 
 // ---- in-register Q-point complex FFT, DIF radix-2, output index bit-reversed ---------------------
+// Complex values are float2 (re, im) so that the butterflies compile to packed fp32 math
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two flops per lane per issue).  On gfx950 the fp32
+// MFMA and the VALU share one issue pipe per SIMD (tools/ubench/overlap.hip: their times add, they do
+// not overlap), so every VALU instruction saved here is kernel time saved.
+using f32x2 = float __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 swap2(f32x2 v) { return f32x2{v.y, v.x}; }
+// v * (c + i sn)
+__device__ __forceinline__ f32x2 cmul(f32x2 v, float c, float sn) {
+    return __builtin_elementwise_fma(swap2(v), f32x2{-sn, sn}, v * f32x2{c, c});
+}
+
 template <int Q>
-__device__ __forceinline__ void fft_inlane(float (&re)[Q], float (&im)[Q]) {
+__device__ __forceinline__ void fft_inlane(f32x2 (&z)[Q]) {
 #pragma unroll
     for (int n = Q; n >= 2; n >>= 1) {
         const int half = n >> 1;
@@ -207,18 +314,13 @@ __device__ __forceinline__ void fft_inlane(float (&re)[Q], float (&im)[Q]) {
 #pragma unroll
             for (int jx = 0; jx < half; ++jx) {
                 const int i0 = b0 + jx, i1 = i0 + half;
-                const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
-                re[i0] = ar + br;
-                im[i0] = ai + bi;
-                const float dr = ar - br, di = ai - bi;
+                const f32x2 u = z[i0], v = z[i1];
+                z[i0] = u + v;
+                const f32x2 d = u - v;
                 const int tw = jx * (32 / n);                  // W_n^jx = W_32^(jx*32/n)
-                if (tw == 0) { re[i1] = dr; im[i1] = di; }
-                else if (tw == 8) { re[i1] = di; im[i1] = -dr; }                 // * (-i)
-                else {
-                    const float c = kCos32[tw], sn = kSin32[tw];               // * (c - i sn)
-                    re[i1] = fmaf(dr, c, di * sn);
-                    im[i1] = fmaf(di, c, -(dr * sn));
-                }
+                if (tw == 0) z[i1] = d;
+                else if (tw == 8) z[i1] = swap2(d) * f32x2{1.0f, -1.0f};        // * (-i)
+                else z[i1] = cmul(d, kCos32[tw], -kSin32[tw]);                   // * (c - i sn)
             }
         }
     }
@@ -232,59 +334,81 @@ __device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, 
     constexpr vadl::Tab tb = vadl::make_tab(8 * Q, Q);
     __builtin_amdgcn_sched_barrier(0);     // keep each pass's loads inside the pass (register budget)
     float s[SL];
-    load_slice<Q, V, PcmT>(s, a, ln);
+    if (VAD_ABLATE & 4) {
+#pragma unroll
+        for (int i = 0; i < SL; ++i) s[i] = (float)(ln.lane + i) * 1e-3f;
+    } else {
+        load_slice<Q, V, PcmT>(s, a, ln);
+    }
+    if (VAD_ABLATE & 2) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) X[k] = s[k] + s[k + Q];
+        X[Q] = s[0];
+        return;
+    }
 
-    float re[Q], im[Q];
+    f32x2 z[Q];
     {   // window (same taps for every frame: the lane's slice always sits at 2Q g inside the frame)
         const f32x4 *w = reinterpret_cast<const f32x4 *>(tab_lds + tb.window + SL * ln.g);
 #pragma unroll
         for (int k = 0; k < SL / 4; ++k) {
             const f32x4 wv = w[k];
-            re[2 * k] = s[4 * k] * wv[0];
-            im[2 * k] = s[4 * k + 1] * wv[1];
-            re[2 * k + 1] = s[4 * k + 2] * wv[2];
-            im[2 * k + 1] = s[4 * k + 3] * wv[3];
+            z[2 * k] = f32x2{s[4 * k], s[4 * k + 1]} * f32x2{wv[0], wv[1]};
+            z[2 * k + 1] = f32x2{s[4 * k + 2], s[4 * k + 3]} * f32x2{wv[2], wv[3]};
         }
     }
     // radix-4 across the 4 lanes of a chunk.  Stage A pairs g <-> g^2, stage B pairs g <-> g^1.
-    const float *tw1 = tab_lds + tb.tw1 + ln.g * Q * 2;
+    const f32x4 *tw1 = reinterpret_cast<const f32x4 *>(tab_lds + tb.tw1 + ln.g * Q * 4);
+    const f32x2 sA{ln.sgnA, ln.sgnA}, sB{ln.sgnB, ln.sgnB};
+    // lane group 3 multiplies by -i between the two stages: x*rotA + swap(x)*rotB
+    const f32x2 rotA = ln.g == 3 ? f32x2{0.f, 0.f} : f32x2{1.f, 1.f};
+    const f32x2 rotB = ln.g == 3 ? f32x2{1.f, -1.f} : f32x2{0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        float xr = re[q], xi = im[q];
-        const float pr = __shfl_xor(xr, 32), pi = __shfl_xor(xi, 32);
-        xr = fmaf(ln.sgnA, xr, pr);                // g<2: own + partner ; g>=2: partner - own
-        xi = fmaf(ln.sgnA, xi, pi);
-        if (ln.g == 3) { const float tr = xr; xr = xi; xi = -tr; }     // * (-i)
-        const float qr = __shfl_xor(xr, 16), qi = __shfl_xor(xi, 16);
-        xr = fmaf(ln.sgnB, xr, qr);                // g even: own + partner ; g odd: partner - own
-        xi = fmaf(ln.sgnB, xi, qi);
-        const float c = tw1[2 * q], sn = tw1[2 * q + 1];               // * W_4Q^(P[g] q)
-        re[q] = fmaf(xr, c, -(xi * sn));
-        im[q] = fmaf(xr, sn, xi * c);
+        f32x2 x = z[q];
+        const f32x2 p{__shfl_xor(x.x, 32), __shfl_xor(x.y, 32)};
+        x = __builtin_elementwise_fma(sA, x, p);       // g<2: own + partner ; g>=2: partner - own
+        x = __builtin_elementwise_fma(swap2(x), rotB, x * rotA);
+        const f32x2 r{__shfl_xor(x.x, 16), __shfl_xor(x.y, 16)};
+        x = __builtin_elementwise_fma(sB, x, r);       // g even: own + partner ; g odd: partner - own
+        const f32x4 t = tw1[q];                        // * W_4Q^(P[g] q): (-s, s, c, 0)
+        z[q] = __builtin_elementwise_fma(swap2(x), f32x2{t[0], t[1]}, x * f32x2{t[2], t[2]});
     }
-    fft_inlane<Q>(re, im);
+    fft_inlane<Q>(z);
     // real-FFT split: Y[k] = E + W_8Q^k O from Z[k] and conj Z[4Q - k]
     constexpr int LG = ilog2(Q);
-    const float *tw2 = tab_lds + tb.tw2 + ln.g * Q * 2;
+    const f32x4 *tw2 = reinterpret_cast<const f32x4 *>(tab_lds + tb.tw2 + ln.g * Q * 4);
+    // partner bin 8Q - k lives in the same lane for groups 0, 1 and in lane ^ 16 for groups 2, 3
+    const int src_lane4 = (ln.g >= 2 ? (ln.lane ^ 16) : ln.lane) * 4;
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
-        const float ur = re[bitrev(k, LG)], ui = im[bitrev(k, LG)];
+        const f32x2 u = z[bitrev(k, LG)];
         const int ks = bitrev((Q - k) % Q, LG), kr = bitrev(Q - 1 - k, LG);
-        const float xr = __shfl_xor(re[kr], 16), xi = __shfl_xor(im[kr], 16);
-        float pr = ln.g >= 2 ? xr : re[kr], pi = ln.g >= 2 ? xi : im[kr];
-        pr = ln.g == 0 ? re[ks] : pr;
-        pi = ln.g == 0 ? im[ks] : pi;
-        const float ar = ur + pr, ai = ui - pi;                // Z + conj(Zp)
-        const float dr = ui + pi, di = pr - ur;                // -i (Z - conj(Zp))
-        const float c = tw2[2 * k], sn = tw2[2 * k + 1];
-        const float yr = ar + fmaf(dr, c, -(di * sn));
-        const float yi = ai + fmaf(dr, sn, di * c);
-        X[k] = 0.5f * __builtin_amdgcn_sqrtf(fmaf(yr, yr, yi * yi));
+        const f32x2 own = z[kr], alt = z[ks];
+        const float xr = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane4, __float_as_int(own.x)));
+        const float xi = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane4, __float_as_int(own.y)));
+        const f32x2 p{ln.g == 0 ? alt.x : xr, ln.g == 0 ? alt.y : xi};
+        const f32x2 av = __builtin_elementwise_fma(p, f32x2{1.0f, -1.0f}, u);     // Z + conj(Zp)
+        const f32x2 ev = __builtin_elementwise_fma(p, f32x2{-1.0f, 1.0f}, u);     // Z - conj(Zp)
+        // y = av + (-i ev) (c + i sn) = av + ev (sn - i c)
+        const f32x4 t = tw2[k];                                                  // (c, -c, s, 0)
+        const f32x2 y = __builtin_elementwise_fma(swap2(ev), f32x2{t[0], t[1]},
+                                                  __builtin_elementwise_fma(ev, f32x2{t[2], t[2]}, av));
+        const f32x2 yy = y * y;
+        X[k] = 0.5f * __builtin_amdgcn_sqrtf(yy.x + yy.y);
     }
-    X[Q] = ln.g == 0 ? fabsf(re[0] - im[0]) : 0.f;             // Nyquist: Re Z0 - Im Z0
+    X[Q] = ln.g == 0 ? fabsf(z[0].x - z[0].y) : 0.f;           // Nyquist: Re Z0 - Im Z0
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------
+#if VAD_TRACE
+#define TRACE(i)                                                                          \
+    do {                                                                                  \
+        if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define TRACE(i) do {} while (0)
+#endif
 template <int Q, typename PcmT>
 __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
     using namespace vadl;
@@ -311,19 +435,42 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
     ln.sgnA = ln.g < 2 ? 1.f : -1.f;
     ln.sgnB = (ln.g & 1) ? -1.f : 1.f;
 
+    TRACE(0);
+#if VAD_TRACE
+    if (a.trace && threadIdx.x == 0) {
+        a.trace[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+        a.trace[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+#endif
+    if (VAD_STAGGER > 0 && blockIdx.x < 512) {
+        // The two workgroups that share a CU start together and run the same program, so their VALU
+        // (FFT) and MFMA phases coincide for the whole launch (later workgroups inherit the phase of
+        // the one they replace).  Delay the one in the odd wave slot once, by about half a tile, so
+        // that one group's FFT overlaps the other's MFMAs.  HW_ID[3:0] = wave slot within the SIMD.
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u;
+        if (slot)
+            for (int i = 0; i < VAD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     Ring ring{lds + TABF, a.wfront, 0};
     constexpr long o_e0t0 = seg_offset(E0T0, Q), o_e0t1 = seg_offset(E0T1, Q), o_e0t2 = seg_offset(E0T2, Q);
     constexpr long o_e1t0 = seg_offset(E1T0, Q), o_e1t1 = seg_offset(E1T1, Q), o_e1t2 = seg_offset(E1T2, Q);
     constexpr long o_e2t1 = seg_offset(E2T1, Q), o_e2t2 = seg_offset(E2T2, Q), o_e3t1 = seg_offset(E3T1, Q);
 
-    ring_issue<8>(ring, o_e0t1, 0, ln);          // first unit of the program: E0T1 k-group 0
+    constexpr int FB_E0 = first_unit_blocks(8, Q + 1), FB_E1 = first_unit_blocks(4, 32),
+                  FB_E2 = first_unit_blocks(4, 16), FB_E3 = first_unit_blocks(8, 16),
+                  FB_IH = first_unit_blocks(8, 32);
+    ring_issue<FB_E0>(ring, o_e0t1, 0, ln);      // first unit of the program: head of E0T1
     for (int i = threadIdx.x; i < tb.total; i += 256) tab[i] = a.tables[i];
     __syncthreads();
 
     float X0[Q + 1], X1[Q + 1], X2[Q + 1], X3[Q + 1];
+    TRACE(1);
     fft_pass<Q, 0, PcmT>(X0, a, tab, ln);
+    TRACE(2);
     fft_pass<Q, 1, PcmT>(X1, a, tab, ln);
+    TRACE(3);
     fft_pass<Q, 2, PcmT>(X2, a, tab, ln);
+    TRACE(4);
 
     auto bX0 = [&](int s) { return X0[s]; };
     auto bX1 = [&](int s) { return X1[s]; };
@@ -336,36 +483,42 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
 
     // enc0 frame 0 (taps 1,2; tap 0 is the left zero pad)  -> enc1 out 0 tap 1
     init_bias<8>(Y, tab + tb.b_e0, ln);
-    gemm_seg<8, KS0, 8>(Y, bX0, ring, o_e0t1, o_e0t2, ln);
-    gemm_seg<8, KS0, 4>(Y, bX1, ring, o_e0t2, o_e1t1, ln);
+    gemm_seg<8, KS0, FB_E0>(Y, bX0, ring, o_e0t1, o_e0t2, ln);
+    gemm_seg<8, KS0, FB_E1>(Y, bX1, ring, o_e0t2, o_e1t1, ln);
     relu<8>(Y);
     init_bias<4>(Z0, tab + tb.b_e1, ln);
-    gemm_seg<4, 32, 8>(Z0, bY, ring, o_e1t1, o_e0t0, ln);
+    gemm_seg<4, 32, FB_E0>(Z0, bY, ring, o_e1t1, o_e0t0, ln);
     // enc0 frame 1 -> enc1 out 0 tap 2, out 1 tap 0
     init_bias<8>(Y, tab + tb.b_e0, ln);
-    gemm_seg<8, KS0, 8>(Y, bX0, ring, o_e0t0, o_e0t1, ln);
-    gemm_seg<8, KS0, 8>(Y, bX1, ring, o_e0t1, o_e0t2, ln);
-    gemm_seg<8, KS0, 4>(Y, bX2, ring, o_e0t2, o_e1t2, ln);
+    gemm_seg<8, KS0, FB_E0>(Y, bX0, ring, o_e0t0, o_e0t1, ln);
+    gemm_seg<8, KS0, FB_E0>(Y, bX1, ring, o_e0t1, o_e0t2, ln);
+    gemm_seg<8, KS0, FB_E1>(Y, bX2, ring, o_e0t2, o_e1t2, ln);
     relu<8>(Y);
-    gemm_seg<4, 32, 4>(Z0, bY, ring, o_e1t2, o_e1t0, ln);
+    gemm_seg<4, 32, FB_E1>(Z0, bY, ring, o_e1t2, o_e1t0, ln);
     init_bias<4>(Z1, tab + tb.b_e1, ln);
-    gemm_seg<4, 32, 8>(Z1, bY, ring, o_e1t0, o_e0t0, ln);
+    gemm_seg<4, 32, FB_E0>(Z1, bY, ring, o_e1t0, o_e0t0, ln);
 
+    TRACE(5);
+#if VAD_TRACE
+    ring.span += __builtin_readcyclecounter() - ring.last;
+    ring.last = 0;
+#endif
     fft_pass<Q, 3, PcmT>(X3, a, tab, ln);
+    TRACE(6);
 
     // enc0 frame 2 -> enc1 out 1 tap 1
     init_bias<8>(Y, tab + tb.b_e0, ln);
-    gemm_seg<8, KS0, 8>(Y, bX1, ring, o_e0t0, o_e0t1, ln);
-    gemm_seg<8, KS0, 8>(Y, bX2, ring, o_e0t1, o_e0t2, ln);
-    gemm_seg<8, KS0, 4>(Y, bX3, ring, o_e0t2, o_e1t1, ln);
+    gemm_seg<8, KS0, FB_E0>(Y, bX1, ring, o_e0t0, o_e0t1, ln);
+    gemm_seg<8, KS0, FB_E0>(Y, bX2, ring, o_e0t1, o_e0t2, ln);
+    gemm_seg<8, KS0, FB_E1>(Y, bX3, ring, o_e0t2, o_e1t1, ln);
     relu<8>(Y);
-    gemm_seg<4, 32, 8>(Z1, bY, ring, o_e1t1, o_e0t0, ln);
+    gemm_seg<4, 32, FB_E0>(Z1, bY, ring, o_e1t1, o_e0t0, ln);
     // enc0 frame 3 (taps 0,1; tap 2 is the right zero pad) -> enc1 out 1 tap 2
     init_bias<8>(Y, tab + tb.b_e0, ln);
-    gemm_seg<8, KS0, 8>(Y, bX2, ring, o_e0t0, o_e0t1, ln);
-    gemm_seg<8, KS0, 4>(Y, bX3, ring, o_e0t1, o_e1t2, ln);
+    gemm_seg<8, KS0, FB_E0>(Y, bX2, ring, o_e0t0, o_e0t1, ln);
+    gemm_seg<8, KS0, FB_E1>(Y, bX3, ring, o_e0t1, o_e1t2, ln);
     relu<8>(Y);
-    gemm_seg<4, 32, 4>(Z1, bY, ring, o_e1t2, o_e2t1, ln);
+    gemm_seg<4, 32, FB_E2>(Z1, bY, ring, o_e1t2, o_e2t1, ln);
     relu<4>(Z0);
     relu<4>(Z1);
 
@@ -374,15 +527,17 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
     auto bZ0 = [&](int s) { return Z0[s >> 2][s & 3]; };
     auto bZ1 = [&](int s) { return Z1[s >> 2][s & 3]; };
     auto bV = [&](int s) { return Vv[s >> 2][s & 3]; };
+    TRACE(7);
     init_bias<4>(Vv, tab + tb.b_e2, ln);
-    gemm_seg<4, 16, 4>(Vv, bZ0, ring, o_e2t1, o_e2t2, ln);
-    gemm_seg<4, 16, 8>(Vv, bZ1, ring, o_e2t2, o_e3t1, ln);
+    gemm_seg<4, 16, FB_E2>(Vv, bZ0, ring, o_e2t1, o_e2t2, ln);
+    gemm_seg<4, 16, FB_E3>(Vv, bZ1, ring, o_e2t2, o_e3t1, ln);
     relu<4>(Vv);
     f32x4 Fe[8];
     auto bF = [&](int s) { return Fe[s >> 2][s & 3]; };
     init_bias<8>(Fe, tab + tb.b_e3, ln);
-    gemm_seg<8, 16, 8>(Fe, bV, ring, o_e3t1, seg_offset(IH0, Q), ln);
+    gemm_seg<8, 16, FB_IH>(Fe, bV, ring, o_e3t1, seg_offset(IH0, Q), ln);
     relu<8>(Fe);
+    TRACE(8);
 
     // LSTM input-gate pre-activations, one gate (8 row blocks) at a time, stored in D-fragment order
     float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32) * 256 + ln.lane * 4;
@@ -390,7 +545,7 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
     for (int q = 0; q < 4; ++q) {
         f32x4 G[8];
         init_bias<8>(G, tab + tb.b_g + 128 * q, ln);
-        if (q < 3) gemm_seg<8, 32, 8>(G, bF, ring, seg_offset(IH0 + q, Q), seg_offset(IH0 + q + 1, Q), ln);
+        if (q < 3) gemm_seg<8, 32, FB_IH>(G, bF, ring, seg_offset(IH0 + q, Q), seg_offset(IH0 + q + 1, Q), ln);
         else gemm_seg<8, 32, 0>(G, bF, ring, seg_offset(IH3, Q), 0, ln);
         if (ln.tile_valid) {
 #pragma unroll
@@ -398,6 +553,15 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
                 *reinterpret_cast<f32x4 *>(gxt + (size_t)(8 * q + m) * 256) = G[m];
         }
     }
+    TRACE(9);
+#if VAD_TRACE
+    if (a.trace && threadIdx.x == 0) {
+        ring.span += __builtin_readcyclecounter() - ring.last;
+        a.trace[(size_t)blockIdx.x * 16 + 12] = ring.wait;
+        a.trace[(size_t)blockIdx.x * 16 + 13] = ring.span;
+        a.trace[(size_t)blockIdx.x * 16 + 14] = ring.unit;
+    }
+#endif
 }
 
 __global__ void unpack_gx_kernel(const float *gx, float *out, int B, long T) {

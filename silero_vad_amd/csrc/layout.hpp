@@ -66,8 +66,9 @@ constexpr Tab make_tab(int F, int Q) {
     t.w_out = o; o += 128;
     t.b_out = o; o += 4;          // [0] used, padded to keep 16-B alignment
     t.window = o; o += F;         // row 0 of the reference's forward_basis_buffer (= periodic Hann)
-    t.tw1 = o; o += 4 * Q * 2;    // [g][q] (re, im) of exp(-2 pi i P[g] q / (4Q))
-    t.tw2 = o; o += 4 * Q * 2;    // [g][k'] (re, im) of exp(-2 pi i (4k' + P[g]) / (8Q))
+    // twiddles are stored in the operand order of the packed complex multiply (kernel_front.hip):
+    t.tw1 = o; o += 4 * Q * 4;    // [g][q]  (-s, s, c, 0),  c + i s = exp(-2 pi i P[g] q / (4Q))
+    t.tw2 = o; o += 4 * Q * 4;    // [g][k'] (c, -c, s, 0),  c + i s = exp(-2 pi i (4k' + P[g]) / (8Q))
     t.total = o;
     return t;
 }

@@ -130,11 +130,13 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
     for (int gg = 0; gg < 4; ++gg)
         for (int q = 0; q < Q; ++q) {
             const double a1 = two_pi * kResidue[gg] * q / (4.0 * Q);
-            T[tb.tw1 + (gg * Q + q) * 2 + 0] = (float)std::cos(a1);
-            T[tb.tw1 + (gg * Q + q) * 2 + 1] = (float)-std::sin(a1);
+            const float c1 = (float)std::cos(a1), s1 = (float)-std::sin(a1);
+            float *t1 = T + tb.tw1 + (gg * Q + q) * 4;
+            t1[0] = -s1; t1[1] = s1; t1[2] = c1; t1[3] = 0.f;
             const double a2 = two_pi * (4 * q + kResidue[gg]) / (8.0 * Q);
-            T[tb.tw2 + (gg * Q + q) * 2 + 0] = (float)std::cos(a2);
-            T[tb.tw2 + (gg * Q + q) * 2 + 1] = (float)-std::sin(a2);
+            const float c2 = (float)std::cos(a2), s2 = (float)-std::sin(a2);
+            float *t2 = T + tb.tw2 + (gg * Q + q) * 4;
+            t2[0] = c2; t2[1] = -c2; t2[2] = s2; t2[3] = 0.f;
         }
 }
 

@@ -49,7 +49,10 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().vad_destroy(self._h)
+            try:
+                lib().vad_destroy(self._h)
+            except Exception:        # interpreter shutdown: module globals may already be gone
+                pass
             self._h = None
 
     __del__ = close

@@ -46,7 +46,7 @@ def batch_speech_timestamps(audios: Sequence[torch.Tensor], model, sampling_rate
     result in input order (other ranks get None).  kwargs are those of get_speech_timestamps."""
     import warnings
 
-    from .streams import chunk_size, ragged_probs, segment_probs_batch
+    from .streams import ragged_speech_segments
     from .timestamps import get_speech_timestamps
 
     mine = list(shard_range(len(audios), world_size, rank))
@@ -63,20 +63,14 @@ def batch_speech_timestamps(audios: Sequence[torch.Tensor], model, sampling_rate
         if sr > 16000 and sr % 16000 == 0:                 # utils_vad.py:301-307
             step, sr = sr // 16000, 16000
             warnings.warn('Sampling rate is a multiply of 16000, casting to 16000 manually!')
-        n = chunk_size(sr)
         local = []
         for i in mine:
             a = audios[i] if torch.is_tensor(audios[i]) else torch.as_tensor(audios[i])
             while a.dim() > 1 and a.shape[0] == 1:
                 a = a.squeeze(0)
             local.append(a[::step] if step > 1 else a)
-        probs = ragged_probs(local, model, sr)
         lens = [int(a.shape[0]) for a in local]
-        T = max((len(p) for p in probs), default=0)
-        table = torch.zeros((len(local), max(T, 1)), dtype=torch.float32)
-        for r, p in enumerate(probs):
-            table[r, : len(p)] = p
-        segs = segment_probs_batch(table, [(m + n - 1) // n for m in lens], lens, sr, **scan_kw)
+        segs = ragged_speech_segments(local, model, sr, **scan_kw)
         seconds, res = kwargs.get("return_seconds", False), kwargs.get("time_resolution", 1)
         for r, i in enumerate(mine):
             out = segs[r]

@@ -71,69 +71,147 @@ class RaggedPlan:
         return sum(n for n in self.lengths if n > 0)
 
 
-def _stage(audios, idxs, width, dtype, pinned):
-    """Pack recordings `idxs` into one zero-padded [len(idxs), width] host tensor."""
-    host = torch.zeros((len(idxs), width), dtype=dtype, pin_memory=pinned)
-    for row, i in enumerate(idxs):
+class _StagePool:
+    """Two pinned host buffers + two device buffers reused for every bucket (pinned allocation is
+    expensive; the engine call of bucket k overlaps the staging + H2D copy of bucket k+1)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.host = [None, None]
+        self.dev = [None, None]
+        self.done = [None, None]            # event: H2D of this slot finished (host buffer reusable)
+        self.consumed = [None, None]        # event: the kernels that read this slot's device buffer finished
+        self.stream = torch.cuda.Stream(device)
+
+    def get(self, k, nbytes):
+        i = k & 1
+        if self.done[i] is not None:
+            self.done[i].synchronize()
+        if self.host[i] is None or self.host[i].numel() < nbytes:
+            cap = max(nbytes, 1 << 20)
+            self.host[i] = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            self.dev[i] = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        return i
+
+
+def _stage_into(audios, idxs, width, dtype, dst: torch.Tensor):
+    """Pack recordings `idxs` into dst[len(idxs), width] (zero padded) with the native threaded copy."""
+    n = len(idxs)
+    rows = (ctypes.c_void_p * n)()
+    lens = (ctypes.c_long * n)()
+    keep = []
+    for r, i in enumerate(idxs):
         a = audios[i]
         a = a if torch.is_tensor(a) else torch.as_tensor(a)
         if a.dim() != 1:
             raise ValueError("More than one dimension in audio. Are you trying to process audio with 2 channels?")
-        if dtype == torch.int16 and a.dtype != torch.int16:
-            raise TypeError("mixed int16 / float recordings in one call")
-        host[row, : a.shape[0]] = a.to(dtype)
-    return host
+        if a.dtype != dtype or not a.is_contiguous() or a.is_cuda:
+            if dtype == torch.int16 and a.dtype != torch.int16:
+                raise TypeError("mixed int16 / float recordings in one call")
+            a = a.to("cpu", dtype).contiguous()
+        keep.append(a)
+        rows[r] = a.data_ptr()
+        lens[r] = a.shape[0]
+    rc = lib().vad_stage_rows(rows, lens, n, width, dst.element_size(), dst.data_ptr(), 0)
+    if rc:
+        raise _lib.VadError(rc, "vad_stage_rows")
+
+
+def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
+                   max_bytes: int = 256 << 20, plan: RaggedPlan = None):
+    """Generator over the plan's buckets: yields (indices, probs[len(indices), T_bucket] on the CPU).
+    Recording i of a bucket owns the first ceil(len_i / N) entries of its row."""
+    n = chunk_size(sampling_rate)
+    as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
+    dtype = torch.int16 if as_i16 else torch.float32
+    esz = 2 if as_i16 else 4
+    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
+    plan = plan or RaggedPlan(lengths, max_waste, max_bytes, esz)
+    fast = model.audio_forward_device
+    dev = getattr(model, "device", None)
+    on_gpu = dev is not None and torch.device(dev).type == "cuda"
+    if not on_gpu:                                        # CPU stand-in models (tests)
+        for idxs in plan.buckets:
+            width = max(plan.lengths[idxs[0]], n)
+            host = torch.empty((len(idxs), width), dtype=dtype)
+            _stage_into(audios, idxs, width, dtype, host)
+            yield idxs, fast(host, sampling_rate).cpu()
+        return
+    pool = getattr(model, "_stage_pool", None)
+    if pool is None:
+        pool = model._stage_pool = _StagePool(dev)
+    cur = torch.cuda.current_stream(dev)
+
+    def stage(k):
+        idxs = plan.buckets[k]
+        # at least one full window: audio_forward rejects shorter inputs (vad_annotator.py:124)
+        width = max(plan.lengths[idxs[0]], n)
+        nbytes = len(idxs) * width * esz
+        i = pool.get(k, nbytes)
+        host = pool.host[i][:nbytes].view(dtype).view(len(idxs), width)
+        _stage_into(audios, idxs, width, dtype, host)
+        d = pool.dev[i][:nbytes].view(dtype).view(len(idxs), width)
+        if pool.consumed[i] is not None:                  # the device buffer's previous reader is done
+            pool.stream.wait_event(pool.consumed[i])
+        with torch.cuda.stream(pool.stream):
+            d.copy_(host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(pool.stream)
+        pool.done[i] = ev
+        return d, ev, i
+
+    staged = stage(0) if plan.buckets else None
+    prev = None
+    for k, idxs in enumerate(plan.buckets):
+        x, ev, slot = staged
+        cur.wait_event(ev)
+        probs = fast(x, sampling_rate)                    # async: kernels of bucket k
+        pool.consumed[slot] = torch.cuda.Event()
+        pool.consumed[slot].record(cur)
+        out = torch.empty(probs.shape, dtype=torch.float32, pin_memory=True)
+        out.copy_(probs, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(cur)
+        staged = stage(k + 1) if k + 1 < len(plan.buckets) else None   # CPU packs k+1 meanwhile
+        if prev is not None:
+            prev[2].synchronize()
+            yield prev[0], prev[1]
+        prev = (idxs, out, done)
+    if prev is not None:
+        prev[2].synchronize()
+        yield prev[0], prev[1]
 
 
 def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
-                 max_bytes: int = 1 << 30, plan: RaggedPlan = None) -> List[torch.Tensor]:
+                 max_bytes: int = 256 << 20, plan: RaggedPlan = None) -> List[torch.Tensor]:
     """Speech probabilities of many recordings of different lengths.
 
     Returns one 1-D CPU float tensor per recording (ceil(len / N) entries), bit-identical to
     ``model.audio_forward(audio[None], sr)[0]`` on that recording alone.  ``audios`` may be float
     tensors in [-1, 1] or int16 PCM (all of one kind).  `model` needs ``audio_forward_device``
-    (HipSileroVAD); H2D copies of bucket k+1 overlap the kernels of bucket k."""
+    (HipSileroVAD); staging + H2D of bucket k+1 overlap the kernels of bucket k."""
     n = chunk_size(sampling_rate)
-    as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
-    dtype = torch.int16 if as_i16 else torch.float32
     lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
-    plan = plan or RaggedPlan(lengths, max_waste, max_bytes, 2 if as_i16 else 4)
     out: List[torch.Tensor] = [torch.empty(0)] * len(audios)
-    fast = model.audio_forward_device
-    dev = getattr(model, "device", None)
-    on_gpu = dev is not None and torch.device(dev).type == "cuda"
-    copy_stream = torch.cuda.Stream(dev) if on_gpu else None
-    staged = None
-
-    def stage(k):
-        idxs = plan.buckets[k]
-        host = _stage(audios, idxs, plan.lengths[idxs[0]], dtype, on_gpu)
-        if not on_gpu:
-            return host, None
-        with torch.cuda.stream(copy_stream):
-            d = host.to(dev, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(copy_stream)
-        return (host, d), ev
-
-    pending = []
-    if plan.buckets:
-        staged = stage(0)
-    for k, idxs in enumerate(plan.buckets):
-        cur, ev = staged
-        staged = stage(k + 1) if k + 1 < len(plan.buckets) else None
-        if on_gpu:
-            torch.cuda.current_stream(dev).wait_event(ev)
-            x = cur[1]
-            x.record_stream(torch.cuda.current_stream(dev))
-        else:
-            x = cur
-        probs = fast(x, sampling_rate)
-        pending.append((idxs, probs))
-    for idxs, probs in pending:
-        p = probs.cpu()
+    for idxs, probs in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes, plan):
         for row, i in enumerate(idxs):
-            out[i] = p[row, : (lengths[i] + n - 1) // n].clone()
+            out[i] = probs[row, : (lengths[i] + n - 1) // n].clone()
+    return out
+
+
+def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
+                           max_bytes: int = 256 << 20, threads: int = 0, **scan_kw) -> List[list]:
+    """Speech segments (sample indices) of many recordings: bucketed GPU batches + the native
+    threaded scanner per bucket.  scan_kw: the threshold/duration arguments of get_speech_timestamps."""
+    n = chunk_size(sampling_rate)
+    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
+    out: List[list] = [[] for _ in audios]
+    for idxs, probs in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes):
+        lens = [lengths[i] for i in idxs]
+        segs = segment_probs_batch(probs, [(m + n - 1) // n for m in lens], lens, sampling_rate,
+                                   threads=threads, **scan_kw)
+        for row, i in enumerate(idxs):
+            out[i] = segs[row]
     return out
 
 

@@ -25,7 +25,10 @@ def _speech_probs(audio, model, sampling_rate, window, progress_cb):
     n = len(audio)
     fast = getattr(model, "audio_forward_device", None)
     if fast is not None and n > 0:
-        probs = fast(audio.unsqueeze(0), sampling_rate)[0].cpu()
+        x = audio.unsqueeze(0)
+        if n < window:      # the reference pads every chunk to a full window (utils_vad.py:326-327), so a
+            x = torch.nn.functional.pad(x, (0, window - n))   # recording shorter than one window is legal here
+        probs = fast(x, sampling_rate)[0].cpu()
     else:
         model.reset_states()
         vals = []

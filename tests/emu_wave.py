@@ -51,8 +51,8 @@ class Tab:
         self.w_out = o; o += 128
         self.b_out = o; o += 4
         self.window = o; o += F
-        self.tw1 = o; o += 4 * Q * 2
-        self.tw2 = o; o += 4 * Q * 2
+        self.tw1 = o; o += 4 * Q * 4
+        self.tw2 = o; o += 4 * Q * 4
         self.total = o
 
 
@@ -144,7 +144,7 @@ class FrontEmu:
                 im[2 * k + 1][m] = s[4 * k + 3][m] * w[4 * k + 3]
         sgnA = np.where(G < 2, 1, -1).astype(f32)
         sgnB = np.where(G & 1, -1, 1).astype(f32)
-        tw1 = T[tb.tw1: tb.tw1 + 4 * Q * 2].reshape(4, Q, 2)
+        tw1 = T[tb.tw1: tb.tw1 + 4 * Q * 4].reshape(4, Q, 4)      # (-s, s, c, 0)
         for q in range(Q):
             xr, xi = re[q], im[q]
             pr, pi = shfl_xor(xr, 32), shfl_xor(xi, 32)
@@ -153,12 +153,12 @@ class FrontEmu:
             xr, xi = np.where(g3, xi, xr), np.where(g3, -xr, xi)
             qr, qi = shfl_xor(xr, 16), shfl_xor(xi, 16)
             xr, xi = sgnB * xr + qr, sgnB * xi + qi
-            c, sn = tw1[G, q, 0], tw1[G, q, 1]
+            c, sn = tw1[G, q, 2], tw1[G, q, 1]
             re[q] = xr * c - xi * sn
             im[q] = xr * sn + xi * c
         self.fft_inlane(re, im)
         LG = Q.bit_length() - 1
-        tw2 = T[tb.tw2: tb.tw2 + 4 * Q * 2].reshape(4, Q, 2)
+        tw2 = T[tb.tw2: tb.tw2 + 4 * Q * 4].reshape(4, Q, 4)      # (c, -c, s, 0)
         X = np.zeros((Q + 1, 64), f32)
         for k in range(Q):
             ur, ui = re[bitrev(k, LG)], im[bitrev(k, LG)]
@@ -170,7 +170,7 @@ class FrontEmu:
             pi = np.where(G == 0, im[ks], pi)
             ar, ai = ur + pr, ui - pi
             dr, di = ui + pi, pr - ur
-            c, sn = tw2[G, k, 0], tw2[G, k, 1]
+            c, sn = tw2[G, k, 0], tw2[G, k, 2]
             yr = ar + (dr * c - di * sn)
             yi = ai + (dr * sn + di * c)
             X[k] = f32(0.5) * np.sqrt(yr * yr + yi * yi)

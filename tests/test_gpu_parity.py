@@ -372,6 +372,8 @@ def test_ragged_corpus_equals_single_recording_runs(model, golden, tag):
         audios = [torch.from_numpy(src[s:s + m].copy()) for s, m in zip(starts, lens)]
         got = ragged_probs(audios, model, sr, max_waste=0.2, max_bytes=1 << 20)
         for a, p in zip(audios, got):
+            if len(a) < n:                                # audio_forward itself rejects < 1 window (:124)
+                a = torch.nn.functional.pad(a, (0, n - len(a)))
             want = model.audio_forward(a[None], sr)[0]
             assert torch.equal(p, want)
     audios = [torch.from_numpy(g["wav"][s:s + m].copy()) for s, m in zip(starts, lens)]

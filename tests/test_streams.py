@@ -37,7 +37,7 @@ def test_ragged_probs_equal_single_recording_runs(built, as_i16):
     """Zero padding to the bucket length must not change a recording's own probabilities."""
     from silero_vad_amd import ragged_probs
     pcm = _wav()
-    lens = [40000, 40000, 25000, 39999, 33333, 512, 100, 16000, 0]
+    lens = [40000, 40000, 25000, 39999, 33333, 512, 100, 16000, 0, 90, 110]
     audios = []
     for k, n in enumerate(lens):
         a = pcm[k * 45000: k * 45000 + n]

@@ -2,7 +2,10 @@
 """Condense rocprofv3 output directories (gpurun_out/prof/<pass>/...) into small tracked files
 under profiles/: per-kernel duration stats and per-kernel PMC means.
 
-    python tools/summarize_prof.py gpurun_out/prof profiles/r01
+    python tools/summarize_prof.py gpurun_out/prof profiles/r01 [sr streams chunks]
+
+The optional workload triple is recorded in the JSON so that bench.py can match a PMC summary to
+the workload it is running (roofline.traffic).
 """
 import collections
 import csv
@@ -19,9 +22,10 @@ def short(name):
     return None
 
 
-def main(src, dst_prefix):
+def main(src, dst_prefix, workload=(16000, 4096, 256)):
     src = Path(src)
-    out = {"kernel_trace": {}, "pmc": {}}
+    out = {"workload": {"sr": int(workload[0]), "streams": int(workload[1]), "chunks": int(workload[2])},
+           "kernel_trace": {}, "pmc": {}}
     lines = ["# rocprofv3 summary (" + dst_prefix + ")", ""]
     for f in glob.glob(str(src / "trace" / "**" / "*_kernel_stats.csv"), recursive=True):
         lines += ["## --kernel-trace --stats (engine kernels only)", "",
@@ -72,4 +76,4 @@ def main(src, dst_prefix):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3:6] if len(sys.argv) >= 6 else (16000, 4096, 256))

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Build and time A/B variants of the kernels (compile-time knobs in csrc/*.hip).
+
+    python tools/variants.py build            # here (no GPU): build/variants/lib_<name>.so
+    python tools/variants.py run [names...]   # on the GPU box: bench each, write gpurun_out/variants.json
+
+A variant is a set of -D flags.  Variants whose name starts with "abl" are timing-only ablations
+(wrong results by construction); every other variant is parity-checked against the oracle before
+it is timed.  The product library is always silero_vad_amd/libsilero_vad_hip.so (default knobs).
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "silero_vad_amd" / "csrc"
+OUT = ROOT / "build" / "variants"
+HIP = ["engine.hip", "kernel_front.hip", "kernel_rec.hip", "kernels_ref.hip"]
+CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
+
+VARIANTS = {
+    "base": [],
+    "slot8": ["-DVAD_SLOT_BLOCKS=8"],
+    "slot16": ["-DVAD_SLOT_BLOCKS=16"],
+    "stag6": ["-DVAD_STAGGER=6"],
+    "stag11": ["-DVAD_STAGGER=11"],
+    "stag16": ["-DVAD_STAGGER=16"],
+    "slot8_stag11": ["-DVAD_SLOT_BLOCKS=8", "-DVAD_STAGGER=11"],
+    "trace": ["-DVAD_TRACE=1"],
+    "trace_slot8": ["-DVAD_TRACE=1", "-DVAD_SLOT_BLOCKS=8"],
+    "trace_noload": ["-DVAD_TRACE=1", "-DVAD_ABLATE=4"],
+    "trace_stag11": ["-DVAD_TRACE=1", "-DVAD_STAGGER=11"],
+    "abl_nobar": ["-DVAD_ABLATE=1"],
+    "abl_nofft": ["-DVAD_ABLATE=2"],
+    "abl_noload": ["-DVAD_ABLATE=4"],
+    "abl_noring": ["-DVAD_ABLATE=8"],
+    "abl_mfma_only": ["-DVAD_ABLATE=15"],
+    "abl_coalesced": ["-DVAD_ABLATE=16"],
+    "abl_seg64": ["-DVAD_ABLATE=32"],
+    "abl_coalesced_noring": ["-DVAD_ABLATE=24"],
+    "abl_noload_noring": ["-DVAD_ABLATE=12"],
+    "abl_nofft_noload": ["-DVAD_ABLATE=6"],
+}
+
+
+def build(names):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    OUT.mkdir(parents=True, exist_ok=True)
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-I", str(ROOT / "include")]
+    shared = OUT / "obj_shared"
+    shared.mkdir(exist_ok=True)
+    procs = []
+    # translation units without knobs are compiled once
+    knob_units = {"kernel_front.hip", "kernel_rec.hip"}
+    for src in HIP + CPP:
+        if src in knob_units:
+            continue
+        o = shared / (src + ".o")
+        cmd = ([hipcc, "--offload-arch=gfx950"] + common + ["-c", str(CSRC / src), "-o", str(o)]
+               if src.endswith(".hip") else [hipcc] + common + ["-x", "c++", "-c", str(CSRC / src), "-o", str(o)])
+        procs.append(subprocess.Popen(cmd))
+    for name in names:
+        d = OUT / ("obj_" + name)
+        d.mkdir(exist_ok=True)
+        for src in knob_units:
+            procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950"] + common + VARIANTS[name]
+                                          + ["-c", str(CSRC / src), "-o", str(d / (src + ".o"))]))
+    for p in procs:
+        if p.wait() != 0:
+            sys.exit("compile failed")
+    for name in names:
+        objs = [str(shared / (s + ".o")) for s in HIP + CPP if s not in knob_units] + \
+               [str(OUT / ("obj_" + name) / (s + ".o")) for s in knob_units]
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o",
+                        str(OUT / f"lib_{name}.so")] + objs, check=True)
+        print("built", name)
+
+
+CHECK = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import silero_vad_amd
+from oracle import Oracle
+m = silero_vad_amd.load_silero_vad(device=0)
+o = Oracle()
+wav = np.load(%r)["pcm"].astype(np.float32) / 32768.0
+rows = np.stack([np.roll(wav, -b * 7919)[:20 * 512] for b in range(40)])
+got = m.audio_forward(torch.from_numpy(rows), 16000).numpy()
+want = o.audio_forward(rows, 16000)
+print("PARITY", float(np.abs(got - want).max()))
+"""
+
+
+def run(names):
+    res = {}
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    for name in names:
+        lib = OUT / f"lib_{name}.so"
+        env = dict(os.environ, SILERO_VAD_AMD_LIB=str(lib))
+        r = {}
+        if not name.startswith("abl"):
+            chk = subprocess.run([sys.executable, "-c", CHECK % (str(ROOT), str(ROOT / "tests/golden/audio_16k.npz"))],
+                                 env=env, capture_output=True, text=True, timeout=600)
+            r["parity"] = next((float(l.split()[1]) for l in chk.stdout.splitlines() if l.startswith("PARITY")), None)
+            if r["parity"] is None:
+                r["error"] = chk.stderr[-500:]
+        b = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--steps", "8", "--warmup", "2"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        line = next((l for l in b.stdout.splitlines() if l.startswith('{"metric"')), None)
+        if line:
+            d = json.loads(line)
+            r.update(value=d["value"], ms_per_step=d["ms_per_step"], kernel_ms=d["kernel_ms"])
+        else:
+            r["error"] = (b.stderr or b.stdout)[-500:]
+        res[name] = r
+        print(name, json.dumps(r), flush=True)
+        (ROOT / "gpurun_out" / "variants.json").write_text(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    cmd = sys.argv[1] if len(sys.argv) > 1 else "build"
+    names = sys.argv[2:] or list(VARIANTS)
+    (build if cmd == "build" else run)(names)
