@@ -40,6 +40,7 @@ STREAMS = 4096           # per GPU (c2 / 8k)
 CHUNKS_PER_STREAM = 256  # per step
 LIVE_STREAMS = 8192      # per GPU (stream): 65 536 per 8-GPU node
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
+PEAK_F16_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 # Algorithmic work per chunk.  "dense" = exactly as the reference
@@ -49,11 +50,15 @@ WORK = {
     16000: {"chunk": 512, "flop": 1_359_104, "bytes": 2_052,
             "front_dense": 2 * (264_192 + 198_144 + 49_152 + 12_288 + 24_576 + 65_536),
             "front_mfma": 2 * (10 * 128 * 132 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
-            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<32,float>"},
+            "front_split_mfma": 2 * 3 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
+            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<32,float>",
+            "front_split_kernel": "front_split_kernel<32,float>"},
     8000: {"chunk": 256, "flop": 767_232, "bytes": 1_028,
            "front_dense": 2 * (66_560 + 99_840 + 49_152 + 12_288 + 24_576 + 65_536),
            "front_mfma": 2 * (10 * 128 * 68 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
-           "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<16,float>"},
+           "front_split_mfma": 2 * 3 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
+           "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<16,float>",
+           "front_split_kernel": "front_split_kernel<16,float>"},
 }
 
 
@@ -150,21 +155,35 @@ def synth_pcm(B, L, sr, dev, seed):
     return pcm
 
 
-def roofline(sr, chunks_per_launch, front_ms_avg, B, T):
+def roofline(sr, chunks_per_launch, front_ms_avg, B, T, precision="fp32"):
+    """Dominant kernel = the frontend (STFT + encoder + W_ih).  `achieved` = the reference's DENSE flop
+    count for that part of the path per second, against the fp32 MFMA peak -- the precision
+    the result is delivered in.  `mfma_executed` is what the matrix pipe really runs (fp32 MFMA, or
+    3 f16 MFMA flops per algorithmic flop for precision=f16x3, against the f16 peak); `hbm` is the
+    same launch against the HBM roofline (PCM in + gx out, 2 x 2048 B per 16 kHz chunk)."""
     w = WORK[sr]
+    split = precision == "f16x3"
     s = front_ms_avg / 1e3
     dense = chunks_per_launch * w["front_dense"] / s / 1e12
-    execd = chunks_per_launch * w["front_mfma"] / s / 1e12
-    tr = pmc_traffic("front_kernel<%d" % (32 if sr == 16000 else 16), sr, B, T)
-    return {"bound": "mfma", "kernel": w["front_kernel"],
+    ex_flop = w["front_split_mfma"] if split else w["front_mfma"]
+    ex_peak = PEAK_F16_TFLOPS if split else PEAK_F32_TFLOPS
+    execd = chunks_per_launch * ex_flop / s / 1e12
+    kname = w["front_split_kernel"] if split else w["front_kernel"]
+    tr = pmc_traffic(kname.split(",")[0], sr, B, T)
+    io_bytes = chunks_per_launch * (w["chunk"] * 4 + 2048)
+    hbm = io_bytes / s / 1e9
+    return {"bound": "mfma", "kernel": kname,
             "achieved": round(dense, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(dense / PEAK_F32_TFLOPS, 4),
-            "note": "achieved/frac use the reference's DENSE flop count (SURVEY 8d); the kernel replaces the "
-                    "DFT-basis conv by an rFFT and skips zero-pad taps, so frac can exceed 1 -- "
-                    "mfma_executed is the matrix-pipe utilisation",
+            "note": "achieved/frac use the reference's DENSE flop count (SURVEY 8d) against the fp32 peak; the "
+                    "kernel replaces the DFT-basis conv by an rFFT, skips zero-pad taps and (f16x3) runs "
+                    "each product as 3 f16 MFMA products, so frac can exceed 1 -- mfma_executed is the "
+                    "matrix-pipe utilisation, hbm the same launch against the HBM roofline",
             "flop_per_launch": chunks_per_launch * w["front_dense"],
-            "mfma_executed": {"flop_per_launch": chunks_per_launch * w["front_mfma"],
-                              "achieved": round(execd, 3), "frac": round(execd / PEAK_F32_TFLOPS, 4)},
+            "mfma_executed": {"flop_per_launch": chunks_per_launch * ex_flop, "dtype": "f16" if split else "f32",
+                              "achieved": round(execd, 3), "peak": ex_peak, "frac": round(execd / ex_peak, 4)},
+            "hbm": {"bytes_per_launch": io_bytes, "achieved": round(hbm, 1), "peak": PEAK_HBM_GBPS,
+                    "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBPS, 4)},
             "avg_launch_ms": round(front_ms_avg, 4),
             "traffic": tr["bytes"] if tr else None, "traffic_detail": tr}
 
@@ -173,7 +192,8 @@ def base_line(args, world, metric_sr, value, elapsed, steps):
     return {"metric": f"audio-chunks/sec (32 ms @ {metric_sr // 1000} kHz)", "value": round(value, 1),
             "unit": "chunks/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x3 products, f32 sums",
+            "precision": args.precision, "data": "synthetic"}
 
 
 # ---- c2 / 8k: HBM-resident batch ------------------------------------------------------------------------
@@ -181,6 +201,7 @@ def run_batch(args, sr, rank, world, local, dist):
     from silero_vad_amd import Engine
     dev = torch.device("cuda", local)
     eng = Engine(device=local)
+    eng.set_precision(args.precision)
     n = WORK[sr]["chunk"]
     B, T = args.streams, args.chunks
     pcm = synth_pcm(B, T * n, sr, dev, 17 + sr + rank)
@@ -201,6 +222,21 @@ def run_batch(args, sr, rank, world, local, dist):
     front_ms, rec_ms, calls = eng.kernel_times()
     eng.set_option("profile", "0")
     ok = bool(torch.isfinite(probs).all().item())
+    other = None
+    if world == 1:                                     # the other arithmetic, same workload, for the record
+        alt = "fp32" if args.precision == "f16x3" else "f16x3"
+        p_main = probs.clone()
+        eng.set_precision(alt)
+        for _ in range(2):
+            step()
+        eng.set_option("profile", "1")
+        e2 = timed(world, dist, dev, max(3, args.steps // 2), step)
+        f2, r2, c2 = eng.kernel_times()
+        eng.set_option("profile", "0")
+        other = {"precision": alt, "value": round(B * T * max(3, args.steps // 2) / e2, 1), "unit": "chunks/s",
+                 "kernel_ms": {"front": round(f2 / max(c2, 1), 4), "rec": round(r2 / max(c2, 1), 4)},
+                 "max_abs_prob_diff_vs_main": float((probs - p_main).abs().max().item())}
+        eng.set_precision(args.precision)
     if rank != 0:
         return None
     w = WORK[sr]
@@ -218,9 +254,12 @@ def run_batch(args, sr, rank, world, local, dist):
                             "flop_per_chunk": w["flop"], "bytes_per_chunk": w["bytes"]}
     c = max(calls, 1)
     out["kernel_ms"] = {"front": round(front_ms / c, 4), "rec": round(rec_ms / c, 4)}
-    out["roofline"] = roofline(sr, B * T, front_ms / c, B, T)
-    out["rec_kernel"] = {"mfma_executed_frac": round(B * T * w["rec_mfma"] / (rec_ms / c / 1e3) / 1e12
-                                                     / PEAK_F32_TFLOPS, 4)}
+    out["roofline"] = roofline(sr, B * T, front_ms / c, B, T, args.precision)
+    rs = rec_ms / c / 1e3
+    out["rec_kernel"] = {"gx_read_GBps": round(B * T * 2048 / rs / 1e9, 1),
+                         "hbm_frac": round(B * T * 2048 / rs / 1e9 / PEAK_HBM_GBPS, 4)}
+    if other:
+        out["other_precision"] = other
     return out
 
 
@@ -230,6 +269,7 @@ def run_stream(args, rank, world, local, dist):
     sr = 16000
     dev = torch.device("cuda", local)
     eng = Engine(device=local)
+    eng.set_precision(args.precision)
     n = WORK[sr]["chunk"]
     cap = args.live
     pool = StreamPool(eng, sr, capacity=cap, graph=True)
@@ -277,7 +317,7 @@ def run_stream(args, rank, world, local, dist):
                               "budget_ms": 32.0}
     c = max(calls, 1)
     out["kernel_ms"] = {"front": round(front_ms / c, 4), "rec": round(rec_ms / c, 4)}
-    out["roofline"] = roofline(sr, cap, front_ms / c, cap, 1)
+    out["roofline"] = roofline(sr, cap, front_ms / c, cap, 1, args.precision)
     return out
 
 
@@ -287,7 +327,7 @@ def run_corpus(args, rank, world, local, dist):
     from silero_vad_amd import load_silero_vad, ragged_speech_segments
     sr = 16000
     dev = torch.device("cuda", local)
-    model = load_silero_vad(device=local)
+    model = load_silero_vad(device=local, precision=args.precision)
     n = WORK[sr]["chunk"]
     rng = np.random.default_rng(101 + rank)
     base_len = 8 << 20
@@ -332,6 +372,9 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["c2", "8k", "stream", "corpus"], default="c2")
+    ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
+                    help="f16x3 (default): fp16x3 split products on the f16 matrix cores, fp32 sums; "
+                         "fp32: exact v_mfma_f32_16x16x4_f32 chain")
     ap.add_argument("--streams", type=int, default=STREAMS, help=argparse.SUPPRESS)
     ap.add_argument("--chunks", type=int, default=CHUNKS_PER_STREAM, help=argparse.SUPPRESS)
     ap.add_argument("--live", type=int, default=LIVE_STREAMS, help=argparse.SUPPRESS)

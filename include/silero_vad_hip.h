@@ -15,7 +15,8 @@
  *     asynchronous with respect to the host unless stated otherwise;
  *   - one engine per GPU; an engine is not thread-safe (the reference model object is not
  *     either: src/silero_vad/utils_vad.py:51-92 mutates _state/_context per call);
- *   - all arithmetic is fp32; sample rates 16000 (chunk N=512, context
+ *   - all sums are fp32 and all operands carry >= 22 significant bits (option
+ *     "precision" below); sample rates 16000 (chunk N=512, context
  *     C=64) and 8000 (N=256, C=32).
  */
 #ifndef SILERO_VAD_HIP_H
@@ -60,6 +61,13 @@ int  vad_geometry(int sr, int *chunk, int *context);
 /* Options (strings so that bindings need no enum mirror):
  *   "impl"      = "mfma" (default, the product path) | "reference" (slow all-VALU kernels kept
  *                 as an on-device A/B for tests; never the default)
+ *   "precision" = "f16x3" (default) | "fp32".  f16x3: every product of the matrix contractions is
+ *                 evaluated as a 3-term fp16 split (a_hi b_hi + a_hi b_lo + a_lo b_hi; 22-bit operands)
+ *                 on the f16 matrix cores with fp32 accumulation -- the same <= 1e-5 agreement with the
+ *                 reference as exact fp32, at 5x the matrix rate.  Its activations must stay below the
+ *                 fp16 range (65504): true for |pcm| <= 1 with a 12x margin on every signal tried; a
+ *                 stream that leaves the range gets NaN probabilities (never a wrong number) from that
+ *                 chunk on and must be rerun with "fp32" (exact v_mfma_f32_16x16x4_f32 chain, no limit).
  *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)
  *   "trace_ptr" = device address (bring-up only): builds compiled with -DVAD_TRACE=1 write 16
  *                 int64 phase timestamps per frontend workgroup there; normal builds ignore it  */
@@ -154,12 +162,19 @@ int  vad_stage_rows(const void *const *rows, const long *lens, long n, long widt
  * W_hh image, 2 = small tables (biases, head, window, twiddles).                                  */
 long vad_debug_packed_floats(const vad_engine *e, int sr, int which);
 int  vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n);
+/* which = 3 / 4: the fp16x3 split frontend / recurrent images (precision=f16x3), returned as raw
+ * 4-byte words holding two halves each.                                                          */
 /* Host-only engine for the hooks above (no device needed).                                       */
 int  vad_create_host_only(const void *weights, size_t nbytes, vad_engine **out);
 /* Device: run the frontend only and return the LSTM input-gate pre-activations
  * gx[B][T][512] = W_ih * enc(stft(x)) + b_ih + b_hh  (row-major, gate order i,f,g,o).            */
 int  vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, long ld,
                         const float *ctx, float *gx, void *stream);
+
+/* Device: one v_mfma_f32_16x16x32_f16 on host-supplied fragments a, b [64 lanes][8 halves] ->
+ * d [64 lanes][4 floats]; pins the operand-slot pairing and the subnormal behaviour the fp16x3 split
+ * arithmetic relies on.  Synchronous.                                                           */
+int  vad_debug_mfma_f16(vad_engine *e, const uint16_t *a, const uint16_t *b, float *d);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,14 @@ struct RecArgs {
 };
 hipError_t launch_rec(int sr, const RecArgs &a, hipStream_t s);
 
+// fp16x3 split variants (kernel_front_split.hip, kernel_rec_split.hip): same arguments, `wfront` /
+// `whh` point to the split images (layout.hpp "split").
+template <typename PcmT>
+hipError_t launch_front_split(int sr, const FrontArgs &a, hipStream_t s);
+hipError_t launch_rec_split(int sr, const RecArgs &a, hipStream_t s);
+// one v_mfma_f32_16x16x32_f16: a, b device [64 lanes][8 halves], d device [64 lanes][4 floats]
+hipError_t launch_mfma_f16_probe(const void *a, const void *b, float *d, hipStream_t s);
+
 // gx (fragment order) -> row-major [B][T][512] for vad_debug_frontend
 hipError_t launch_unpack_gx(const float *gx, float *out, int B, long T, hipStream_t s);
 

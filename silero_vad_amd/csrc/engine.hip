@@ -20,6 +20,7 @@ struct vad_engine {
     int device = -1;
     std::string err;
     bool impl_reference = false;
+    bool split = true;                              // precision: fp16x3 split MFMA (default) | exact fp32 MFMA
     bool profile = false;
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
 
@@ -27,6 +28,7 @@ struct vad_engine {
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
     float *d_front[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
+    uint16_t *d_front_split[2] = {}, *d_whh_split[2] = {};
 
     // scratch
     float *d_gx = nullptr;
@@ -173,7 +175,7 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
     for (long t0 = 0; t0 < T; t0 += slab) {
         const long nt = std::min(slab, T - t0);
         vad::FrontArgs fa{};
-        fa.wfront = e->d_front[ni];
+        fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni]) : e->d_front[ni];
         fa.tables = e->d_tables[ni];
         fa.pcm = pcm;
         fa.tail = tail;
@@ -184,7 +186,7 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
         fa.B = B;
         fa.trace = e->trace;
         vad::RecArgs ra{};
-        ra.whh = e->d_whh[ni];
+        ra.whh = e->split ? reinterpret_cast<const float *>(e->d_whh_split[ni]) : e->d_whh[ni];
         ra.tables = e->d_tables[ni];
         ra.gx = e->d_gx;
         ra.state = state;
@@ -201,18 +203,21 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
             e->ev_used += 3;
             HIP_TRY(e, hipEventRecord(ev[0], stream));
         }
-        HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
+        if (e->split) HIP_TRY(e, vad::launch_front_split<PcmT>(sr, fa, stream));
+        else HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
-        HIP_TRY(e, vad::launch_rec(sr, ra, stream));
+        if (e->split) HIP_TRY(e, vad::launch_rec_split(sr, ra, stream));
+        else HIP_TRY(e, vad::launch_rec(sr, ra, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[2], stream));
     }
     HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return VAD_OK;
 }
 
-int upload(vad_engine *e, float **dst, const std::vector<float> &src) {
-    HIP_TRY(e, hipMalloc((void **)dst, src.size() * sizeof(float)));
-    HIP_TRY(e, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+template <typename T>
+int upload(vad_engine *e, T **dst, const std::vector<T> &src) {
+    HIP_TRY(e, hipMalloc((void **)dst, src.size() * sizeof(T)));
+    HIP_TRY(e, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return VAD_OK;
 }
 
@@ -283,6 +288,8 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
         if (upload(e, &e->d_front[ni], e->weights.packed[ni].front)) return bail(VAD_ERR_HIP);
         if (upload(e, &e->d_whh[ni], e->weights.packed[ni].whh)) return bail(VAD_ERR_HIP);
         if (upload(e, &e->d_tables[ni], e->weights.packed[ni].tables)) return bail(VAD_ERR_HIP);
+        if (upload(e, &e->d_front_split[ni], e->weights.packed[ni].front_split)) return bail(VAD_ERR_HIP);
+        if (upload(e, &e->d_whh_split[ni], e->weights.packed[ni].whh_split)) return bail(VAD_ERR_HIP);
     }
     // canonical tensors for impl=reference
     const auto &blob = e->weights.blob;
@@ -313,6 +320,8 @@ void vad_destroy(vad_engine *e) {
             if (e->d_front[ni]) (void)hipFree(e->d_front[ni]);
             if (e->d_whh[ni]) (void)hipFree(e->d_whh[ni]);
             if (e->d_tables[ni]) (void)hipFree(e->d_tables[ni]);
+            if (e->d_front_split[ni]) (void)hipFree(e->d_front_split[ni]);
+            if (e->d_whh_split[ni]) (void)hipFree(e->d_whh_split[ni]);
         }
         if (e->d_blob) (void)hipFree(e->d_blob);
         if (e->d_gx) (void)hipFree(e->d_gx);
@@ -331,6 +340,12 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         if (v == "mfma") e->impl_reference = false;
         else if (v == "reference") e->impl_reference = true;
         else return fail(e, VAD_ERR_OPTION, "impl must be mfma|reference");
+        return VAD_OK;
+    }
+    if (n == "precision") {
+        if (v == "f16x3") e->split = true;
+        else if (v == "fp32") e->split = false;
+        else return fail(e, VAD_ERR_OPTION, "precision must be f16x3|fp32");
         return VAD_OK;
     }
     if (n == "trace_ptr") {                          // bring-up only; ignored by normal builds
@@ -401,16 +416,38 @@ long vad_debug_packed_floats(const vad_engine *e, int sr, int which) {
     if (!e || ni < 0) return -1;
     const vad::PackedNet &p = e->weights.packed[ni];
     return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size()
-         : which == 2 ? (long)p.tables.size() : -1;
+         : which == 2 ? (long)p.tables.size() : which == 3 ? (long)p.front_split.size() / 2
+         : which == 4 ? (long)p.whh_split.size() / 2 : -1;
 }
 
 int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n) {
     const int ni = net_index(sr);
     if (!e || ni < 0 || !dst) return VAD_ERR_ARG;
     const vad::PackedNet &p = e->weights.packed[ni];
+    if (which == 3 || which == 4) {                 // split images: raw 4-byte words (two halves each)
+        const std::vector<uint16_t> &h = which == 3 ? p.front_split : p.whh_split;
+        if (n != (long)h.size() / 2) return VAD_ERR_ARG;
+        std::memcpy(dst, h.data(), h.size() * sizeof(uint16_t));
+        return VAD_OK;
+    }
     const std::vector<float> *v = which == 0 ? &p.front : which == 1 ? &p.whh : which == 2 ? &p.tables : nullptr;
     if (!v || n != (long)v->size()) return VAD_ERR_ARG;
     std::memcpy(dst, v->data(), v->size() * sizeof(float));
+    return VAD_OK;
+}
+
+int vad_debug_mfma_f16(vad_engine *e, const uint16_t *a, const uint16_t *b, float *d) {
+    if (!e || !a || !b || !d) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    HIP_TRY(e, hipSetDevice(e->device));
+    uint8_t *buf = nullptr;
+    HIP_TRY(e, hipMalloc((void **)&buf, 3072));
+    hipError_t rc = hipMemcpy(buf, a, 1024, hipMemcpyHostToDevice);
+    if (rc == hipSuccess) rc = hipMemcpy(buf + 1024, b, 1024, hipMemcpyHostToDevice);
+    if (rc == hipSuccess) rc = vad::launch_mfma_f16_probe(buf, buf + 1024, reinterpret_cast<float *>(buf + 2048), nullptr);
+    if (rc == hipSuccess) rc = hipMemcpy(d, buf + 2048, 1024, hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (rc != hipSuccess) return hip_fail(e, rc, "mfma probe");
     return VAD_OK;
 }
 
@@ -431,7 +468,7 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     if (L % N || ((size_t)pcm & 15) || (ld * sizeof(float)) % 16 || ((size_t)ctx & 15))
         return fail(e, VAD_ERR_ARG, "debug frontend: whole chunks and 16-byte aligned rows only");
     vad::FrontArgs fa{};
-    fa.wfront = e->d_front[ni];
+    fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni]) : e->d_front[ni];
     fa.tables = e->d_tables[ni];
     fa.pcm = pcm;
     fa.ld = ld; fa.L = L; fa.T = T; fa.t0 = 0; fa.nt = T;
@@ -439,7 +476,8 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.ctx_out = nullptr;
     fa.gx = e->d_gx;
     fa.B = B;
-    HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
+    if (e->split) HIP_TRY(e, vad::launch_front_split<float>(sr, fa, stream));
+    else HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
     HIP_TRY(e, vad::launch_unpack_gx(e->d_gx, gx, B, T, stream));
     return VAD_OK;
 }

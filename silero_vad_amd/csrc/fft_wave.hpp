@@ -1,0 +1,251 @@
+// fft_wave.hpp -- per-wave framing + in-wave real FFT magnitude shared by the frontend kernels
+// (kernel_front.hip: exact-fp32 MFMA chain; kernel_front_split.hip: fp16x3 split MFMA chain).
+//
+// One wave owns 16 chunks; lane (g, j) = (l>>4, l&15); the 4 lanes g of a chunk cooperate on each
+// of its 4 STFT frames.  Output is "mag layout" (layout.hpp): X[s], s < Q, = |Y[4s + P[g]]|, and
+// X[Q] = Nyquist magnitude in lane group 0.
+// (reference: JIT!/vad/model/vad_annotator.py:58-67 framing; JIT!/vad/utils/pytorch_stft.py:17-34;
+//  right reflect pad JIT!/torch/nn/modules/padding/___torch_mangle_8.py:6,10.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_api.hpp"
+#include "layout.hpp"
+
+namespace vad {
+namespace {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+
+#ifndef VAD_TRACE
+#define VAD_TRACE 0              // 1: workgroups write phase timestamps to FrontArgs::trace (tools/trace_front.py)
+#endif
+#ifndef VAD_ABLATE
+#define VAD_ABLATE 0             // timing experiments only (wrong results): 1 no barriers, 2 no FFT
+#endif                           // math, 4 no PCM loads, 8 no weight-ring loads
+
+// W_32^j = cos - i sin, j < 16 (fp32-rounded from double)
+__device__ constexpr float kCos32[16] = {1.0f, 0.98078525f, 0.9238795f, 0.8314696f, 0.70710677f,
+    0.55557024f, 0.38268343f, 0.19509032f, 0.0f, -0.19509032f, -0.38268343f, -0.55557024f,
+    -0.70710677f, -0.8314696f, -0.9238795f, -0.98078525f};
+__device__ constexpr float kSin32[16] = {0.0f, 0.19509032f, 0.38268343f, 0.55557024f, 0.70710677f,
+    0.8314696f, 0.9238795f, 0.98078525f, 1.0f, 0.98078525f, 0.9238795f, 0.8314696f, 0.70710677f,
+    0.55557024f, 0.38268343f, 0.19509032f};
+
+constexpr int bitrev(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+
+// ---- per-lane context ---------------------------------------------------------------------------
+struct Lane {
+    int lane, g, j, wave;
+    long t;                  // absolute time step of this wave's tile
+    long tl;                 // slab-relative
+    long st;                 // stream tile
+    int b;                   // stream of this lane (clamped to B-1)
+    bool tile_valid;         // wave-uniform
+    bool from_tail;          // wave-uniform: this is the last, partial chunk -> read a.tail
+    float sgnA, sgnB;        // +-1 butterfly signs for the cross-lane radix-4
+};
+
+// ---- PCM slice loads --------------------------------------------------------------------------------
+__device__ __forceinline__ void cvt8(const u32x4 v, float *o) {       // 8 x int16 -> float / 32768
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int lo = (int)(v[k] << 16) >> 16, hi = (int)v[k] >> 16;
+        o[2 * k] = (float)lo * (1.0f / 32768.0f);
+        o[2 * k + 1] = (float)hi * (1.0f / 32768.0f);
+    }
+}
+template <int SL>
+__device__ __forceinline__ void load_vec(const float *p, float (&s)[SL]) {
+#pragma unroll
+    for (int k = 0; k < SL / 4; ++k) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(p)[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
+    }
+}
+template <int SL>
+__device__ __forceinline__ void load_vec(const int16_t *p, float (&s)[SL]) {
+#pragma unroll
+    for (int k = 0; k < SL / 8; ++k) cvt8(reinterpret_cast<const u32x4 *>(p)[k], &s[8 * k]);
+}
+
+// slice V of the lane: s[i] = x[2Q*(2V+g) + i], x = ctx | chunk (| reflected tail for V==3,g==3).
+// Vector loads only: the engine guarantees 16-byte aligned rows, and hands the (zero padded) last
+// chunk of every stream in `tail` when L is not a multiple of the chunk size.
+template <int Q, int V, typename PcmT>
+__device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a, const Lane &ln) {
+    constexpr int SL = 2 * Q, N = 16 * Q;
+    const PcmT *row = reinterpret_cast<const PcmT *>(a.pcm) + (size_t)ln.b * a.ld;
+    const int sigma = 2 * V + ln.g;
+    const int sg = (V == 3 && sigma > 8) ? 8 : sigma;
+    const long p0 = (long)SL * (8 * ln.t - 1 + sg);          // stream-absolute index of s[0]
+    const PcmT *src = row + p0;
+    const PcmT *esrc = row + ((long)N * ln.t + N - SL - 1);   // x[16Q-1], for the reflect pad
+    if (ln.from_tail) {                                       // wave-uniform
+        const PcmT *trow = reinterpret_cast<const PcmT *>(a.tail) + (size_t)ln.b * N;
+        if (sg > 0) src = trow + SL * (sg - 1);
+        esrc = trow + (N - SL - 1);
+    }
+    if (VAD_ABLATE & 16) {
+        // timing experiment: same instruction count and bytes, but every instruction reads 1 KiB of
+        // ONE row (lane l <- 16 B at l*16), i.e. perfectly coalesced
+        const PcmT *r0 = reinterpret_cast<const PcmT *>(a.pcm) + (size_t)(ln.st * 16) * a.ld + (long)SL * 8 * ln.t;
+#pragma unroll
+        for (int k = 0; k < SL / 4; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(r0) + (size_t)(k & 15) * a.ld + ln.lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
+        }
+    } else if (VAD_ABLATE & 32) {
+        // timing experiment: the 4 lanes of a chunk read one contiguous 64-B segment per instruction
+        const float *rr = reinterpret_cast<const float *>(row) + (long)SL * 8 * ln.t;
+#pragma unroll
+        for (int k = 0; k < SL / 4; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(rr + 16 * k + 4 * ln.g + 128 * V);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
+        }
+    } else if (V == 0 && ln.t == 0 && ln.g == 0) load_vec<SL>(a.ctx_in + (size_t)ln.b * SL, s);
+    else load_vec<SL>(src, s);
+    if (V == 3) {
+        // context for the next call = last C = 2Q samples of the (zero padded) last chunk = slice 8
+        if (a.ctx_out && ln.t == a.T - 1 && ln.g == 2 && ln.tile_valid &&
+            (ln.st * 16 + ln.j) < a.B) {
+            float *o = a.ctx_out + (size_t)ln.b * SL;
+#pragma unroll
+            for (int k = 0; k < SL / 4; ++k)
+                reinterpret_cast<f32x4 *>(o)[k] = f32x4{s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]};
+        }
+        // right reflect pad: lanes g == 3 need x[18Q-2-i] = slice8[2Q-2-i] (i < 2Q-1), x[16Q-1] (i = 2Q-1)
+        const bool rev = ln.g == 3;
+        float extra = 0.f;
+        if (rev) extra = load_pcm(esrc);
+#pragma unroll
+        for (int i = 0; i < SL / 2 - 1; ++i) {
+            const int k = SL - 2 - i;                          // i <-> k, i < k
+            const float lo = s[i], hi = s[k];
+            s[i] = rev ? hi : lo;
+            s[k] = rev ? lo : hi;
+        }
+        s[SL - 1] = rev ? extra : s[SL - 1];
+    }
+}
+
+// ---- in-register Q-point complex FFT, DIF radix-2, output index bit-reversed ---------------------
+// Complex values are float2 (re, im) so that the butterflies compile to packed fp32 math
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two flops per lane per issue).  On gfx950 the fp32
+// MFMA and the VALU share one issue pipe per SIMD (tools/ubench/overlap.hip: their times add, they do
+// not overlap), so every VALU instruction saved here is kernel time saved.
+using f32x2 = float __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 swap2(f32x2 v) { return f32x2{v.y, v.x}; }
+// v * (c + i sn)
+__device__ __forceinline__ f32x2 cmul(f32x2 v, float c, float sn) {
+    return __builtin_elementwise_fma(swap2(v), f32x2{-sn, sn}, v * f32x2{c, c});
+}
+
+template <int Q>
+__device__ __forceinline__ void fft_inlane(f32x2 (&z)[Q]) {
+#pragma unroll
+    for (int n = Q; n >= 2; n >>= 1) {
+        const int half = n >> 1;
+#pragma unroll
+        for (int b0 = 0; b0 < Q; b0 += n) {
+#pragma unroll
+            for (int jx = 0; jx < half; ++jx) {
+                const int i0 = b0 + jx, i1 = i0 + half;
+                const f32x2 u = z[i0], v = z[i1];
+                z[i0] = u + v;
+                const f32x2 d = u - v;
+                const int tw = jx * (32 / n);                  // W_n^jx = W_32^(jx*32/n)
+                if (tw == 0) z[i1] = d;
+                else if (tw == 8) z[i1] = swap2(d) * f32x2{1.0f, -1.0f};        // * (-i)
+                else z[i1] = cmul(d, kCos32[tw], -kSin32[tw]);                   // * (c - i sn)
+            }
+        }
+    }
+}
+
+// One frame (V) of 16 chunks: X[s] (s < Q): |Y[4s + P[g]]|;  X[Q]: |Y[4Q]| in group 0, 0 elsewhere.
+template <int Q, int V, typename PcmT>
+__device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, const float *tab_lds,
+                                         const Lane &ln) {
+    constexpr int SL = 2 * Q;
+    constexpr vadl::Tab tb = vadl::make_tab(8 * Q, Q);
+    __builtin_amdgcn_sched_barrier(0);     // keep each pass's loads inside the pass (register budget)
+    float s[SL];
+    if (VAD_ABLATE & 4) {
+#pragma unroll
+        for (int i = 0; i < SL; ++i) s[i] = (float)(ln.lane + i) * 1e-3f;
+    } else {
+        load_slice<Q, V, PcmT>(s, a, ln);
+    }
+    if (VAD_ABLATE & 2) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) X[k] = s[k] + s[k + Q];
+        X[Q] = s[0];
+        return;
+    }
+
+    f32x2 z[Q];
+    {   // window (same taps for every frame: the lane's slice always sits at 2Q g inside the frame)
+        const f32x4 *w = reinterpret_cast<const f32x4 *>(tab_lds + tb.window + SL * ln.g);
+#pragma unroll
+        for (int k = 0; k < SL / 4; ++k) {
+            const f32x4 wv = w[k];
+            z[2 * k] = f32x2{s[4 * k], s[4 * k + 1]} * f32x2{wv[0], wv[1]};
+            z[2 * k + 1] = f32x2{s[4 * k + 2], s[4 * k + 3]} * f32x2{wv[2], wv[3]};
+        }
+    }
+    // radix-4 across the 4 lanes of a chunk.  Stage A pairs g <-> g^2, stage B pairs g <-> g^1.
+    const f32x4 *tw1 = reinterpret_cast<const f32x4 *>(tab_lds + tb.tw1 + ln.g * Q * 4);
+    const f32x2 sA{ln.sgnA, ln.sgnA}, sB{ln.sgnB, ln.sgnB};
+    // lane group 3 multiplies by -i between the two stages: x*rotA + swap(x)*rotB
+    const f32x2 rotA = ln.g == 3 ? f32x2{0.f, 0.f} : f32x2{1.f, 1.f};
+    const f32x2 rotB = ln.g == 3 ? f32x2{1.f, -1.f} : f32x2{0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        f32x2 x = z[q];
+        const f32x2 p{__shfl_xor(x.x, 32), __shfl_xor(x.y, 32)};
+        x = __builtin_elementwise_fma(sA, x, p);       // g<2: own + partner ; g>=2: partner - own
+        x = __builtin_elementwise_fma(swap2(x), rotB, x * rotA);
+        const f32x2 r{__shfl_xor(x.x, 16), __shfl_xor(x.y, 16)};
+        x = __builtin_elementwise_fma(sB, x, r);       // g even: own + partner ; g odd: partner - own
+        const f32x4 t = tw1[q];                        // * W_4Q^(P[g] q): (-s, s, c, 0)
+        z[q] = __builtin_elementwise_fma(swap2(x), f32x2{t[0], t[1]}, x * f32x2{t[2], t[2]});
+    }
+    fft_inlane<Q>(z);
+    // real-FFT split: Y[k] = E + W_8Q^k O from Z[k] and conj Z[4Q - k]
+    constexpr int LG = ilog2(Q);
+    const f32x4 *tw2 = reinterpret_cast<const f32x4 *>(tab_lds + tb.tw2 + ln.g * Q * 4);
+    // partner bin 8Q - k lives in the same lane for groups 0, 1 and in lane ^ 16 for groups 2, 3
+    const int src_lane4 = (ln.g >= 2 ? (ln.lane ^ 16) : ln.lane) * 4;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const f32x2 u = z[bitrev(k, LG)];
+        const int ks = bitrev((Q - k) % Q, LG), kr = bitrev(Q - 1 - k, LG);
+        const f32x2 own = z[kr], alt = z[ks];
+        const float xr = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane4, __float_as_int(own.x)));
+        const float xi = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane4, __float_as_int(own.y)));
+        const f32x2 p{ln.g == 0 ? alt.x : xr, ln.g == 0 ? alt.y : xi};
+        const f32x2 av = __builtin_elementwise_fma(p, f32x2{1.0f, -1.0f}, u);     // Z + conj(Zp)
+        const f32x2 ev = __builtin_elementwise_fma(p, f32x2{-1.0f, 1.0f}, u);     // Z - conj(Zp)
+        // y = av + (-i ev) (c + i sn) = av + ev (sn - i c)
+        const f32x4 t = tw2[k];                                                  // (c, -c, s, 0)
+        const f32x2 y = __builtin_elementwise_fma(swap2(ev), f32x2{t[0], t[1]},
+                                                  __builtin_elementwise_fma(ev, f32x2{t[2], t[2]}, av));
+        const f32x2 yy = y * y;
+        X[k] = 0.5f * __builtin_amdgcn_sqrtf(yy.x + yy.y);
+    }
+    X[Q] = ln.g == 0 ? fabsf(z[0].x - z[0].y) : 0.f;           // Nyquist: Re Z0 - Im Z0
+}
+
+}  // namespace
+}  // namespace vad

@@ -1,0 +1,389 @@
+// kernel_front_split.hip -- the time-parallel part of the path (same function as kernel_front.hip:
+// PCM -> framing -> 4 x real-FFT magnitude -> 4 x ReLU(Conv1d k=3) -> W_ih * feat + b  => gx), with
+// every matrix product evaluated as an fp16 x 3 "split" product on the f16 matrix cores:
+//
+//     a = a_hi + a_lo,  b = b_hi + b_lo   (hi = fp16(x), lo = fp16(x - hi), round to nearest)
+//     a b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi          (dropped term a_lo b_lo < 2^-22 |a b|)
+//
+// accumulated in fp32 by v_mfma_f32_16x16x32_f16.  Operands keep 22 significant bits, sums are fp32:
+// measured against the reference this is indistinguishable from the exact-fp32 chain (both ~2e-6 on
+// the speech probability, tests/test_gpu_parity.py), while gfx950 runs f16 MFMA at 16x the rate of
+// f32 MFMA (MI355X_MICROARCH.md: 2.5 PFLOP/s vs 157 TFLOP/s), i.e. 16/3 = 5.3x fewer matrix-pipe
+// cycles for the same contraction.
+//
+// (reference: JIT!/vad/model/vad_annotator.py:58-67 framing, JIT!/vad/utils/pytorch_stft.py:17-34
+//  STFT, JIT!/vad/utils/model_utils.py:19-25 encoder, the W_ih half of aten::lstm_cell
+//  JIT!/torch/nn/modules/rnn.py:69.)
+//
+// What changes with the matrix pipe 5x faster is what bounds the kernel: LDS bandwidth for the A
+// (weight) fragments.  Hence, relative to kernel_front.hip:
+//   * an A fragment read from LDS is used for TWO frames where the conv taps allow it (enc0 is
+//     evaluated for frame pairs (0,1) and (2,3); 1.67 uses per fragment on average);
+//   * enc0 is evaluated in two halves of its output rows and enc1 in the matching halves of its
+//     K dimension, which keeps only 2 x 4 accumulator blocks of enc0 live;
+//   * the Nyquist bin (the 129th / 65th input channel of enc0, alone in a fifth K step) is applied as
+//     an fp32 rank-1 VALU update instead of an almost empty MFMA step;
+//   * activations are converted to (hi, lo) half pairs once, when produced (5 VALU per 2 values), and
+//     live in registers as the packed B operands of the next layer (chain layout, layout.hpp).
+// Range: fp16 overflows at 65504.  |pcm| <= 1 keeps every activation below ~5.3e3 on all inputs tried
+// (sines, square waves, noise, speech); a lane that nevertheless sees |x| > 65000 poisons its chunk's
+// gx with NaN, which kernel_rec_split.hip propagates to the probability, so an out-of-range input is
+// reported as NaN (the host wrapper reruns it with precision=fp32) and never as a wrong number.
+#include <hip/hip_runtime.h>
+
+#include "fft_wave.hpp"
+
+namespace vad {
+namespace {
+
+using h8 = _Float16 __attribute__((ext_vector_type(8)));
+using h2 = _Float16 __attribute__((ext_vector_type(2)));
+
+#ifndef VAD_SPLIT_SLOT_BLOCKS
+#define VAD_SPLIT_SLOT_BLOCKS 32   // 1-KiB blocks per ring slot = 16 (u, mblock) pairs
+#endif
+constexpr int kSB = VAD_SPLIT_SLOT_BLOCKS;
+constexpr int kSlotWords = kSB * 256;
+constexpr float kHalfLimit = 65000.f;
+
+struct SRing {
+    unsigned *slots;           // LDS, 2 x kSlotWords
+    const unsigned *w;         // global split image
+    int unit;                  // units consumed so far (wave-uniform)
+};
+struct Bop {                   // B operand of one K32 step: 8 halves hi, 8 halves lo
+    u32x4 hi, lo;
+};
+
+template <int BLOCKS>
+__device__ __forceinline__ void sring_issue(const SRing &r, long woff, int slot, const Lane &ln) {
+    // BLOCKS x 1 KiB, wave w copies blocks w, w+4, ...; global_load_lds issued from asm for the reason
+    // given in kernel_front.hip (ring_issue): keeps the compiler's lgkmcnt waits fine-grained.
+    static_assert(BLOCKS % 4 == 0 && BLOCKS <= kSB, "unit must be whole 4-block groups");
+    if (VAD_ABLATE & 8) return;
+    const unsigned *gbase = r.w + woff + (long)ln.wave * 256;
+    const unsigned voff = ln.lane * 16;
+    const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned *)(r.slots + slot * kSlotWords))
+                           + (unsigned)ln.wave * 1024u;
+#pragma unroll
+    for (int blk = 0; blk < BLOCKS; blk += 4) {
+        const unsigned *src = gbase + (long)blk * 256;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lbase + (unsigned)blk * 1024u);
+        unsigned keep_m0;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep_m0)
+                     : "v"(voff), "s"(src), "s"(dst)
+                     : "memory");
+    }
+}
+__device__ __forceinline__ void sring_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+constexpr int seg_blocks(int M, int U) { return 2 * M * U; }
+constexpr int first_blocks(int M, int U) { return seg_blocks(M, U) < kSB ? seg_blocks(M, U) : kSB; }
+
+// One segment = U K32-steps x M row blocks, streamed as ring units of up to kSB/2 (u, mblock) pairs.
+// NUSE accumulator sets share every A fragment:  acc0 += A * b0,  (NUSE == 2:) acc1 += A * b1.
+// b*(u) returns the packed B operand of K32 step u (compile-time u).  NEXT_BLOCKS / next_off describe
+// the first unit of the segment that follows in program order (prefetch; 0 = none).
+template <int M, int U, int NEXT_BLOCKS, int NUSE, class BF0, class BF1>
+__device__ __forceinline__ void gemm_split(f32x4 (&acc0)[M], BF0 b0, f32x4 (&acc1)[M], BF1 b1, SRing &ring,
+                                           long seg_off, long next_off, const Lane &ln) {
+    constexpr int PAIRS = U * M, PPU = kSB / 2, NU = (PAIRS + PPU - 1) / PPU;
+    static_assert(PPU % M == 0 && M % 2 == 0, "a unit holds whole K32 steps; steps take two row blocks");
+#pragma unroll
+    for (int un = 0; un < NU; ++un) {
+        sring_wait();
+        if (!(VAD_ABLATE & 1)) __syncthreads();        // unit landed for every wave; other slot free
+        const int slot = ring.unit & 1;
+        constexpr int LASTP = PAIRS - (NU - 1) * PPU;  // pairs in the segment's last unit
+        const int np = (un + 1 < NU) ? PPU : LASTP;
+        if (un + 1 < NU) {
+            const long off = seg_off + (long)(un + 1) * PPU * 512;
+            if (un + 2 < NU) sring_issue<2 * PPU>(ring, off, slot ^ 1, ln);
+            else sring_issue<2 * LASTP>(ring, off, slot ^ 1, ln);
+        } else if (NEXT_BLOCKS > 0) {
+            sring_issue<(NEXT_BLOCKS > 0 ? NEXT_BLOCKS : 4)>(ring, next_off, slot ^ 1, ln);
+        }
+        // A step = two row blocks of one K32 step: fragments (hi, lo) x 2, 6 (12) MFMAs ordered so that
+        // MFMAs on the same accumulator are never adjacent.  The fragments of step i+1 are read from
+        // LDS before the MFMAs of step i issue (explicit double buffer, as in kernel_front.hip).
+        const u32x4 *A = reinterpret_cast<const u32x4 *>(ring.slots + slot * kSlotWords) + ln.lane;
+        u32x4 c0 = A[0], c1 = A[64], c2 = A[128], c3 = A[192];
+#pragma unroll
+        for (int st = 0; st < PPU / 2; ++st) {
+            if (st < np / 2) {
+                u32x4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+                if (st + 1 < np / 2) {
+                    n0 = A[(4 * (st + 1) + 0) * 64];
+                    n1 = A[(4 * (st + 1) + 1) * 64];
+                    n2 = A[(4 * (st + 1) + 2) * 64];
+                    n3 = A[(4 * (st + 1) + 3) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int p = un * PPU + 2 * st, u = p / M, m = p % M;
+                const Bop x0 = b0(u);
+                acc0[m] = mfma_h(c0, x0.hi, acc0[m]);
+                acc0[m + 1] = mfma_h(c2, x0.hi, acc0[m + 1]);
+                if (NUSE == 2) {
+                    const Bop x1 = b1(u);
+                    acc1[m] = mfma_h(c0, x1.hi, acc1[m]);
+                    acc1[m + 1] = mfma_h(c2, x1.hi, acc1[m + 1]);
+                    acc0[m] = mfma_h(c0, x0.lo, acc0[m]);
+                    acc0[m + 1] = mfma_h(c2, x0.lo, acc0[m + 1]);
+                    acc1[m] = mfma_h(c0, x1.lo, acc1[m]);
+                    acc1[m + 1] = mfma_h(c2, x1.lo, acc1[m + 1]);
+                    acc0[m] = mfma_h(c1, x0.hi, acc0[m]);
+                    acc0[m + 1] = mfma_h(c3, x0.hi, acc0[m + 1]);
+                    acc1[m] = mfma_h(c1, x1.hi, acc1[m]);
+                    acc1[m + 1] = mfma_h(c3, x1.hi, acc1[m + 1]);
+                } else {
+                    acc0[m] = mfma_h(c0, x0.lo, acc0[m]);
+                    acc0[m + 1] = mfma_h(c2, x0.lo, acc0[m + 1]);
+                    acc0[m] = mfma_h(c1, x0.hi, acc0[m]);
+                    acc0[m + 1] = mfma_h(c3, x0.hi, acc0[m + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            }
+        }
+        ring.unit++;
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[M], const float *bias_lds, const Lane &ln) {
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        acc[m] = *reinterpret_cast<const f32x4 *>(bias_lds + 16 * m + 4 * ln.g);
+}
+
+// (x0, x1) -> packed halves hi, lo; mx tracks the largest magnitude converted
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo, float &mx) {
+    const f32x2 v{x0, x1};
+    const h2 h = __builtin_convertvector(v, h2);                 // v_cvt_pk_f16_f32 (RTN)
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);       // exact
+    const h2 l = __builtin_convertvector(r, h2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+    mx = fmaxf(mx, fmaxf(fabsf(x0), fabsf(x1)));                 // v_max3_f32 |.| |.|
+}
+// ReLU + split of NB D-fragment blocks into NB/2 K32-step operands (chain layout)
+template <int NB>
+__device__ __forceinline__ void relu_pack(const f32x4 (&D)[NB], Bop (&B)[NB / 2], float &mx) {
+#pragma unroll
+    for (int u = 0; u < NB / 2; ++u) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x4 d = D[2 * u + (p >> 1)];
+            const int r = 2 * (p & 1);
+            unsigned hi, lo;
+            split2(fmaxf(d[r], 0.f), fmaxf(d[r + 1], 0.f), hi, lo, mx);
+            B[u].hi[p] = hi;
+            B[u].lo[p] = lo;
+        }
+    }
+}
+// mag layout -> K32-step operands: slot (g, e) of step u = X[8u + e]
+template <int Q>
+__device__ __forceinline__ void pack_mag(const float (&X)[Q + 1], Bop (&B)[Q / 8], float &mx) {
+#pragma unroll
+    for (int u = 0; u < Q / 8; ++u)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned hi, lo;
+            split2(X[8 * u + 2 * p], X[8 * u + 2 * p + 1], hi, lo, mx);
+            B[u].hi[p] = hi;
+            B[u].lo[p] = lo;
+        }
+}
+// Nyquist bin: Y[row] += w_nyq[tap][row] * |Y_nyq| of the chunk, exact fp32
+__device__ __forceinline__ void nyq_update(f32x4 (&Y)[4], float xn, const float *wn_lds, const Lane &ln) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(wn_lds + 16 * m + 4 * ln.g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[m][r] = fmaf(w[r], xn, Y[m][r]);
+    }
+}
+
+template <int Q, typename PcmT>
+__global__ void __launch_bounds__(256, 2) front_split_kernel(const FrontArgs a) {
+    using namespace vadl;
+    constexpr Tab tb = make_tab(8 * Q, Q);
+    constexpr int TABF = (tb.total + 3) / 4 * 4;
+    constexpr int U0 = Q / 8;
+    __shared__ __attribute__((aligned(16))) float lds[TABF + 2 * kSlotWords];
+    float *tab = lds;
+
+    Lane ln;
+    ln.lane = threadIdx.x & 63;
+    ln.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    ln.g = ln.lane >> 4;
+    ln.j = ln.lane & 15;
+    const long nst = (a.B + 15) / 16, total = nst * a.nt;
+    long wt = (long)blockIdx.x * 4 + ln.wave;
+    ln.tile_valid = wt < total;
+    if (!ln.tile_valid) wt = total - 1;
+    ln.tl = wt % a.nt;
+    ln.st = wt / a.nt;
+    ln.t = a.t0 + ln.tl;
+    const long bb = ln.st * 16 + ln.j;
+    ln.b = (int)(bb < a.B ? bb : a.B - 1);
+    ln.from_tail = a.tail != nullptr && ln.t == a.T - 1;
+    ln.sgnA = ln.g < 2 ? 1.f : -1.f;
+    ln.sgnB = (ln.g & 1) ? -1.f : 1.f;
+
+    SRing ring{reinterpret_cast<unsigned *>(lds + TABF), reinterpret_cast<const unsigned *>(a.wfront), 0};
+    auto off = [](int s) { return sseg_offset(s, Q); };
+    constexpr int FB_E0 = first_blocks(4, U0), FB_E1 = first_blocks(4, 2), FB_E2 = first_blocks(4, 2),
+                  FB_E3 = first_blocks(8, 2), FB_IH = first_blocks(8, 4);
+
+    sring_issue<FB_E0>(ring, off(SE0 + 0), 0, ln);      // first unit of the program
+    for (int i = threadIdx.x; i < tb.total; i += 256) tab[i] = a.tables[i];
+    __syncthreads();
+
+    float mx = 0.f;
+    Bop X0[U0], X1[U0], X2[U0], X3[U0];
+    float xn0, xn1, xn2, xn3;
+    {
+        float Xf[Q + 1];
+        fft_pass<Q, 0, PcmT>(Xf, a, tab, ln);
+        pack_mag<Q>(Xf, X0, mx);
+        xn0 = __shfl(Xf[Q], ln.j);
+        fft_pass<Q, 1, PcmT>(Xf, a, tab, ln);
+        pack_mag<Q>(Xf, X1, mx);
+        xn1 = __shfl(Xf[Q], ln.j);
+        fft_pass<Q, 2, PcmT>(Xf, a, tab, ln);
+        pack_mag<Q>(Xf, X2, mx);
+        xn2 = __shfl(Xf[Q], ln.j);
+    }
+    mx = fmaxf(mx, fmaxf(xn0, fmaxf(xn1, xn2)));
+    auto bX0 = [&](int u) { return X0[u]; };
+    auto bX1 = [&](int u) { return X1[u]; };
+    auto bX2 = [&](int u) { return X2[u]; };
+    auto bX3 = [&](int u) { return X3[u]; };
+
+    f32x4 Z0[4], Z1[4];
+    init_bias<4>(Z0, tab + tb.b_e1, ln);
+    init_bias<4>(Z1, tab + tb.b_e1, ln);
+    const float *wn = tab + tb.w_nyq;
+
+    // ---- frames 0 and 1 of enc0 (rows 64h..64h+63) -> enc1 out 0 taps 1,2 and out 1 tap 0 ------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 Ya[4], Yb[4];                              // enc0 frame 0, frame 1
+        init_bias<4>(Ya, tab + tb.b_e0 + 64 * h, ln);
+        init_bias<4>(Yb, tab + tb.b_e0 + 64 * h, ln);
+        gemm_split<4, U0, FB_E0, 1>(Yb, bX0, Yb, bX0, ring, off(SE0 + 6 * h + 0), off(SE0 + 6 * h + 1), ln);
+        gemm_split<4, U0, FB_E0, 2>(Ya, bX0, Yb, bX1, ring, off(SE0 + 6 * h + 1), off(SE0 + 6 * h + 2), ln);
+        gemm_split<4, U0, FB_E1, 2>(Ya, bX1, Yb, bX2, ring, off(SE0 + 6 * h + 2), off(SE1 + 6 * h + 1), ln);
+        nyq_update(Yb, xn0, wn + 0 * 128 + 64 * h, ln);
+        nyq_update(Ya, xn0, wn + 1 * 128 + 64 * h, ln);
+        nyq_update(Yb, xn1, wn + 1 * 128 + 64 * h, ln);
+        nyq_update(Ya, xn1, wn + 2 * 128 + 64 * h, ln);
+        nyq_update(Yb, xn2, wn + 2 * 128 + 64 * h, ln);
+        Bop Pa[2], Pb[2];
+        relu_pack<4>(Ya, Pa, mx);
+        relu_pack<4>(Yb, Pb, mx);
+        auto bPa = [&](int u) { return Pa[u]; };
+        auto bPb = [&](int u) { return Pb[u]; };
+        gemm_split<4, 2, FB_E1, 1>(Z0, bPa, Z0, bPa, ring, off(SE1 + 6 * h + 1), off(SE1 + 6 * h + 2), ln);
+        gemm_split<4, 2, FB_E1, 1>(Z0, bPb, Z0, bPb, ring, off(SE1 + 6 * h + 2), off(SE1 + 6 * h + 0), ln);
+        // after h = 1 the next segment is phase B's first (SE0 h=0 tap 0)
+        gemm_split<4, 2, FB_E0, 1>(Z1, bPb, Z1, bPb, ring, off(SE1 + 6 * h + 0), off(SE0 + (h == 0 ? 6 : 0)), ln);
+    }
+
+    {
+        float Xf[Q + 1];
+        fft_pass<Q, 3, PcmT>(Xf, a, tab, ln);
+        pack_mag<Q>(Xf, X3, mx);
+        xn3 = __shfl(Xf[Q], ln.j);
+        mx = fmaxf(mx, xn3);
+    }
+
+    // ---- frames 2 and 3 of enc0 -> enc1 out 1 taps 1,2 -------------------------------------------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 Ya[4], Yb[4];                              // enc0 frame 2, frame 3
+        init_bias<4>(Ya, tab + tb.b_e0 + 64 * h, ln);
+        init_bias<4>(Yb, tab + tb.b_e0 + 64 * h, ln);
+        gemm_split<4, U0, FB_E0, 2>(Ya, bX1, Yb, bX2, ring, off(SE0 + 6 * h + 0), off(SE0 + 6 * h + 1), ln);
+        gemm_split<4, U0, FB_E0, 2>(Ya, bX2, Yb, bX3, ring, off(SE0 + 6 * h + 1), off(SE0 + 6 * h + 2), ln);
+        gemm_split<4, U0, FB_E1, 1>(Ya, bX3, Ya, bX3, ring, off(SE0 + 6 * h + 2), off(SE1 + 6 * h + 1), ln);
+        nyq_update(Ya, xn1, wn + 0 * 128 + 64 * h, ln);
+        nyq_update(Yb, xn2, wn + 0 * 128 + 64 * h, ln);
+        nyq_update(Ya, xn2, wn + 1 * 128 + 64 * h, ln);
+        nyq_update(Yb, xn3, wn + 1 * 128 + 64 * h, ln);
+        nyq_update(Ya, xn3, wn + 2 * 128 + 64 * h, ln);
+        Bop Pa[2], Pb[2];
+        relu_pack<4>(Ya, Pa, mx);
+        relu_pack<4>(Yb, Pb, mx);
+        auto bPa = [&](int u) { return Pa[u]; };
+        auto bPb = [&](int u) { return Pb[u]; };
+        gemm_split<4, 2, FB_E1, 1>(Z1, bPa, Z1, bPa, ring, off(SE1 + 6 * h + 1), off(SE1 + 6 * h + 2), ln);
+        if (h == 0)
+            gemm_split<4, 2, FB_E0, 1>(Z1, bPb, Z1, bPb, ring, off(SE1 + 6 * h + 2), off(SE0 + 6), ln);
+        else
+            gemm_split<4, 2, FB_E2, 1>(Z1, bPb, Z1, bPb, ring, off(SE1 + 6 * h + 2), off(SE2T1), ln);
+    }
+
+    // ---- enc2 (stride 2, taps 1,2 see enc1 outputs 0,1), enc3 (centre tap), W_ih ----------------------
+    Bop Q0[2], Q1[2];
+    relu_pack<4>(Z0, Q0, mx);
+    relu_pack<4>(Z1, Q1, mx);
+    auto bQ0 = [&](int u) { return Q0[u]; };
+    auto bQ1 = [&](int u) { return Q1[u]; };
+    f32x4 Vv[4];
+    init_bias<4>(Vv, tab + tb.b_e2, ln);
+    gemm_split<4, 2, FB_E2, 1>(Vv, bQ0, Vv, bQ0, ring, off(SE2T1), off(SE2T2), ln);
+    gemm_split<4, 2, FB_E3, 1>(Vv, bQ1, Vv, bQ1, ring, off(SE2T2), off(SE3T1), ln);
+    Bop Pv[2];
+    relu_pack<4>(Vv, Pv, mx);
+    auto bPv = [&](int u) { return Pv[u]; };
+    f32x4 Fe[8];
+    init_bias<8>(Fe, tab + tb.b_e3, ln);
+    gemm_split<8, 2, FB_IH, 1>(Fe, bPv, Fe, bPv, ring, off(SE3T1), off(SIH0), ln);
+    Bop Pf[4];
+    relu_pack<8>(Fe, Pf, mx);
+    auto bPf = [&](int u) { return Pf[u]; };
+
+    const bool bad = !(mx < kHalfLimit);                 // out of fp16 range (or NaN input): poison
+    const float nanv = __builtin_nanf("");
+    float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32) * 256 + ln.lane * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 G[8];
+        init_bias<8>(G, tab + tb.b_g + 128 * q, ln);
+        if (q < 3) gemm_split<8, 4, FB_IH, 1>(G, bPf, G, bPf, ring, off(SIH0 + q), off(SIH0 + q + 1), ln);
+        else gemm_split<8, 4, 0, 1>(G, bPf, G, bPf, ring, off(SIH3), 0, ln);
+        if (ln.tile_valid) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                f32x4 v = G[m];
+                if (bad) v = f32x4{nanv, nanv, nanv, nanv};
+                *reinterpret_cast<f32x4 *>(gxt + (size_t)(8 * q + m) * 256) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+template <typename PcmT>
+hipError_t launch_front_split(int sr, const FrontArgs &a, hipStream_t s) {
+    if (a.B <= 0 || a.nt <= 0) return hipSuccess;
+    const long nst = (a.B + 15) / 16, total = nst * a.nt;
+    const unsigned grid = (unsigned)((total + 3) / 4);
+    if (sr == 16000) hipLaunchKernelGGL((front_split_kernel<32, PcmT>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((front_split_kernel<16, PcmT>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+template hipError_t launch_front_split<float>(int, const FrontArgs &, hipStream_t);
+template hipError_t launch_front_split<int16_t>(int, const FrontArgs &, hipStream_t);
+
+}  // namespace vad

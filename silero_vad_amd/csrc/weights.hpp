@@ -24,7 +24,9 @@ struct PackedNet {
     vadl::Geo geo{};
     std::vector<float> front;    // frontend GEMM stream (layout.hpp Seg order)
     std::vector<float> whh;      // recurrent image
-    std::vector<float> tables;   // biases, head, window, twiddles
+    std::vector<float> tables;   // biases, head, window, twiddles, Nyquist-bin weights
+    std::vector<uint16_t> front_split;   // fp16 hi/lo frontend image (layout.hpp SSeg order)
+    std::vector<uint16_t> whh_split;     // fp16 hi/lo recurrent image
 };
 
 struct Weights {

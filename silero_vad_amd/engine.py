@@ -46,6 +46,10 @@ class Engine:
         impl = os.environ.get("SILERO_VAD_AMD_IMPL")
         if impl:
             self.set_option("impl", impl)
+        self.precision = "f16x3"                     # the engine's default (include/silero_vad_hip.h)
+        prec = os.environ.get("SILERO_VAD_AMD_PRECISION")
+        if prec:
+            self.set_precision(prec)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -59,6 +63,11 @@ class Engine:
 
     def set_option(self, name, value):
         check(self._h, lib().vad_set_option(self._h, name.encode(), str(value).encode()))
+
+    def set_precision(self, precision):
+        """"f16x3" (fp16 x 3 split products on the f16 matrix cores, fp32 sums) | "fp32" (exact)."""
+        self.set_option("precision", precision)
+        self.precision = precision
 
     def reserve(self, sr, B, T):
         check(self._h, lib().vad_reserve(self._h, sr, B, T))
@@ -109,11 +118,38 @@ class Engine:
 class HipSileroVAD:
     """Drop-in for the reference's model object (TorchScript `VADRNNJITMerge` / `OnnxWrapper`)."""
 
-    def __init__(self, device=0, engine=None):
+    def __init__(self, device=0, engine=None, precision="auto"):
+        """precision: "auto" (default) runs the f16x3 kernels and transparently reruns a call in exact
+        fp32 if it reports an out-of-fp16-range input (NaN probability; include/silero_vad_hip.h,
+        option "precision"); "f16x3" / "fp32" pin one implementation."""
+        if precision not in ("auto", "f16x3", "fp32"):
+            raise ValueError("precision must be auto|f16x3|fp32")
         self.engine = engine or Engine(device)
+        self.precision = precision
+        if precision != "auto":
+            self.engine.set_precision(precision)
         self.device = torch.device("cuda", self.engine.device)
         self.sample_rates = [8000, 16000]
         self.reset_states()
+
+    def _guarded(self, run):
+        """Run `run()` (which advances self._state / self._context in place and returns probabilities);
+        in "auto" mode, if the f16x3 kernels flag the input (NaN), restore the carried state and rerun
+        in fp32.  The check reads the probabilities back, i.e. synchronises, as every caller of the
+        reference protocol does anyway (`.item()` / `.cpu()`)."""
+        if self.precision != "auto" or self.engine.precision != "f16x3":
+            return run()
+        st0, ctx0 = self._state.clone(), self._context.clone()
+        out = run()
+        if bool(torch.isnan(out).any()):
+            self._state.copy_(st0)
+            self._context.copy_(ctx0)
+            self.engine.set_precision("fp32")
+            try:
+                out = run()
+            finally:
+                self.engine.set_precision("f16x3")
+        return out
 
     # -- reference: vad_annotator.py:91-127 / utils_vad.py:33-49 --------------------------------------
     def _validate_input(self, x, sr: int):
@@ -167,7 +203,7 @@ class HipSileroVAD:
             if xd.dtype == torch.int16:
                 xd = xd.to(torch.float32) / 32768.0
             out = torch.empty((batch_size, 1), dtype=torch.float32, device=self.device)
-            self.engine.step(xd, sr, self._context, self._state, out)
+            out = self._guarded(lambda: self.engine.step(xd, sr, self._context, self._state, out))
         self._last_sr = sr
         self._last_batch_size = batch_size
         return out
@@ -176,23 +212,25 @@ class HipSileroVAD:
 
     # -- reference: vad_annotator.py:128-156 (returns a CPU tensor, like the reference) ----------------
     def audio_forward(self, x, sr: int):
-        return self.audio_forward_device(x, sr).cpu()
+        return self.audio_forward_device(x, sr, guarded=True).cpu()
 
-    def audio_forward_device(self, x, sr: int):
-        """audio_forward that leaves the probabilities in HBM (no host sync)."""
+    def audio_forward_device(self, x, sr: int, guarded=False):
+        """audio_forward that leaves the probabilities in HBM (no host sync unless `guarded`)."""
         x, sr = self._validate_input(x, sr)
         self.reset_states()
         batch_size = x.shape[0]
         self._ensure_state(sr, batch_size)
         with torch.cuda.device(self.device):
             xd = self._to_device(x)
-            probs = self.engine.forward_audio(xd, sr, self._context, self._state)
+            run = lambda: self.engine.forward_audio(xd, sr, self._context, self._state)
+            probs = self._guarded(run) if guarded else run()
         self._last_sr = sr
         self._last_batch_size = batch_size
         return probs
 
 
-def load_silero_vad(onnx=False, opset_version=16, device=0):
-    """Reference signature (src/silero_vad/model.py:6) plus `device`.  `onnx`/`opset_version` are
-    accepted for source compatibility and ignored: there is one backend, the HIP engine."""
-    return HipSileroVAD(device=device)
+def load_silero_vad(onnx=False, opset_version=16, device=0, precision="auto"):
+    """Reference signature (src/silero_vad/model.py:6) plus `device` and `precision`.
+    `onnx`/`opset_version` are accepted for source compatibility and ignored: there is one backend,
+    the HIP engine."""
+    return HipSileroVAD(device=device, precision=precision)

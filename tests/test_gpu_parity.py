@@ -21,13 +21,16 @@ TOL = 1e-4          # the contract
 TIGHT = 2e-5        # what fp32 in a different summation order actually delivers; regression guard
 
 
-@pytest.fixture(scope="module")
-def model(built):
+@pytest.fixture(scope="module", params=["f16x3", "fp32"])
+def model(built, request):
+    """Every parity test runs against both arithmetic implementations of the engine: the default
+    fp16x3 split MFMA kernels and the exact-fp32 MFMA kernels (option "precision")."""
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU (there is no CPU fallback to silently pass on)")
     from silero_vad_amd import load_silero_vad
-    m = load_silero_vad(device=0)
+    m = load_silero_vad(device=0, precision=request.param)
     assert m.engine._h, "native engine not created"
+    assert m.engine.precision == request.param
     return m
 
 
@@ -385,3 +388,71 @@ def test_ragged_corpus_equals_single_recording_runs(model, golden, tag):
         single_s = [get_speech_timestamps(a, model, sampling_rate=sr, return_seconds=True) for a in audios]
     assert batch == single and batch_s == single_s
     assert sum(len(s) for s in single) > 10
+
+
+# ---- (5) the fp16x3 split arithmetic: what it relies on, and its range guard -------------------------
+def _probe(model, a, b):
+    from silero_vad_amd import _lib
+    a = np.ascontiguousarray(a, np.float16)
+    b = np.ascontiguousarray(b, np.float16)
+    d = np.empty((64, 4), np.float32)
+    _lib.check(model.engine._h, _lib.lib().vad_debug_mfma_f16(
+        model.engine._h, a.ctypes.data, b.ctypes.data, d.ctypes.data))
+    return d
+
+
+def test_f16_mfma_slot_pairing_and_subnormals(model):
+    """v_mfma_f32_16x16x32_f16 as the split kernels use it: slot (g, e) of A pairs with slot (g, e) of
+    B (tests/emu_wave.py mfma_16x16x32_f16 is the specification), products and sums are exact in fp32,
+    and fp16 subnormal inputs are NOT flushed -- the lo halves of small activations live there."""
+    import emu_wave as E
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((64, 8)).astype(np.float16)
+    b = rng.standard_normal((64, 8)).astype(np.float16)
+    want = E.mfma_16x16x32_f16(a, b, np.zeros((4, 64), np.float32))          # [r][lane]
+    got = _probe(model, a, b)
+    assert np.abs(got.T - want).max() < 1e-5
+    # subnormal halves (|x| < 2^-14) times normal halves
+    a = (rng.integers(1, 1024, (64, 8)) * 2.0 ** -24).astype(np.float16)      # all subnormal
+    assert np.all(np.abs(a.astype(np.float32)) < 2.0 ** -14) and np.all(a != 0)
+    b = rng.integers(1, 64, (64, 8)).astype(np.float16)
+    want = E.mfma_16x16x32_f16(a, b, np.zeros((4, 64), np.float32))
+    got = _probe(model, a, b)
+    assert np.all(want != 0)
+    assert np.array_equal(got.T, want), "fp16 subnormal operands were flushed"
+    got = _probe(model, b, a)                                                 # subnormal B operand
+    want = E.mfma_16x16x32_f16(b, a, np.zeros((4, 64), np.float32))
+    assert np.array_equal(got.T, want), "fp16 subnormal B operands were flushed"
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_split_range_guard(model, oracle, golden, tag):
+    """An input far outside [-1, 1] drives activations past the fp16 range: the f16x3 kernels must
+    answer NaN for that stream (and only that stream), the fp32 kernels and the "auto" wrapper must
+    answer what the oracle answers."""
+    from silero_vad_amd import HipSileroVAD
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    B, T = 18, 6
+    rows = rolled_rows(g["wav"], B, T * n, 4001).copy()
+    rows[5] *= 3000.0
+    rows[17, 2 * n:] *= 3000.0                  # goes out of range from chunk 2 on
+    want, _, _ = oracle.forward_audio(rows, sr)
+    probs, _, _ = run_engine(model, rows, sr)
+    ok = [b for b in range(B) if b not in (5, 17)]
+    assert np.abs(probs[ok] - want[ok]).max() < TIGHT
+    if model.engine.precision == "f16x3":
+        assert np.isnan(probs[5]).all()
+        assert np.abs(probs[17, :2] - want[17, :2]).max() < TIGHT and np.isnan(probs[17, 2:]).all()
+    else:
+        assert np.abs(probs - want).max() < TOL
+    auto = HipSileroVAD(engine=model.engine, precision="auto")
+    before = model.engine.precision
+    got = auto.audio_forward(torch.from_numpy(rows), sr).numpy()
+    assert model.engine.precision == before
+    assert np.abs(got - want).max() < TOL
+    # per-chunk protocol through the guard
+    auto.reset_states()
+    for t in range(T):
+        p = auto(torch.from_numpy(rows[:, t * n:(t + 1) * n]), sr).cpu().numpy()[:, 0]
+        assert np.abs(p - want[:, t]).max() < TOL, t

@@ -16,7 +16,8 @@ from pathlib import Path
 
 
 def short(name):
-    for key in ("front_kernel", "rec_kernel", "ref_forward_kernel", "unpack_gx"):
+    for key in ("front_split_kernel", "rec_split_kernel", "front_kernel", "rec_kernel", "ref_forward_kernel",
+                "unpack_gx"):
         if key in name:
             return name[name.index(key):].split("(")[0]
     return None
