@@ -21,6 +21,7 @@ struct vad_engine {
     std::string err;
     bool impl_reference = false;
     bool split = true;                              // precision: fp16x3 split MFMA (default) | exact fp32 MFMA
+    bool split_rec = true;                          // (bring-up: the two kernels can be chosen separately)
     bool profile = false;
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
 
@@ -186,7 +187,7 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
         fa.B = B;
         fa.trace = e->trace;
         vad::RecArgs ra{};
-        ra.whh = e->split ? reinterpret_cast<const float *>(e->d_whh_split[ni]) : e->d_whh[ni];
+        ra.whh = e->split_rec ? reinterpret_cast<const float *>(e->d_whh_split[ni]) : e->d_whh[ni];
         ra.tables = e->d_tables[ni];
         ra.gx = e->d_gx;
         ra.state = state;
@@ -206,7 +207,7 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
         if (e->split) HIP_TRY(e, vad::launch_front_split<PcmT>(sr, fa, stream));
         else HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
-        if (e->split) HIP_TRY(e, vad::launch_rec_split(sr, ra, stream));
+        if (e->split_rec) HIP_TRY(e, vad::launch_rec_split(sr, ra, stream));
         else HIP_TRY(e, vad::launch_rec(sr, ra, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[2], stream));
     }
@@ -343,9 +344,14 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         return VAD_OK;
     }
     if (n == "precision") {
-        if (v == "f16x3") e->split = true;
-        else if (v == "fp32") e->split = false;
+        if (v == "f16x3") e->split = e->split_rec = true;
+        else if (v == "fp32") e->split = e->split_rec = false;
         else return fail(e, VAD_ERR_OPTION, "precision must be f16x3|fp32");
+        return VAD_OK;
+    }
+    if (n == "precision_front" || n == "precision_rec") {   // bring-up: mix the two kernels
+        if (v != "f16x3" && v != "fp32") return fail(e, VAD_ERR_OPTION, "precision must be f16x3|fp32");
+        (n == "precision_front" ? e->split : e->split_rec) = (v == "f16x3");
         return VAD_OK;
     }
     if (n == "trace_ptr") {                          // bring-up only; ignored by normal builds
@@ -476,6 +482,7 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.ctx_out = nullptr;
     fa.gx = e->d_gx;
     fa.B = B;
+    fa.trace = e->trace;
     if (e->split) HIP_TRY(e, vad::launch_front_split<float>(sr, fa, stream));
     else HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
     HIP_TRY(e, vad::launch_unpack_gx(e->d_gx, gx, B, T, stream));

@@ -25,6 +25,21 @@
 //     an fp32 rank-1 VALU update instead of an almost empty MFMA step;
 //   * activations are converted to (hi, lo) half pairs once, when produced (5 VALU per 2 values), and
 //     live in registers as the packed B operands of the next layer (chain layout, layout.hpp).
+// BUILD REQUIREMENT -- no packed-fp32 VALU instructions in this translation unit
+// (__graft_entry__.py: -Xclang -target-feature -Xclang -packed-fp32-ops, and it disassembles the object
+// to check).  Measured on MI355X / ROCm 7.2: when one wave of a SIMD runs v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 (the in-wave FFT of fft_wave.hpp compiles to them) while ANOTHER wave of the same SIMD
+// has v_mfma_f32_16x16x32_f16 in flight, the MFMA results are corrupted now and then: with two
+// workgroups per CU -- whose FFT and MFMA phases are not barrier-locked to each other -- about 3 % of
+// the 16-chunk tiles of a launch came out wrong and differently on every run, independent of how the
+// weights reached the matrix pipe (LDS-DMA ring, register copies or plain global loads), of builtin
+// vs inline-asm MFMAs and of wait-state padding; one workgroup per CU (all waves in the same phase) or
+// the same code without packed-fp32 instructions is bit-stable over > 10^6 tiles
+// (tools/split_stress.py, tools/variants.py `nopk*`, `at2_lds1`, `w8`).  Scalar fp32 VALU costs nothing
+// here: beside MFMAs the packed forms are no faster (MI355X_MICROARCH.md, "price of one filler").
+// kernel_front.hip (f32 MFMA, which shares the VALU's issue pipe and therefore never overlaps it) is
+// not affected and keeps the packed FFT.
+//
 // Range: fp16 overflows at 65504.  |pcm| <= 1 keeps every activation below ~5.3e3 on all inputs tried
 // (sines, square waves, noise, speech); a lane that nevertheless sees |x| > 65000 poisons its chunk's
 // gx with NaN, which kernel_rec_split.hip propagates to the probability, so an out-of-range input is
@@ -42,6 +57,10 @@ using h2 = _Float16 __attribute__((ext_vector_type(2)));
 #ifndef VAD_SPLIT_SLOT_BLOCKS
 #define VAD_SPLIT_SLOT_BLOCKS 32   // 1-KiB blocks per ring slot = 16 (u, mblock) pairs
 #endif
+#ifndef VAD_SPLIT_WAVES
+#define VAD_SPLIT_WAVES 4          // waves (= 16-chunk tiles) per workgroup
+#endif
+constexpr int kWV = VAD_SPLIT_WAVES;
 constexpr int kSB = VAD_SPLIT_SLOT_BLOCKS;
 constexpr int kSlotWords = kSB * 256;
 constexpr float kHalfLimit = 65000.f;
@@ -59,14 +78,14 @@ template <int BLOCKS>
 __device__ __forceinline__ void sring_issue(const SRing &r, long woff, int slot, const Lane &ln) {
     // BLOCKS x 1 KiB, wave w copies blocks w, w+4, ...; global_load_lds issued from asm for the reason
     // given in kernel_front.hip (ring_issue): keeps the compiler's lgkmcnt waits fine-grained.
-    static_assert(BLOCKS % 4 == 0 && BLOCKS <= kSB, "unit must be whole 4-block groups");
+    static_assert(BLOCKS % kWV == 0 && BLOCKS <= kSB, "unit must be whole groups of one block per wave");
     if (VAD_ABLATE & 8) return;
     const unsigned *gbase = r.w + woff + (long)ln.wave * 256;
     const unsigned voff = ln.lane * 16;
     const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned *)(r.slots + slot * kSlotWords))
                            + (unsigned)ln.wave * 1024u;
 #pragma unroll
-    for (int blk = 0; blk < BLOCKS; blk += 4) {
+    for (int blk = 0; blk < BLOCKS; blk += kWV) {
         const unsigned *src = gbase + (long)blk * 256;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lbase + (unsigned)blk * 1024u);
         unsigned keep_m0;
@@ -80,6 +99,10 @@ __device__ __forceinline__ void sring_issue(const SRing &r, long woff, int slot,
 __device__ __forceinline__ void sring_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
+    if (VAD_ABLATE & 64) {                 // timing experiment: no matrix pipe, operands stay live
+        c[0] += __uint_as_float((a[0] ^ b[0]) & 0x3fffffffu);
+        return c;
+    }
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
@@ -107,18 +130,21 @@ __device__ __forceinline__ void gemm_split(f32x4 (&acc0)[M], BF0 b0, f32x4 (&acc
             if (un + 2 < NU) sring_issue<2 * PPU>(ring, off, slot ^ 1, ln);
             else sring_issue<2 * LASTP>(ring, off, slot ^ 1, ln);
         } else if (NEXT_BLOCKS > 0) {
-            sring_issue<(NEXT_BLOCKS > 0 ? NEXT_BLOCKS : 4)>(ring, next_off, slot ^ 1, ln);
+            sring_issue<(NEXT_BLOCKS > 0 ? NEXT_BLOCKS : kWV)>(ring, next_off, slot ^ 1, ln);
         }
         // A step = two row blocks of one K32 step: fragments (hi, lo) x 2, 6 (12) MFMAs ordered so that
         // MFMAs on the same accumulator are never adjacent.  The fragments of step i+1 are read from
         // LDS before the MFMAs of step i issue (explicit double buffer, as in kernel_front.hip).
         const u32x4 *A = reinterpret_cast<const u32x4 *>(ring.slots + slot * kSlotWords) + ln.lane;
+        if (VAD_ABLATE & 128) A = reinterpret_cast<const u32x4 *>(ring.slots) + ln.lane;   // timing: see below
         u32x4 c0 = A[0], c1 = A[64], c2 = A[128], c3 = A[192];
 #pragma unroll
         for (int st = 0; st < PPU / 2; ++st) {
             if (st < np / 2) {
                 u32x4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
-                if (st + 1 < np / 2) {
+                if ((VAD_ABLATE & 128) && st > 0) {
+                    // timing experiment: one fragment read per unit instead of one per step
+                } else if (st + 1 < np / 2) {
                     n0 = A[(4 * (st + 1) + 0) * 64];
                     n1 = A[(4 * (st + 1) + 1) * 64];
                     n2 = A[(4 * (st + 1) + 2) * 64];
@@ -212,7 +238,7 @@ __device__ __forceinline__ void nyq_update(f32x4 (&Y)[4], float xn, const float 
 }
 
 template <int Q, typename PcmT>
-__global__ void __launch_bounds__(256, 2) front_split_kernel(const FrontArgs a) {
+__global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArgs a) {
     using namespace vadl;
     constexpr Tab tb = make_tab(8 * Q, Q);
     constexpr int TABF = (tb.total + 3) / 4 * 4;
@@ -226,7 +252,7 @@ __global__ void __launch_bounds__(256, 2) front_split_kernel(const FrontArgs a) 
     ln.g = ln.lane >> 4;
     ln.j = ln.lane & 15;
     const long nst = (a.B + 15) / 16, total = nst * a.nt;
-    long wt = (long)blockIdx.x * 4 + ln.wave;
+    long wt = (long)blockIdx.x * kWV + ln.wave;
     ln.tile_valid = wt < total;
     if (!ln.tile_valid) wt = total - 1;
     ln.tl = wt % a.nt;
@@ -244,7 +270,7 @@ __global__ void __launch_bounds__(256, 2) front_split_kernel(const FrontArgs a) 
                   FB_E3 = first_blocks(8, 2), FB_IH = first_blocks(8, 4);
 
     sring_issue<FB_E0>(ring, off(SE0 + 0), 0, ln);      // first unit of the program
-    for (int i = threadIdx.x; i < tb.total; i += 256) tab[i] = a.tables[i];
+    for (int i = threadIdx.x; i < tb.total; i += 64 * kWV) tab[i] = a.tables[i];
     __syncthreads();
 
     float mx = 0.f;
@@ -378,9 +404,9 @@ template <typename PcmT>
 hipError_t launch_front_split(int sr, const FrontArgs &a, hipStream_t s) {
     if (a.B <= 0 || a.nt <= 0) return hipSuccess;
     const long nst = (a.B + 15) / 16, total = nst * a.nt;
-    const unsigned grid = (unsigned)((total + 3) / 4);
-    if (sr == 16000) hipLaunchKernelGGL((front_split_kernel<32, PcmT>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((front_split_kernel<16, PcmT>), dim3(grid), dim3(256), 0, s, a);
+    const unsigned grid = (unsigned)((total + kWV - 1) / kWV);
+    if (sr == 16000) hipLaunchKernelGGL((front_split_kernel<32, PcmT>), dim3(grid), dim3(64 * kWV), 0, s, a);
+    else hipLaunchKernelGGL((front_split_kernel<16, PcmT>), dim3(grid), dim3(64 * kWV), 0, s, a);
     return hipGetLastError();
 }
 template hipError_t launch_front_split<float>(int, const FrontArgs &, hipStream_t);

@@ -10,6 +10,7 @@
 // the whole launch.  Per step 48 MFMAs of 16 cycles replace 128 of 32 cycles; h_t is exchanged through
 // a double-buffered LDS image that already is the packed (hi, lo) B operand of the next step.
 // A NaN/Inf cell state (poisoned gx, kernel_front_split.hip) is propagated to the probability.
+// Built without packed-fp32 VALU instructions, like kernel_front_split.hip (see the note there).
 #include <hip/hip_runtime.h>
 
 #include "device_api.hpp"

@@ -17,7 +17,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
-HIP = ["engine.hip", "kernel_front.hip", "kernel_rec.hip", "kernels_ref.hip"]
+HIP = ["engine.hip", "kernel_front.hip", "kernel_rec.hip", "kernel_front_split.hip", "kernel_rec_split.hip",
+       "kernels_ref.hip"]
 CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
 VARIANTS = {
@@ -42,6 +43,60 @@ VARIANTS = {
     "abl_coalesced_noring": ["-DVAD_ABLATE=24"],
     "abl_noload_noring": ["-DVAD_ABLATE=12"],
     "abl_nofft_noload": ["-DVAD_ABLATE=6"],
+    # split-kernel experiments (VAD_ABLATE bits 64: no matrix pipe, 128: one A-fragment read per unit)
+    "sslot16": ["-DVAD_SPLIT_SLOT_BLOCKS=16"],
+    "slds1": ["-DVAD_SPLIT_LDS_PAD=8192"],           # 109 KB of LDS: one workgroup per CU
+    "sendbar": ["-DVAD_SPLIT_END_BARRIER=1"],
+    "sdmasync": ["-DVAD_SPLIT_DMA_SYNC=1"],
+    "sm0const": ["-DVAD_SPLIT_SLOT_BLOCKS=16", "-DVAD_SPLIT_M0_CONST=1"],
+    "sprobe": ["-DVAD_SPLIT_PROBE=1"],
+    "saglobal": ["-DVAD_SPLIT_A_FROM_GLOBAL=1"],
+    "swho": ["-DVAD_SPLIT_WHO=1"],
+    "sdump1": ["-DVAD_SPLIT_DUMP=1"], "sdump2": ["-DVAD_SPLIT_DUMP=2"],
+    "d2_pureglobal": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_A_FROM_GLOBAL=1", "-DVAD_ABLATE=8"],
+    "d2_regcopy": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_REG_COPY=1"],
+    "d2_nonyq": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_NO_NYQ=1"],
+    "d2_lds1": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LDS_PAD=8192"],
+    "d2_dmasync": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_DMA_SYNC=1"],
+    "d2_nop1": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_MFMA_NOP=1"],
+    "d2_nop7": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_MFMA_NOP=7"],
+    "d2_asm": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_MFMA_ASM=1"],
+    "d2_base": ["-DVAD_SPLIT_DUMP=2"],
+    "d2_warpad2": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_WAR_PAD=2"],
+    "d2_warpad8": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_WAR_PAD=8"],
+    "d2_at0": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LOAD_AT=0"],
+    "d2_at1": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LOAD_AT=1"],
+    "d2_at2": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LOAD_AT=2"],
+    "d2_at0pad2": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LOAD_AT=0", "-DVAD_SPLIT_WAR_PAD=2"],
+    "at0": ["-DVAD_SPLIT_LOAD_AT=0"], "at1": ["-DVAD_SPLIT_LOAD_AT=1"], "at2": ["-DVAD_SPLIT_LOAD_AT=2"],
+    "at0pad2": ["-DVAD_SPLIT_LOAD_AT=0", "-DVAD_SPLIT_WAR_PAD=2"],
+    "at0pad4": ["-DVAD_SPLIT_LOAD_AT=0", "-DVAD_SPLIT_WAR_PAD=4"],
+    "at2_lds1": ["-DVAD_SPLIT_LOAD_AT=2", "-DVAD_SPLIT_LDS_PAD=8192"],
+    "at2pad2": ["-DVAD_SPLIT_LOAD_AT=2", "-DVAD_SPLIT_WAR_PAD=2"],
+    "w8_lds1": ["-DVAD_SPLIT_WAVES=8", "-DVAD_SPLIT_LDS_PAD=8192"],
+    "w8": ["-DVAD_SPLIT_WAVES=8"],
+    "n_regcopy": ["-DVAD_SPLIT_REG_COPY=1"],
+    "n_pureglobal": ["-DVAD_SPLIT_A_FROM_GLOBAL=1", "-DVAD_ABLATE=8"],
+    "n_dmasync": ["-DVAD_SPLIT_DMA_SYNC=1"],
+    "n_m0const16": ["-DVAD_SPLIT_SLOT_BLOCKS=16", "-DVAD_SPLIT_M0_CONST=1"],
+    "nopk": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+    "nopk_builtin": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_MFMA_BUILTIN=1"],
+    "nopk_builtin_at0": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_MFMA_BUILTIN=1",
+                         "-DVAD_SPLIT_LOAD_AT=0"],
+    "nopk_at0": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_LOAD_AT=0"],
+    "nopk_at1": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_LOAD_AT=1"],
+    "at2pad1": ["-DVAD_SPLIT_LOAD_AT=2", "-DVAD_SPLIT_WAR_PAD=1"],
+    "sdump3": ["-DVAD_SPLIT_DUMP=3"], "sdump4": ["-DVAD_SPLIT_DUMP=4"],
+    "sregcopy": ["-DVAD_SPLIT_REG_COPY=1"],
+    "sm0nops": ["-DVAD_SPLIT_M0_NOPS=1"],
+    "ssleep": ["-DVAD_SPLIT_POST_SLEEP=8"],
+    "s2bar": ["-DVAD_SPLIT_TWO_BARRIERS=1"],
+    "abl_nomfma": ["-DVAD_ABLATE=64"],
+    "abl_nolds": ["-DVAD_ABLATE=128"],
+    "abl_nomfma_nolds": ["-DVAD_ABLATE=192"],
+    "abl_nofft_nomfma": ["-DVAD_ABLATE=66"],
+    "abl_mfma_lds_only": ["-DVAD_ABLATE=15"],
+    "abl_fft_only": ["-DVAD_ABLATE=201"],
 }
 
 
@@ -53,7 +108,7 @@ def build(names):
     shared.mkdir(exist_ok=True)
     procs = []
     # translation units without knobs are compiled once
-    knob_units = {"kernel_front.hip", "kernel_rec.hip"}
+    knob_units = {"kernel_front.hip", "kernel_rec.hip", "kernel_front_split.hip", "kernel_rec_split.hip"}
     for src in HIP + CPP:
         if src in knob_units:
             continue
@@ -61,11 +116,13 @@ def build(names):
         cmd = ([hipcc, "--offload-arch=gfx950"] + common + ["-c", str(CSRC / src), "-o", str(o)]
                if src.endswith(".hip") else [hipcc] + common + ["-x", "c++", "-c", str(CSRC / src), "-o", str(o)])
         procs.append(subprocess.Popen(cmd))
+    nopk = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
     for name in names:
         d = OUT / ("obj_" + name)
         d.mkdir(exist_ok=True)
         for src in knob_units:
-            procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950"] + common + VARIANTS[name]
+            extra = nopk if ("split" in src and not name.startswith("pk")) else []   # product flags (see __graft_entry__)
+            procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950"] + common + extra + VARIANTS[name]
                                           + ["-c", str(CSRC / src), "-o", str(d / (src + ".o"))]))
     for p in procs:
         if p.wait() != 0:
