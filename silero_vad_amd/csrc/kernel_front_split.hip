@@ -190,7 +190,8 @@ __device__ __forceinline__ void init_bias(f32x4 (&acc)[M], const float *bias_lds
 
 // (x0, x1) -> packed halves hi, lo; mx tracks the largest magnitude converted
 __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo, float &mx) {
-    const f32x2 v{x0, x1};
+#pragma clang fp contract(off)      // lo must come from the ROUNDED x (a caller's multiply must not fuse in):
+    const f32x2 v{x0, x1};              // the same x, reloaded from HBM by a later call, has to split alike
     const h2 h = __builtin_convertvector(v, h2);                 // v_cvt_pk_f16_f32 (RTN)
     const f32x2 r = v - __builtin_convertvector(h, f32x2);       // exact
     const h2 l = __builtin_convertvector(r, h2);

@@ -34,7 +34,8 @@ __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo) {
-    const f32x2 v{x0, x1};
+#pragma clang fp contract(off)      // lo must come from the ROUNDED x (a caller's multiply must not fuse in):
+    const f32x2 v{x0, x1};              // the same x, reloaded from HBM by a later call, has to split alike
     const h2 h = __builtin_convertvector(v, h2);
     const f32x2 r = v - __builtin_convertvector(h, f32x2);
     const h2 l = __builtin_convertvector(r, h2);
