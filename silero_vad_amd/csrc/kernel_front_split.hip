@@ -55,7 +55,10 @@ using h8 = _Float16 __attribute__((ext_vector_type(8)));
 using h2 = _Float16 __attribute__((ext_vector_type(2)));
 
 #ifndef VAD_SPLIT_SLOT_BLOCKS
-#define VAD_SPLIT_SLOT_BLOCKS 32   // 1-KiB blocks per ring slot = 16 (u, mblock) pairs
+#define VAD_SPLIT_SLOT_BLOCKS 16   // 1-KiB blocks per ring slot = per unit = 8 (u, mblock) pairs
+#endif
+#ifndef VAD_SPLIT_SLOTS
+#define VAD_SPLIT_SLOTS 4          // ring slots; a unit is requested VAD_SPLIT_SLOTS - 1 units ahead of its use
 #endif
 #ifndef VAD_SPLIT_WAVES
 #define VAD_SPLIT_WAVES 4          // waves (= 16-chunk tiles) per workgroup
@@ -63,12 +66,45 @@ using h2 = _Float16 __attribute__((ext_vector_type(2)));
 constexpr int kWV = VAD_SPLIT_WAVES;
 constexpr int kSB = VAD_SPLIT_SLOT_BLOCKS;
 constexpr int kSlotWords = kSB * 256;
+constexpr int kSlots = VAD_SPLIT_SLOTS, kAhead = kSlots - 1;
+
+// Program order of the weight stream, as ring units (word offsets into the split image).  The kernel
+// walks its segments in exactly this order; gemm_split() cross-checks every unit it consumes.
+struct Sched {
+    int n;
+    int off[96];
+};
+constexpr Sched make_sched(int Q) {
+    using namespace vadl;
+    Sched sc{};
+    int n = 0;
+    const int a_order[6] = {SE0 + 0, SE0 + 1, SE0 + 2, SE1 + 1, SE1 + 2, SE1 + 0};   // frames 0,1 (per row half)
+    const int b_order[5] = {SE0 + 0, SE0 + 1, SE0 + 2, SE1 + 1, SE1 + 2};            // frames 2,3
+    int segs[40] = {};
+    int ns = 0;
+    for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 6; ++i) segs[ns++] = a_order[i] + 6 * h;
+    for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 5; ++i) segs[ns++] = b_order[i] + 6 * h;
+    segs[ns++] = SE2T1; segs[ns++] = SE2T2; segs[ns++] = SE3T1;
+    for (int q = 0; q < 4; ++q) segs[ns++] = SIH0 + q;
+    for (int i = 0; i < ns; ++i) {
+        const int units = (int)(sseg_words(segs[i], Q) / kSlotWords);
+        for (int u = 0; u < units; ++u) sc.off[n++] = (int)(sseg_offset(segs[i], Q) + (long)u * kSlotWords);
+    }
+    sc.n = n;
+    return sc;
+}
+__device__ const Sched kSched32 = make_sched(32);
+__device__ const Sched kSched16 = make_sched(16);
 constexpr float kHalfLimit = 65000.f;
 
 struct SRing {
-    unsigned *slots;           // LDS, 2 x kSlotWords
+    unsigned *slots;           // LDS, kSlots x kSlotWords
     const unsigned *w;         // global split image
+    const Sched *sched;
     int unit;                  // units consumed so far (wave-uniform)
+    int bad;                   // a consumed unit was not the scheduled one (programming error): poison
 };
 struct Bop {                   // B operand of one K32 step: 8 halves hi, 8 halves lo
     u32x4 hi, lo;
@@ -96,7 +132,21 @@ __device__ __forceinline__ void sring_issue(const SRing &r, long woff, int slot,
                      : "memory");
     }
 }
-__device__ __forceinline__ void sring_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Unit `ring.unit` has landed for THIS wave.  Every wave issues exactly kSB / kWV LDS-DMA instructions
+// per unit and `later` younger units are in flight, so the wait is counted: loads (PCM, DMA) complete
+// in order among themselves; stores (gx, ctx) may complete out of order but only ever ADD to the
+// counter, so they can delay this wait, never release it early.
+__device__ __forceinline__ void sring_wait(int later) {
+    static_assert(kSB / kWV == 4 && kAhead <= 3, "wait counts below assume 4 DMA instructions per unit");
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void sring_request(const SRing &r, int unit, const Lane &ln);
+
+__device__ __forceinline__ void sring_request(const SRing &r, int unit, const Lane &ln) {
+    sring_issue<kSB>(r, r.sched->off[unit], unit % kSlots, ln);
+}
 
 __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
     if (VAD_ABLATE & 64) {                 // timing experiment: no matrix pipe, operands stay live
@@ -116,22 +166,18 @@ constexpr int first_blocks(int M, int U) { return seg_blocks(M, U) < kSB ? seg_b
 template <int M, int U, int NEXT_BLOCKS, int NUSE, class BF0, class BF1>
 __device__ __forceinline__ void gemm_split(f32x4 (&acc0)[M], BF0 b0, f32x4 (&acc1)[M], BF1 b1, SRing &ring,
                                            long seg_off, long next_off, const Lane &ln) {
-    constexpr int PAIRS = U * M, PPU = kSB / 2, NU = (PAIRS + PPU - 1) / PPU;
-    static_assert(PPU % M == 0 && M % 2 == 0, "a unit holds whole K32 steps; steps take two row blocks");
+    constexpr int PAIRS = U * M, PPU = kSB / 2, NU = PAIRS / PPU;
+    static_assert(PPU % M == 0 && M % 2 == 0 && PAIRS % PPU == 0,
+                  "a unit holds whole K32 steps; steps take two row blocks; segments are whole units");
+    constexpr int np = PPU;
 #pragma unroll
     for (int un = 0; un < NU; ++un) {
-        sring_wait();
-        if (!(VAD_ABLATE & 1)) __syncthreads();        // unit landed for every wave; other slot free
-        const int slot = ring.unit & 1;
-        constexpr int LASTP = PAIRS - (NU - 1) * PPU;  // pairs in the segment's last unit
-        const int np = (un + 1 < NU) ? PPU : LASTP;
-        if (un + 1 < NU) {
-            const long off = seg_off + (long)(un + 1) * PPU * 512;
-            if (un + 2 < NU) sring_issue<2 * PPU>(ring, off, slot ^ 1, ln);
-            else sring_issue<2 * LASTP>(ring, off, slot ^ 1, ln);
-        } else if (NEXT_BLOCKS > 0) {
-            sring_issue<(NEXT_BLOCKS > 0 ? NEXT_BLOCKS : kWV)>(ring, next_off, slot ^ 1, ln);
-        }
+        const int later = ring.sched->n - 1 - ring.unit;
+        sring_wait(later < kAhead - 1 ? later : kAhead - 1);
+        if (!(VAD_ABLATE & 1)) __syncthreads();        // unit landed for every wave; slot of unit-1 is free
+        if (ring.sched->off[ring.unit] != (int)(seg_off + (long)un * kSlotWords)) ring.bad = 1;
+        if (ring.unit + kAhead < ring.sched->n) sring_request(ring, ring.unit + kAhead, ln);
+        const int slot = ring.unit % kSlots;
         // A step = two row blocks of one K32 step: fragments (hi, lo) x 2, 6 (12) MFMAs ordered so that
         // MFMAs on the same accumulator are never adjacent.  The fragments of step i+1 are read from
         // LDS before the MFMAs of step i issue (explicit double buffer, as in kernel_front.hip).
@@ -244,7 +290,7 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
     constexpr Tab tb = make_tab(8 * Q, Q);
     constexpr int TABF = (tb.total + 3) / 4 * 4;
     constexpr int U0 = Q / 8;
-    __shared__ __attribute__((aligned(16))) float lds[TABF + 2 * kSlotWords];
+    __shared__ __attribute__((aligned(16))) float lds[TABF + kSlots * kSlotWords];
     float *tab = lds;
 
     Lane ln;
@@ -265,12 +311,14 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
     ln.sgnA = ln.g < 2 ? 1.f : -1.f;
     ln.sgnB = (ln.g & 1) ? -1.f : 1.f;
 
-    SRing ring{reinterpret_cast<unsigned *>(lds + TABF), reinterpret_cast<const unsigned *>(a.wfront), 0};
+    SRing ring{reinterpret_cast<unsigned *>(lds + TABF), reinterpret_cast<const unsigned *>(a.wfront),
+               Q == 32 ? &kSched32 : &kSched16, 0, 0};
     auto off = [](int s) { return sseg_offset(s, Q); };
     constexpr int FB_E0 = first_blocks(4, U0), FB_E1 = first_blocks(4, 2), FB_E2 = first_blocks(4, 2),
                   FB_E3 = first_blocks(8, 2), FB_IH = first_blocks(8, 4);
 
-    sring_issue<FB_E0>(ring, off(SE0 + 0), 0, ln);      // first unit of the program
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) sring_request(ring, u, ln);      // prime the ring
     for (int i = threadIdx.x; i < tb.total; i += 64 * kWV) tab[i] = a.tables[i];
     __syncthreads();
 
@@ -379,7 +427,7 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
     relu_pack<8>(Fe, Pf, mx);
     auto bPf = [&](int u) { return Pf[u]; };
 
-    const bool bad = !(mx < kHalfLimit);                 // out of fp16 range (or NaN input): poison
+    const bool bad = !(mx < kHalfLimit) || ring.bad;     // out of fp16 range (or NaN input): poison
     const float nanv = __builtin_nanf("");
     float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32) * 256 + ln.lane * 4;
 #pragma unroll
