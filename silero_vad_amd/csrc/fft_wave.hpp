@@ -12,6 +12,10 @@
 #include "device_api.hpp"
 #include "layout.hpp"
 
+#ifndef VAD_NT_PCM
+#define VAD_NT_PCM 0     // 1: PCM is loaded with the non-temporal hint (read once; keep the L2 for the weights)
+#endif
+
 namespace vad {
 namespace {
 
@@ -65,7 +69,8 @@ template <int SL>
 __device__ __forceinline__ void load_vec(const float *p, float (&s)[SL]) {
 #pragma unroll
     for (int k = 0; k < SL / 4; ++k) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(p)[k];
+        const f32x4 v = VAD_NT_PCM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p) + k)
+                                   : reinterpret_cast<const f32x4 *>(p)[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
     }
@@ -73,7 +78,9 @@ __device__ __forceinline__ void load_vec(const float *p, float (&s)[SL]) {
 template <int SL>
 __device__ __forceinline__ void load_vec(const int16_t *p, float (&s)[SL]) {
 #pragma unroll
-    for (int k = 0; k < SL / 8; ++k) cvt8(reinterpret_cast<const u32x4 *>(p)[k], &s[8 * k]);
+    for (int k = 0; k < SL / 8; ++k)
+        cvt8(VAD_NT_PCM ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p) + k)
+                        : reinterpret_cast<const u32x4 *>(p)[k], &s[8 * k]);
 }
 
 // slice V of the lane: s[i] = x[2Q*(2V+g) + i], x = ctx | chunk (| reflected tail for V==3,g==3).

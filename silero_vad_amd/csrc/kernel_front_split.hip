@@ -46,6 +46,13 @@
 // reported as NaN (the host wrapper reruns it with precision=fp32) and never as a wrong number.
 #include <hip/hip_runtime.h>
 
+#ifndef VAD_SPLIT_NT_PCM
+#define VAD_SPLIT_NT_PCM 0         // non-temporal hint on the PCM loads / the gx stores (measured: both cost time in
+#endif                             // this kernel -- frames overlap, so PCM lines are re-read; kept as knobs)
+#ifndef VAD_SPLIT_NT_GX
+#define VAD_SPLIT_NT_GX 0
+#endif
+#define VAD_NT_PCM VAD_SPLIT_NT_PCM
 #include "fft_wave.hpp"
 
 namespace vad {
@@ -441,7 +448,9 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
             for (int m = 0; m < 8; ++m) {
                 f32x4 v = G[m];
                 if (bad) v = f32x4{nanv, nanv, nanv, nanv};
-                *reinterpret_cast<f32x4 *>(gxt + (size_t)(8 * q + m) * 256) = v;
+                f32x4 *dst = reinterpret_cast<f32x4 *>(gxt + (size_t)(8 * q + m) * 256);
+                if (VAD_SPLIT_NT_GX) __builtin_nontemporal_store(v, dst);
+                else *dst = v;
             }
         }
     }

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(512, 2) rec_split_kernel(const RecArgs a) {
     for (int d = 0; d < kDepth; ++d)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            gpre[d][q] = gx[((size_t)(d < a.nt ? d : 0) * 32 + 8 * q + w) * 64];
+            gpre[d][q] = __builtin_nontemporal_load(gx + ((size_t)(d < a.nt ? d : 0) * 32 + 8 * q + w) * 64);
     __syncthreads();
 
     for (long t = 0; t < a.nt; ++t) {
@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(512, 2) rec_split_kernel(const RecArgs a) {
         {
             const long tn = t + kDepth < a.nt ? t + kDepth : a.nt - 1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gpre[kDepth - 1][q] = gx[((size_t)tn * 32 + 8 * q + w) * 64];
+            for (int q = 0; q < 4; ++q)
+                gpre[kDepth - 1][q] = __builtin_nontemporal_load(gx + ((size_t)tn * 32 + 8 * q + w) * 64);   // streamed once
         }
         // gates += W_hh h_{t-1}
         const u32x4 *hb = reinterpret_cast<const u32x4 *>(&hbuf[cur][0]) + lane;

@@ -85,6 +85,7 @@ VARIANTS = {
                          "-DVAD_SPLIT_LOAD_AT=0"],
     "nopk_at0": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_LOAD_AT=0"],
     "nopk_at1": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_LOAD_AT=1"],
+    "ntpcm": ["-DVAD_SPLIT_NT_PCM=1"], "ntgx": ["-DVAD_SPLIT_NT_GX=1"],
     "at2pad1": ["-DVAD_SPLIT_LOAD_AT=2", "-DVAD_SPLIT_WAR_PAD=1"],
     "sdump3": ["-DVAD_SPLIT_DUMP=3"], "sdump4": ["-DVAD_SPLIT_DUMP=4"],
     "sregcopy": ["-DVAD_SPLIT_REG_COPY=1"],
