@@ -43,7 +43,10 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigne
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-constexpr int kDepth = 2;      // gx prefetch distance in time steps
+#ifndef VAD_REC_DEPTH
+#define VAD_REC_DEPTH 2
+#endif
+constexpr int kDepth = VAD_REC_DEPTH;      // gx prefetch distance in time steps
 
 template <int NTAB_WOUT, int NTAB_BOUT>
 __global__ void __launch_bounds__(512, 2) rec_split_kernel(const RecArgs a) {

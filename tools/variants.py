@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Build and time A/B variants of the kernels (compile-time knobs in csrc/*.hip).
+"""Build and time A/B variants of the kernels (compile-time knobs in csrc/*.hip; tools/split_stress.py and
+tools/split_diag.py take a variant through SILERO_VAD_AMD_LIB=build/variants/lib_<name>.so).
 
     python tools/variants.py build            # here (no GPU): build/variants/lib_<name>.so
     python tools/variants.py run [names...]   # on the GPU box: bench each, write gpurun_out/variants.json
@@ -43,61 +44,20 @@ VARIANTS = {
     "abl_coalesced_noring": ["-DVAD_ABLATE=24"],
     "abl_noload_noring": ["-DVAD_ABLATE=12"],
     "abl_nofft_noload": ["-DVAD_ABLATE=6"],
-    # split-kernel experiments (VAD_ABLATE bits 64: no matrix pipe, 128: one A-fragment read per unit)
-    "sslot16": ["-DVAD_SPLIT_SLOT_BLOCKS=16"],
-    "slds1": ["-DVAD_SPLIT_LDS_PAD=8192"],           # 109 KB of LDS: one workgroup per CU
-    "sendbar": ["-DVAD_SPLIT_END_BARRIER=1"],
-    "sdmasync": ["-DVAD_SPLIT_DMA_SYNC=1"],
-    "sm0const": ["-DVAD_SPLIT_SLOT_BLOCKS=16", "-DVAD_SPLIT_M0_CONST=1"],
-    "sprobe": ["-DVAD_SPLIT_PROBE=1"],
-    "saglobal": ["-DVAD_SPLIT_A_FROM_GLOBAL=1"],
-    "swho": ["-DVAD_SPLIT_WHO=1"],
-    "sdump1": ["-DVAD_SPLIT_DUMP=1"], "sdump2": ["-DVAD_SPLIT_DUMP=2"],
-    "d2_pureglobal": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_A_FROM_GLOBAL=1", "-DVAD_ABLATE=8"],
-    "d2_regcopy": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_REG_COPY=1"],
-    "d2_nonyq": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_NO_NYQ=1"],
-    "d2_lds1": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LDS_PAD=8192"],
-    "d2_dmasync": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_DMA_SYNC=1"],
-    "d2_nop1": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_MFMA_NOP=1"],
-    "d2_nop7": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_MFMA_NOP=7"],
-    "d2_asm": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_MFMA_ASM=1"],
-    "d2_base": ["-DVAD_SPLIT_DUMP=2"],
-    "d2_warpad2": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_WAR_PAD=2"],
-    "d2_warpad8": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_WAR_PAD=8"],
-    "d2_at0": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LOAD_AT=0"],
-    "d2_at1": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LOAD_AT=1"],
-    "d2_at2": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LOAD_AT=2"],
-    "d2_at0pad2": ["-DVAD_SPLIT_DUMP=2", "-DVAD_SPLIT_LOAD_AT=0", "-DVAD_SPLIT_WAR_PAD=2"],
-    "at0": ["-DVAD_SPLIT_LOAD_AT=0"], "at1": ["-DVAD_SPLIT_LOAD_AT=1"], "at2": ["-DVAD_SPLIT_LOAD_AT=2"],
-    "at0pad2": ["-DVAD_SPLIT_LOAD_AT=0", "-DVAD_SPLIT_WAR_PAD=2"],
-    "at0pad4": ["-DVAD_SPLIT_LOAD_AT=0", "-DVAD_SPLIT_WAR_PAD=4"],
-    "at2_lds1": ["-DVAD_SPLIT_LOAD_AT=2", "-DVAD_SPLIT_LDS_PAD=8192"],
-    "at2pad2": ["-DVAD_SPLIT_LOAD_AT=2", "-DVAD_SPLIT_WAR_PAD=2"],
-    "w8_lds1": ["-DVAD_SPLIT_WAVES=8", "-DVAD_SPLIT_LDS_PAD=8192"],
-    "w8": ["-DVAD_SPLIT_WAVES=8"],
-    "n_regcopy": ["-DVAD_SPLIT_REG_COPY=1"],
-    "n_pureglobal": ["-DVAD_SPLIT_A_FROM_GLOBAL=1", "-DVAD_ABLATE=8"],
-    "n_dmasync": ["-DVAD_SPLIT_DMA_SYNC=1"],
-    "n_m0const16": ["-DVAD_SPLIT_SLOT_BLOCKS=16", "-DVAD_SPLIT_M0_CONST=1"],
-    "nopk": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
-    "nopk_builtin": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_MFMA_BUILTIN=1"],
-    "nopk_builtin_at0": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_MFMA_BUILTIN=1",
-                         "-DVAD_SPLIT_LOAD_AT=0"],
-    "nopk_at0": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_LOAD_AT=0"],
-    "nopk_at1": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DVAD_SPLIT_LOAD_AT=1"],
-    "ntpcm": ["-DVAD_SPLIT_NT_PCM=1"], "ntgx": ["-DVAD_SPLIT_NT_GX=1"],
-    "at2pad1": ["-DVAD_SPLIT_LOAD_AT=2", "-DVAD_SPLIT_WAR_PAD=1"],
-    "sdump3": ["-DVAD_SPLIT_DUMP=3"], "sdump4": ["-DVAD_SPLIT_DUMP=4"],
-    "sregcopy": ["-DVAD_SPLIT_REG_COPY=1"],
-    "sm0nops": ["-DVAD_SPLIT_M0_NOPS=1"],
-    "ssleep": ["-DVAD_SPLIT_POST_SLEEP=8"],
-    "s2bar": ["-DVAD_SPLIT_TWO_BARRIERS=1"],
+    # f16x3 kernels (kernel_front_split.hip, kernel_rec_split.hip).  VAD_ABLATE bits there: 1 no barriers,
+    # 2 no FFT math, 4 no PCM loads, 8 no weight ring, 64 no matrix pipe, 128 one fragment read per unit.
     "abl_nomfma": ["-DVAD_ABLATE=64"],
     "abl_nolds": ["-DVAD_ABLATE=128"],
     "abl_nomfma_nolds": ["-DVAD_ABLATE=192"],
     "abl_nofft_nomfma": ["-DVAD_ABLATE=66"],
     "abl_mfma_lds_only": ["-DVAD_ABLATE=15"],
-    "abl_fft_only": ["-DVAD_ABLATE=201"],
+    "slots2": ["-DVAD_SPLIT_SLOTS=2"], "slots3": ["-DVAD_SPLIT_SLOTS=3"],
+    "w8": ["-DVAD_SPLIT_WAVES=8"],
+    "ntpcm": ["-DVAD_SPLIT_NT_PCM=1"], "ntgx": ["-DVAD_SPLIT_NT_GX=1"],
+    "recd1": ["-DVAD_REC_DEPTH=1"], "recd3": ["-DVAD_REC_DEPTH=3"],
+    # "pk*": the split translation units WITH packed-fp32 VALU instructions -- reproduces the corruption
+    # described in kernel_front_split.hip under two workgroups per CU (tools/split_stress.py)
+    "pk": [],
 }
 
 
