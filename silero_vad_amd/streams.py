@@ -117,6 +117,22 @@ def _stage_into(audios, idxs, width, dtype, dst: torch.Tensor):
         raise _lib.VadError(rc, "vad_stage_rows")
 
 
+def _repair_out_of_range(audios, idxs, probs, model, sampling_rate, n):
+    """The default f16x3 kernels answer NaN for a recording whose activations leave the fp16 range
+    (include/silero_vad_hip.h, option "precision"; |pcm| far above 1).  With the wrapper's "auto" policy such
+    rows are recomputed one by one through the guarded `audio_forward`, which falls back to the fp32 kernels."""
+    if getattr(model, "precision", None) != "auto":
+        return probs
+    bad = torch.isnan(probs).any(dim=1).nonzero().flatten().tolist()
+    for row in bad:
+        a = torch.as_tensor(audios[idxs[row]])
+        if a.shape[0] < n:
+            a = torch.nn.functional.pad(a, (0, n - a.shape[0]))
+        p = model.audio_forward(a[None], sampling_rate)[0]
+        probs[row, : p.numel()] = p
+    return probs
+
+
 def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
                    max_bytes: int = 256 << 20, plan: RaggedPlan = None):
     """Generator over the plan's buckets: yields (indices, probs[len(indices), T_bucket] on the CPU).
@@ -175,11 +191,11 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         staged = stage(k + 1) if k + 1 < len(plan.buckets) else None   # CPU packs k+1 meanwhile
         if prev is not None:
             prev[2].synchronize()
-            yield prev[0], prev[1]
+            yield prev[0], _repair_out_of_range(audios, prev[0], prev[1], model, sampling_rate, n)
         prev = (idxs, out, done)
     if prev is not None:
         prev[2].synchronize()
-        yield prev[0], prev[1]
+        yield prev[0], _repair_out_of_range(audios, prev[0], prev[1], model, sampling_rate, n)
 
 
 def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
@@ -253,6 +269,10 @@ def segment_probs_batch(probs: torch.Tensor, n_chunks, audio_lengths, sampling_r
 
 
 # ---- live streams --------------------------------------------------------------------------------------
+# Live streams: StreamPool drives the engine directly (no host synchronisation per tick), so the wrapper's
+# "auto" fallback does not apply; with the default f16x3 arithmetic a stream whose input leaves the fp16
+# range (|pcm| far above 1) reports NaN from that tick on until it is reset.  Construct the Engine with
+# set_precision("fp32") for inputs that are not normalised.
 class StreamPool:
     """`capacity` concurrently live streams on one GPU, one `tick` per 32 ms chunk.
 

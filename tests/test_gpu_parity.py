@@ -390,6 +390,21 @@ def test_ragged_corpus_equals_single_recording_runs(model, golden, tag):
     assert sum(len(s) for s in single) > 10
 
 
+def test_ragged_corpus_repairs_out_of_range_recordings(model, oracle, golden):
+    """A recording far outside [-1, 1] inside a ragged corpus: the "auto" policy recomputes just that row in
+    fp32, the others keep their f16x3 results."""
+    from silero_vad_amd import HipSileroVAD, ragged_probs
+    sr, n = 16000, 512
+    wav = golden["16k"]["wav"]
+    audios = [torch.from_numpy(wav[s:s + m].copy()) for s, m in ((0, 9 * n), (5000, 20 * n + 17), (90000, 14 * n))]
+    audios[1] = audios[1] * 1.0e5
+    auto = HipSileroVAD(engine=model.engine, precision="auto")
+    got = ragged_probs(audios, auto, sr, max_waste=0.9)
+    for a, p in zip(audios, got):
+        want = oracle.audio_forward(a.numpy()[None], sr)[0]
+        assert not torch.isnan(p).any() and np.abs(p.numpy() - want).max() < TOL
+
+
 # ---- (5) the fp16x3 split arithmetic: what it relies on, and its range guard -------------------------
 def _probe(model, a, b):
     from silero_vad_amd import _lib
