@@ -350,6 +350,10 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
     auto bX2 = [&](int u) { return X2[u]; };
     auto bX3 = [&](int u) { return X3[u]; };
 
+#ifndef VAD_SPLIT_PRIO
+#define VAD_SPLIT_PRIO 0           // s_setprio level of the GEMM phases (the FFT passes run at 0)
+#endif
+    if (VAD_SPLIT_PRIO) __builtin_amdgcn_s_setprio(VAD_SPLIT_PRIO);
     f32x4 Z0[4], Z1[4];
     init_bias<4>(Z0, tab + tb.b_e1, ln);
     init_bias<4>(Z1, tab + tb.b_e1, ln);
@@ -381,11 +385,13 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
     }
 
     {
+        if (VAD_SPLIT_PRIO) __builtin_amdgcn_s_setprio(0);
         float Xf[Q + 1];
         fft_pass<Q, 3, PcmT>(Xf, a, tab, ln);
         pack_mag<Q>(Xf, X3, mx);
         xn3 = __shfl(Xf[Q], ln.j);
         mx = fmaxf(mx, xn3);
+        if (VAD_SPLIT_PRIO) __builtin_amdgcn_s_setprio(VAD_SPLIT_PRIO);
     }
 
     // ---- frames 2 and 3 of enc0 -> enc1 out 1 taps 1,2 -------------------------------------------------

@@ -53,6 +53,7 @@ VARIANTS = {
     "abl_mfma_lds_only": ["-DVAD_ABLATE=15"],
     "slots2": ["-DVAD_SPLIT_SLOTS=2"], "slots3": ["-DVAD_SPLIT_SLOTS=3"],
     "w8": ["-DVAD_SPLIT_WAVES=8"],
+    "prio1": ["-DVAD_SPLIT_PRIO=1"], "prio3": ["-DVAD_SPLIT_PRIO=3"],
     "ntpcm": ["-DVAD_SPLIT_NT_PCM=1"], "ntgx": ["-DVAD_SPLIT_NT_GX=1"],
     "recd1": ["-DVAD_REC_DEPTH=1"], "recd3": ["-DVAD_REC_DEPTH=3"],
     # "pk*": the split translation units WITH packed-fp32 VALU instructions -- reproduces the corruption
