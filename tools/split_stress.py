@@ -9,20 +9,22 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from silero_vad_amd import Engine
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+SR = int(sys.argv[3]) if len(sys.argv) > 3 else 16000
 dev = torch.device("cuda", 0)
 eng = Engine(0)
-wav = torch.from_numpy(np.load(ROOT / "tests/golden/audio_16k.npz")["pcm"].astype(np.float32) / 32768.0).to(dev)
-sr, n, B, T = 16000, 512, 4096, 256
+tag = "16k" if SR == 16000 else "8k"
+wav = torch.from_numpy(np.load(ROOT / f"tests/golden/audio_{tag}.npz")["pcm"].astype(np.float32) / 32768.0).to(dev)
+sr, n, B, T = SR, (512 if SR == 16000 else 256), 4096, 256
 idx = (torch.arange(B, device=dev)[:, None] * 7919 + torch.arange(T * n, device=dev)[None]) % len(wav)
 x = wav[idx].contiguous()
 def run(prec_f, prec_r):
     eng.set_option("precision_front", prec_f); eng.set_option("precision_rec", prec_r)
-    ctx = torch.zeros((B, 64), device=dev); st = torch.zeros((2, B, 128), device=dev)
+    ctx = torch.zeros((B, n // 8), device=dev); st = torch.zeros((2, B, 128), device=dev)
     p = eng.forward_audio(x, sr, ctx, st)
     torch.cuda.synchronize()
     return p.clone(), st
 ref, _ = run("fp32", "fp32")
-out = {"lib": sys.argv[1] if len(sys.argv) > 1 else "", "launches": N}
+out = {"lib": sys.argv[1] if len(sys.argv) > 1 else "", "launches": N, "sr": sr}
 for name, pf, pr in (("front", "f16x3", "fp32"), ("rec", "fp32", "f16x3"), ("both", "f16x3", "f16x3")):
     p0, s0 = run(pf, pr)
     bad_streams, worst = 0, 0.0
@@ -33,7 +35,7 @@ for name, pf, pr in (("front", "f16x3", "fp32"), ("rec", "fp32", "f16x3"), ("bot
     out[name] = {"streams_differing_total": bad_streams, "max_dp_vs_fp32": worst}
 eng.set_option("precision", "f16x3")
 eng.set_option("profile", "1")
-ctx = torch.zeros((B, 64), device=dev); st = torch.zeros((2, B, 128), device=dev)
+ctx = torch.zeros((B, n // 8), device=dev); st = torch.zeros((2, B, 128), device=dev)
 for _ in range(5):
     eng.forward_audio(x, sr, ctx, st)
 f, r, c = eng.kernel_times()
