@@ -163,16 +163,13 @@ __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
-constexpr int seg_blocks(int M, int U) { return 2 * M * U; }
-constexpr int first_blocks(int M, int U) { return seg_blocks(M, U) < kSB ? seg_blocks(M, U) : kSB; }
-
-// One segment = U K32-steps x M row blocks, streamed as ring units of up to kSB/2 (u, mblock) pairs.
+// One segment = U K32-steps x M row blocks = U M / 8 ring units of 8 (u, mblock) pairs, consumed in the
+// order of make_sched() (seg_off, the segment's offset in the image, is only used to cross-check that).
 // NUSE accumulator sets share every A fragment:  acc0 += A * b0,  (NUSE == 2:) acc1 += A * b1.
-// b*(u) returns the packed B operand of K32 step u (compile-time u).  NEXT_BLOCKS / next_off describe
-// the first unit of the segment that follows in program order (prefetch; 0 = none).
-template <int M, int U, int NEXT_BLOCKS, int NUSE, class BF0, class BF1>
+// b*(u) returns the packed B operand of K32 step u (compile-time u).
+template <int M, int U, int NUSE, class BF0, class BF1>
 __device__ __forceinline__ void gemm_split(f32x4 (&acc0)[M], BF0 b0, f32x4 (&acc1)[M], BF1 b1, SRing &ring,
-                                           long seg_off, long next_off, const Lane &ln) {
+                                           long seg_off, const Lane &ln) {
     constexpr int PAIRS = U * M, PPU = kSB / 2, NU = PAIRS / PPU;
     static_assert(PPU % M == 0 && M % 2 == 0 && PAIRS % PPU == 0,
                   "a unit holds whole K32 steps; steps take two row blocks; segments are whole units");
@@ -321,8 +318,6 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
     SRing ring{reinterpret_cast<unsigned *>(lds + TABF), reinterpret_cast<const unsigned *>(a.wfront),
                Q == 32 ? &kSched32 : &kSched16, 0, 0};
     auto off = [](int s) { return sseg_offset(s, Q); };
-    constexpr int FB_E0 = first_blocks(4, U0), FB_E1 = first_blocks(4, 2), FB_E2 = first_blocks(4, 2),
-                  FB_E3 = first_blocks(8, 2), FB_IH = first_blocks(8, 4);
 
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) sring_request(ring, u, ln);      // prime the ring
@@ -365,9 +360,9 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
         f32x4 Ya[4], Yb[4];                              // enc0 frame 0, frame 1
         init_bias<4>(Ya, tab + tb.b_e0 + 64 * h, ln);
         init_bias<4>(Yb, tab + tb.b_e0 + 64 * h, ln);
-        gemm_split<4, U0, FB_E0, 1>(Yb, bX0, Yb, bX0, ring, off(SE0 + 6 * h + 0), off(SE0 + 6 * h + 1), ln);
-        gemm_split<4, U0, FB_E0, 2>(Ya, bX0, Yb, bX1, ring, off(SE0 + 6 * h + 1), off(SE0 + 6 * h + 2), ln);
-        gemm_split<4, U0, FB_E1, 2>(Ya, bX1, Yb, bX2, ring, off(SE0 + 6 * h + 2), off(SE1 + 6 * h + 1), ln);
+        gemm_split<4, U0, 1>(Yb, bX0, Yb, bX0, ring, off(SE0 + 6 * h + 0), ln);
+        gemm_split<4, U0, 2>(Ya, bX0, Yb, bX1, ring, off(SE0 + 6 * h + 1), ln);
+        gemm_split<4, U0, 2>(Ya, bX1, Yb, bX2, ring, off(SE0 + 6 * h + 2), ln);
         nyq_update(Yb, xn0, wn + 0 * 128 + 64 * h, ln);
         nyq_update(Ya, xn0, wn + 1 * 128 + 64 * h, ln);
         nyq_update(Yb, xn1, wn + 1 * 128 + 64 * h, ln);
@@ -378,10 +373,9 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
         relu_pack<4>(Yb, Pb, mx);
         auto bPa = [&](int u) { return Pa[u]; };
         auto bPb = [&](int u) { return Pb[u]; };
-        gemm_split<4, 2, FB_E1, 1>(Z0, bPa, Z0, bPa, ring, off(SE1 + 6 * h + 1), off(SE1 + 6 * h + 2), ln);
-        gemm_split<4, 2, FB_E1, 1>(Z0, bPb, Z0, bPb, ring, off(SE1 + 6 * h + 2), off(SE1 + 6 * h + 0), ln);
-        // after h = 1 the next segment is phase B's first (SE0 h=0 tap 0)
-        gemm_split<4, 2, FB_E0, 1>(Z1, bPb, Z1, bPb, ring, off(SE1 + 6 * h + 0), off(SE0 + (h == 0 ? 6 : 0)), ln);
+        gemm_split<4, 2, 1>(Z0, bPa, Z0, bPa, ring, off(SE1 + 6 * h + 1), ln);
+        gemm_split<4, 2, 1>(Z0, bPb, Z0, bPb, ring, off(SE1 + 6 * h + 2), ln);
+        gemm_split<4, 2, 1>(Z1, bPb, Z1, bPb, ring, off(SE1 + 6 * h + 0), ln);
     }
 
     {
@@ -400,9 +394,9 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
         f32x4 Ya[4], Yb[4];                              // enc0 frame 2, frame 3
         init_bias<4>(Ya, tab + tb.b_e0 + 64 * h, ln);
         init_bias<4>(Yb, tab + tb.b_e0 + 64 * h, ln);
-        gemm_split<4, U0, FB_E0, 2>(Ya, bX1, Yb, bX2, ring, off(SE0 + 6 * h + 0), off(SE0 + 6 * h + 1), ln);
-        gemm_split<4, U0, FB_E0, 2>(Ya, bX2, Yb, bX3, ring, off(SE0 + 6 * h + 1), off(SE0 + 6 * h + 2), ln);
-        gemm_split<4, U0, FB_E1, 1>(Ya, bX3, Ya, bX3, ring, off(SE0 + 6 * h + 2), off(SE1 + 6 * h + 1), ln);
+        gemm_split<4, U0, 2>(Ya, bX1, Yb, bX2, ring, off(SE0 + 6 * h + 0), ln);
+        gemm_split<4, U0, 2>(Ya, bX2, Yb, bX3, ring, off(SE0 + 6 * h + 1), ln);
+        gemm_split<4, U0, 1>(Ya, bX3, Ya, bX3, ring, off(SE0 + 6 * h + 2), ln);
         nyq_update(Ya, xn1, wn + 0 * 128 + 64 * h, ln);
         nyq_update(Yb, xn2, wn + 0 * 128 + 64 * h, ln);
         nyq_update(Ya, xn2, wn + 1 * 128 + 64 * h, ln);
@@ -413,11 +407,8 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
         relu_pack<4>(Yb, Pb, mx);
         auto bPa = [&](int u) { return Pa[u]; };
         auto bPb = [&](int u) { return Pb[u]; };
-        gemm_split<4, 2, FB_E1, 1>(Z1, bPa, Z1, bPa, ring, off(SE1 + 6 * h + 1), off(SE1 + 6 * h + 2), ln);
-        if (h == 0)
-            gemm_split<4, 2, FB_E0, 1>(Z1, bPb, Z1, bPb, ring, off(SE1 + 6 * h + 2), off(SE0 + 6), ln);
-        else
-            gemm_split<4, 2, FB_E2, 1>(Z1, bPb, Z1, bPb, ring, off(SE1 + 6 * h + 2), off(SE2T1), ln);
+        gemm_split<4, 2, 1>(Z1, bPa, Z1, bPa, ring, off(SE1 + 6 * h + 1), ln);
+        gemm_split<4, 2, 1>(Z1, bPb, Z1, bPb, ring, off(SE1 + 6 * h + 2), ln);
     }
 
     // ---- enc2 (stride 2, taps 1,2 see enc1 outputs 0,1), enc3 (centre tap), W_ih ----------------------
@@ -428,14 +419,14 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
     auto bQ1 = [&](int u) { return Q1[u]; };
     f32x4 Vv[4];
     init_bias<4>(Vv, tab + tb.b_e2, ln);
-    gemm_split<4, 2, FB_E2, 1>(Vv, bQ0, Vv, bQ0, ring, off(SE2T1), off(SE2T2), ln);
-    gemm_split<4, 2, FB_E3, 1>(Vv, bQ1, Vv, bQ1, ring, off(SE2T2), off(SE3T1), ln);
+    gemm_split<4, 2, 1>(Vv, bQ0, Vv, bQ0, ring, off(SE2T1), ln);
+    gemm_split<4, 2, 1>(Vv, bQ1, Vv, bQ1, ring, off(SE2T2), ln);
     Bop Pv[2];
     relu_pack<4>(Vv, Pv, mx);
     auto bPv = [&](int u) { return Pv[u]; };
     f32x4 Fe[8];
     init_bias<8>(Fe, tab + tb.b_e3, ln);
-    gemm_split<8, 2, FB_IH, 1>(Fe, bPv, Fe, bPv, ring, off(SE3T1), off(SIH0), ln);
+    gemm_split<8, 2, 1>(Fe, bPv, Fe, bPv, ring, off(SE3T1), ln);
     Bop Pf[4];
     relu_pack<8>(Fe, Pf, mx);
     auto bPf = [&](int u) { return Pf[u]; };
@@ -447,8 +438,7 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
     for (int q = 0; q < 4; ++q) {
         f32x4 G[8];
         init_bias<8>(G, tab + tb.b_g + 128 * q, ln);
-        if (q < 3) gemm_split<8, 4, FB_IH, 1>(G, bPf, G, bPf, ring, off(SIH0 + q), off(SIH0 + q + 1), ln);
-        else gemm_split<8, 4, 0, 1>(G, bPf, G, bPf, ring, off(SIH3), 0, ln);
+        gemm_split<8, 4, 1>(G, bPf, G, bPf, ring, off(SIH0 + q), ln);
         if (ln.tile_valid) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
