@@ -119,32 +119,43 @@ struct Bop {                   // B operand of one K32 step: 8 halves hi, 8 halv
 
 template <int BLOCKS>
 __device__ __forceinline__ void sring_issue(const SRing &r, long woff, int slot, const Lane &ln) {
-    // BLOCKS x 1 KiB, wave w copies blocks w, w+4, ...; global_load_lds issued from asm for the reason
-    // given in kernel_front.hip (ring_issue): keeps the compiler's lgkmcnt waits fine-grained.
-    static_assert(BLOCKS % kWV == 0 && BLOCKS <= kSB, "unit must be whole groups of one block per wave");
+    // BLOCKS x 1 KiB; wave w copies the CONTIGUOUS blocks [w n, (w+1) n), n = BLOCKS / kWV <= 4: one M0
+    // value and one source base per wave and unit, the instruction's immediate offset (which advances
+    // the global and the LDS address alike) selects the block.  global_load_lds is issued from asm for
+    // the reason given in kernel_front.hip (ring_issue): it keeps the compiler's lgkmcnt waits fine-grained.
+    constexpr int PW = BLOCKS / kWV;
+    static_assert(BLOCKS % kWV == 0 && BLOCKS <= kSB && (PW == 4 || PW == 2), "blocks per wave and unit");
     if (VAD_ABLATE & 8) return;
-    const unsigned *gbase = r.w + woff + (long)ln.wave * 256;
+    const unsigned *src = r.w + woff + (long)ln.wave * PW * 256;
     const unsigned voff = ln.lane * 16;
-    const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned *)(r.slots + slot * kSlotWords))
-                           + (unsigned)ln.wave * 1024u;
-#pragma unroll
-    for (int blk = 0; blk < BLOCKS; blk += kWV) {
-        const unsigned *src = gbase + (long)blk * 256;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lbase + (unsigned)blk * 1024u);
-        unsigned keep_m0;
+    const unsigned dst = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned *)(r.slots + slot * kSlotWords))
+                         + (unsigned)ln.wave * PW * 1024u;
+    unsigned keep_m0;                      // M0 is restored: the compiler may keep its own value there
+    if (PW == 4)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
                      : "=&s"(keep_m0)
                      : "v"(voff), "s"(src), "s"(dst)
                      : "memory");
-    }
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep_m0)
+                     : "v"(voff), "s"(src), "s"(dst)
+                     : "memory");
 }
 // Unit `ring.unit` has landed for THIS wave.  Every wave issues exactly kSB / kWV LDS-DMA instructions
 // per unit and `later` younger units are in flight, so the wait is counted: loads (PCM, DMA) complete
 // in order among themselves; stores (gx, ctx) may complete out of order but only ever ADD to the
 // counter, so they can delay this wait, never release it early.
 __device__ __forceinline__ void sring_wait(int later) {
-    static_assert(kSB / kWV == 4 && kAhead <= 3, "wait counts below assume 4 DMA instructions per unit");
+    static_assert(kSB / kWV == 4 && kAhead <= 3, "wait counts below assume 4 DMA instructions per wave and unit");
     if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
