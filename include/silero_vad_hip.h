@@ -89,6 +89,9 @@ int  vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ct
  * (JIT!/vad/model/vad_annotator.py:128-156; ONNX twin utils_vad.py:94-110) with the carried
  * state made explicit (pass zeroed ctx/state for the reference's reset-then-run behaviour).
  * A last partial chunk is right-padded with zeros, as the reference does (:141-148).
+ * `sr` may also be a multiple of 16000 (32000, 48000, ...): the input is then decimated to 16 kHz,
+ * x[:, ::sr/16000] (no filter, first sample kept -- vad_annotator.py:104-112, utils_vad.py:39-42), on
+ * the device, and L / T refer to the input / to ceil(ceil(L / k) / 512) chunks.
  *   pcm    dev [B][L]   row stride `ld`
  *   probs  dev [B][T]   row stride `ldp`                                                        */
 int  vad_forward_audio(vad_engine *e, int sr, int B, long L, const float *pcm, long ld,

@@ -20,6 +20,10 @@ template <typename PcmT>
 hipError_t launch_ref_forward(const RefNet &w, int sr, int B, long L, const PcmT *pcm, long ld,
                               float *ctx, float *state, float *probs, long ldp, hipStream_t s);
 
+// dst[b][i] = src[b][i * k] (the reference's x[:, ::step] for 32/48/... kHz input)
+template <typename PcmT>
+hipError_t launch_decimate(const PcmT *src, long lds, PcmT *dst, long ldd, int B, long Ld, int k, hipStream_t s);
+
 // ---- product path --------------------------------------------------------------------------------
 // Frontend: PCM -> in-wave FFT magnitude -> 4 conv blocks -> W_ih GEMM, fp32 MFMA.
 //   one wave = 16 chunks (16 streams x one time step); gx is written in MFMA D-fragment order

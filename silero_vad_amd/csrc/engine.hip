@@ -40,6 +40,8 @@ struct vad_engine {
     size_t tail_bytes = 0;
     void *d_realign = nullptr;                      // aligned copy of a misaligned input (rare)
     size_t realign_bytes = 0;
+    void *d_decim = nullptr;                        // 16 kHz copy of a 32/48/... kHz input
+    size_t decim_bytes = 0;
     long slab_steps = 0;                            // time steps per gx slab for the last reserve
 
     // profiling: 3 events per (call, slab), read back lazily by vad_kernel_times
@@ -119,10 +121,35 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
                  float *state, float *probs, long ldp, void *stream_v) {
     if (!e) return VAD_ERR_ARG;
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
-    const int ni = net_index(sr);
-    if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000]");
     if (B < 0 || L < 0 || (B > 0 && L > 0 && (!pcm || !ctx || !state || !probs)) || ld < L)
         return fail(e, VAD_ERR_ARG, "bad argument");
+    if (sr > 16000 && sr % 16000 == 0) {
+        // sample-rate front door: a multiple of 16 kHz is decimated to 16 kHz, x[:, ::sr/16000], exactly as the
+        // reference does (vad_annotator.py:104-112), then takes the 16 kHz path
+        if (B == 0 || L == 0) return VAD_OK;
+        const int k = sr / 16000;
+        const long Ld = (L + k - 1) / k, ldd = (Ld + 15) / 16 * 16;
+        const size_t need = (size_t)B * ldd * sizeof(PcmT);
+        hipStream_t stream = (hipStream_t)stream_v;
+        HIP_TRY(e, hipSetDevice(e->device));
+        if (need > e->decim_bytes) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return fail(e, VAD_ERR_CAPTURE, "decimation scratch must grow during stream capture");
+            HIP_TRY(e, hipDeviceSynchronize());
+            if (e->d_decim) (void)hipFree(e->d_decim);
+            e->d_decim = nullptr;
+            e->decim_bytes = 0;
+            if (hipMalloc(&e->d_decim, need) != hipSuccess)
+                return fail(e, VAD_ERR_ALLOC, "cannot allocate decimation scratch");
+            e->decim_bytes = need;
+        }
+        PcmT *dec = reinterpret_cast<PcmT *>(e->d_decim);
+        HIP_TRY(e, vad::launch_decimate<PcmT>(pcm, ld, dec, ldd, B, Ld, k, stream));
+        return forward_impl<PcmT>(e, 16000, B, Ld, dec, ldd, ctx, state, probs, ldp, stream_v);
+    }
+    const int ni = net_index(sr);
+    if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000] (or multiply of 16000)");
     if (B == 0 || L == 0) return VAD_OK;
     const int N = sr == 16000 ? 512 : 256, C = N / 8;
     const long T = (L + N - 1) / N;
@@ -329,6 +356,7 @@ void vad_destroy(vad_engine *e) {
         if (e->d_ctx_new) (void)hipFree(e->d_ctx_new);
         if (e->d_tail) (void)hipFree(e->d_tail);
         if (e->d_realign) (void)hipFree(e->d_realign);
+        if (e->d_decim) (void)hipFree(e->d_decim);
         for (auto &ev : e->ev_pool) (void)hipEventDestroy(ev);
     }
     delete e;
@@ -369,7 +397,7 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
 
 int vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ctx, float *state,
              float *prob, void *stream) {
-    const int N = sr == 16000 ? 512 : 256;
+    const int N = (sr > 16000 && sr % 16000 == 0) ? 512 * (sr / 16000) : sr == 16000 ? 512 : 256;
     return forward_impl<float>(e, sr, B, N, pcm, ld, ctx, state, prob, 1, stream);
 }
 

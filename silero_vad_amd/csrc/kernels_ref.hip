@@ -131,6 +131,26 @@ hipError_t launch_ref_forward(const RefNet &w, int sr, int B, long L, const PcmT
     return hipGetLastError();
 }
 
+// ---- sample-rate front door ---------------------------------------------------------------------------
+// dst[b][i] = src[b][i * k], i < Ld: the reference's decimation of 32 / 48 / ... kHz input to 16 kHz,
+// `x[:, ::step]` (JIT!/vad/model/vad_annotator.py:104-112, src/silero_vad/utils_vad.py:39-42): no
+// filter, first sample kept.  HBM-bound gather; rows of dst are 16-byte aligned (ldd % 8 == 0).
+template <typename PcmT>
+__global__ void decimate_kernel(const PcmT *src, long lds, PcmT *dst, long ldd, long Ld, int k) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long b = blockIdx.y;
+    if (i < Ld) dst[b * ldd + i] = src[b * lds + i * k];
+}
+template <typename PcmT>
+hipError_t launch_decimate(const PcmT *src, long lds, PcmT *dst, long ldd, int B, long Ld, int k, hipStream_t s) {
+    if (B <= 0 || Ld <= 0) return hipSuccess;
+    hipLaunchKernelGGL((decimate_kernel<PcmT>), dim3((unsigned)((Ld + 255) / 256), (unsigned)B), dim3(256), 0, s,
+                       src, lds, dst, ldd, Ld, k);
+    return hipGetLastError();
+}
+template hipError_t launch_decimate<float>(const float *, long, float *, long, int, long, int, hipStream_t);
+template hipError_t launch_decimate<int16_t>(const int16_t *, long, int16_t *, long, int, long, int, hipStream_t);
+
 template hipError_t launch_ref_forward<float>(const RefNet &, int, int, long, const float *, long,
                                               float *, float *, float *, long, hipStream_t);
 template hipError_t launch_ref_forward<int16_t>(const RefNet &, int, int, long, const int16_t *,

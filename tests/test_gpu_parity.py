@@ -237,6 +237,47 @@ def test_int16_ingest(model, golden, tag):
     assert np.array_equal(p_i, p_f) and np.array_equal(s_i, s_f) and np.array_equal(c_i, c_f)
 
 
+@pytest.mark.parametrize("k", [2, 3])
+def test_sample_rate_front_door(model, golden, k):
+    """32 / 48 kHz input through the C ABI: decimated on the device exactly like the reference's
+    x[:, ::sr // 16000] (vad_annotator.py:104-112), then the 16 kHz path -- bit-identical to handing over
+    the decimated signal, for float and int16 PCM and for single steps."""
+    from silero_vad_amd import _lib
+    eng, dev = model.engine, model.device
+    B, T = 5, 7
+    L = k * (T * 512 - 100) + 1                              # ragged: the last chunk is partial after decimation
+    for src, fn in ((golden["16k"]["wav"], _lib.lib().vad_forward_audio),
+                    (golden["16k"]["pcm_i16"], _lib.lib().vad_forward_audio_i16)):
+        x = torch.from_numpy(np.stack([np.roll(src, -b * 3001)[:L] for b in range(B)])).to(dev).contiguous()
+        xd = x[:, ::k].contiguous()
+        outs = []
+        for inp, sr in ((x, 16000 * k), (xd, 16000)):
+            ctx = torch.zeros((B, 64), device=dev)
+            st = torch.zeros((2, B, 128), device=dev)
+            p = torch.empty((B, T), device=dev)
+            _lib.check(eng._h, fn(eng._h, sr, B, inp.shape[1], inp.data_ptr(), inp.stride(0), ctx.data_ptr(),
+                                   st.data_ptr(), p.data_ptr(), T, None))
+            torch.cuda.synchronize()
+            outs.append((p.clone(), st.clone(), ctx.clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    # one step: a 512 k-sample chunk
+    x = torch.from_numpy(np.stack([np.roll(golden["16k"]["wav"], -b * 77)[:512 * k] for b in range(B)])).to(dev)
+    res = []
+    for inp, sr in ((x.contiguous(), 16000 * k), (x[:, ::k].contiguous(), 16000)):
+        ctx = torch.zeros((B, 64), device=dev)
+        st = torch.zeros((2, B, 128), device=dev)
+        p = torch.empty((B,), device=dev)
+        _lib.check(eng._h, _lib.lib().vad_step(eng._h, sr, B, inp.data_ptr(), inp.stride(0), ctx.data_ptr(),
+                                               st.data_ptr(), p.data_ptr(), None))
+        torch.cuda.synchronize()
+        res.append(p.clone())
+    assert torch.equal(res[0], res[1])
+    # rates that are neither supported nor a multiple of 16 kHz are still refused
+    assert _lib.lib().vad_forward_audio(eng._h, 22050, B, 512, x.data_ptr(), x.stride(0), ctx.data_ptr(),
+                                        st.data_ptr(), p.data_ptr(), 1, None) == 2
+
+
 def test_misaligned_rows_are_handled(model, oracle, golden):
     sr, n = 16000, 512
     B, L = 3, 6 * n + 3                                   # odd row stride -> rows not 16-B aligned
