@@ -192,7 +192,7 @@ def base_line(args, world, metric_sr, value, elapsed, steps):
     return {"metric": f"audio-chunks/sec (32 ms @ {metric_sr // 1000} kHz)", "value": round(value, 1),
             "unit": "chunks/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16x3 products, f32 sums",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 sums of f16x3 split products",
             "precision": args.precision, "data": "synthetic"}
 
 

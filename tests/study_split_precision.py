@@ -7,7 +7,7 @@ the network in which every matrix product can be evaluated as
     b3 / b6          bf16 split, 3 products (2 parts) / 6 products (3 parts)
 with fp32 results, run over the 60 s (16 kHz) and 169 s (8 kHz) speech fixtures and compared with the
 golden probabilities recorded from the reference model.
-    python tools/split_precision_study.py f32 h1 h3 h3z b3 b6
+    python tests/study_split_precision.py f32 h1 h3 h3z b3 b6
 """
 import sys, numpy as np
 sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))

@@ -6,7 +6,7 @@ tools/split_diag.py take a variant through SILERO_VAD_AMD_LIB=build/variants/lib
     python tools/variants.py run [names...]   # on the GPU box: bench each, write gpurun_out/variants.json
 
 A variant is a set of -D flags.  Variants whose name starts with "abl" are timing-only ablations
-(wrong results by construction); every other variant is parity-checked against the oracle before
+(wrong results by construction); every other variant is parity-checked against the golden vectors before
 it is timed.  The product library is always silero_vad_amd/libsilero_vad_hip.so (default knobs).
 """
 import json
@@ -101,14 +101,13 @@ CHECK = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
 import silero_vad_amd
-from oracle import Oracle
 m = silero_vad_amd.load_silero_vad(device=0)
-o = Oracle()
+g = np.load(%r)
 wav = np.load(%r)["pcm"].astype(np.float32) / 32768.0
-rows = np.stack([np.roll(wav, -b * 7919)[:20 * 512] for b in range(40)])
+B, T, L, stride = (int(v) for v in g["batch_meta"])
+rows = np.stack([np.roll(wav, -b * stride)[:L] for b in range(B)])
 got = m.audio_forward(torch.from_numpy(rows), 16000).numpy()
-want = o.audio_forward(rows, 16000)
-print("PARITY", float(np.abs(got - want).max()))
+print("PARITY", float(np.abs(got - g["probs_batch"]).max()))        # golden vectors of the reference model
 """
 
 
@@ -120,7 +119,8 @@ def run(names):
         env = dict(os.environ, SILERO_VAD_AMD_LIB=str(lib))
         r = {}
         if not name.startswith("abl"):
-            chk = subprocess.run([sys.executable, "-c", CHECK % (str(ROOT), str(ROOT / "tests/golden/audio_16k.npz"))],
+            chk = subprocess.run([sys.executable, "-c", CHECK % (str(ROOT), str(ROOT / "tests/golden/golden_16k.npz"),
+                                                                  str(ROOT / "tests/golden/audio_16k.npz"))],
                                  env=env, capture_output=True, text=True, timeout=600)
             r["parity"] = next((float(l.split()[1]) for l in chk.stdout.splitlines() if l.startswith("PARITY")), None)
             if r["parity"] is None:
