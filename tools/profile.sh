@@ -15,4 +15,5 @@ rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o fetch --output-format csv -- pytho
 rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o write --output-format csv -- python bench.py $args > "$out/write.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d "$out/sq" -o sq --output-format csv -- python bench.py $args > "$out/sq.log" 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d "$out/sq2" -o sq2 --output-format csv -- python bench.py $args > "$out/sq2.log" 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_MFMA_MOPS_F16 -d "$out/sq3" -o sq3 --output-format csv -- python bench.py $args > "$out/sq3.log" 2>&1
 grep -h '"metric"' "$out"/*.log | cut -c1-400
