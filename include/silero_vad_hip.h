@@ -68,6 +68,8 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *                 fp16 range (65504): true for |pcm| <= 1 with a 12x margin on every signal tried; a
  *                 stream that leaves the range gets NaN probabilities (never a wrong number) from that
  *                 chunk on and must be rerun with "fp32" (exact v_mfma_f32_16x16x4_f32 chain, no limit).
+ *   "gx_cap_mib"= cap, in MiB, of the engine's scratch for the LSTM input-gate pre-activations (default 6144);
+ *                 a call whose B x T needs more is processed in time slabs, transparently
  *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)
  *   "trace_ptr" = device address (bring-up only): builds compiled with -DVAD_TRACE=1 write 16
  *                 int64 phase timestamps per frontend workgroup there; normal builds ignore it  */

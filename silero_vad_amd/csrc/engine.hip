@@ -43,6 +43,7 @@ struct vad_engine {
     void *d_decim = nullptr;                        // 16 kHz copy of a 32/48/... kHz input
     size_t decim_bytes = 0;
     long slab_steps = 0;                            // time steps per gx slab for the last reserve
+    size_t gx_cap = 6ull << 30;                     // cap of the gx scratch; longer inputs are slabbed (option gx_cap_mib)
 
     // profiling: 3 events per (call, slab), read back lazily by vad_kernel_times
     std::vector<hipEvent_t> ev_pool;
@@ -51,8 +52,6 @@ struct vad_engine {
 };
 
 namespace {
-
-constexpr size_t kMaxGxBytes = 6ull << 30;         // cap of the gx scratch; longer inputs are slabbed
 
 int fail(vad_engine *e, int code, const std::string &msg) {
     if (e) e->err = msg;
@@ -69,16 +68,16 @@ int hip_fail(vad_engine *e, hipError_t rc, const char *what) {
 
 int net_index(int sr) { return sr == 16000 ? 0 : sr == 8000 ? 1 : -1; }
 
-long slab_for(int B, long T) {
+long slab_for(const vad_engine *e, int B, long T) {
     const long nst = (B + 15) / 16;
     const size_t per_step = (size_t)nst * 32 * 256 * sizeof(float);   // gx bytes per time step
-    long s = (long)std::max<size_t>(1, kMaxGxBytes / per_step);
+    long s = (long)std::max<size_t>(1, e->gx_cap / per_step);
     return std::min(s, T);
 }
 
 int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
     const long nst = (B + 15) / 16;
-    const long slab = slab_for(B, T);
+    const long slab = slab_for(e, B, T);
     const size_t need_gx = (size_t)nst * slab * 32 * 256;
     const size_t need_ctx = (size_t)B * (sr == 16000 ? 64 : 32);
     const size_t need_tail = (size_t)B * (sr == 16000 ? 512 : 256) * sizeof(float);
@@ -380,6 +379,12 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
     if (n == "precision_front" || n == "precision_rec") {   // bring-up: mix the two kernels
         if (v != "f16x3" && v != "fp32") return fail(e, VAD_ERR_OPTION, "precision must be f16x3|fp32");
         (n == "precision_front" ? e->split : e->split_rec) = (v == "f16x3");
+        return VAD_OK;
+    }
+    if (n == "gx_cap_mib") {                         // scratch cap (MiB); inputs longer than it allows run in time slabs
+        const long mib = std::strtol(value, nullptr, 0);
+        if (mib < 1) return fail(e, VAD_ERR_OPTION, "gx_cap_mib must be >= 1");
+        e->gx_cap = (size_t)mib << 20;
         return VAD_OK;
     }
     if (n == "trace_ptr") {                          // bring-up only; ignored by normal builds

@@ -278,6 +278,24 @@ def test_sample_rate_front_door(model, golden, k):
                                         st.data_ptr(), p.data_ptr(), 1, None) == 2
 
 
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_time_slabs_are_transparent(model, golden, tag):
+    """An input whose gate pre-activations exceed the scratch cap is processed in time slabs (here: cap 1 MiB,
+    33 streams -> 10 steps per slab, 47 chunks -> 5 slabs); results are bit-identical to the un-slabbed call."""
+    sr = SRS[tag]
+    n = chunk_of(sr)
+    B, T = 33, 47
+    rows = rolled_rows(golden[tag]["wav"], B, T * n - 5, 4567)
+    want = run_engine(model, rows, sr)
+    model.engine.set_option("gx_cap_mib", 1)
+    try:
+        got = run_engine(model, rows, sr)
+    finally:
+        model.engine.set_option("gx_cap_mib", 6144)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
 def test_misaligned_rows_are_handled(model, oracle, golden):
     sr, n = 16000, 512
     B, L = 3, 6 * n + 3                                   # odd row stride -> rows not 16-B aligned
