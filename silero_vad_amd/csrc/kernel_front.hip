@@ -229,7 +229,22 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
                   FB_E2 = first_unit_blocks(4, 16), FB_E3 = first_unit_blocks(8, 16),
                   FB_IH = first_unit_blocks(8, 32);
     ring_issue<FB_E0>(ring, o_e0t1, 0, ln);      // first unit of the program: head of E0T1
-    for (int i = threadIdx.x; i < tb.total; i += 256) tab[i] = a.tables[i];
+    {   // tables -> LDS: all loads of a thread are issued before the first is stored
+        static_assert(tb.total % 4 == 0, "tables are copied as 16-byte vectors");
+        constexpr int NV = tb.total / 4, PER = (NV + 255) / 256;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.tables);
+        f32x4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            v[k] = src[i < NV ? i : NV - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < NV) reinterpret_cast<f32x4 *>(tab)[i] = v[k];
+        }
+    }
     __syncthreads();
 
     float X0[Q + 1], X1[Q + 1], X2[Q + 1], X3[Q + 1];

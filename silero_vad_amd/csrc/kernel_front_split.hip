@@ -332,7 +332,24 @@ __global__ void __launch_bounds__(64 * kWV, 2) front_split_kernel(const FrontArg
 
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) sring_request(ring, u, ln);      // prime the ring
-    for (int i = threadIdx.x; i < tb.total; i += 64 * kWV) tab[i] = a.tables[i];
+    if (!(VAD_ABLATE & 256)) {             // (256: timing experiment, tables left uninitialised)
+        // tables -> LDS: all loads of a thread are issued before the first is stored (one memory latency,
+        // not one per 1 KiB; the plain loop cost 4 % of the kernel)
+        static_assert(tb.total % 4 == 0, "tables are copied as 16-byte vectors");
+        constexpr int NV = tb.total / 4, PER = (NV + 64 * kWV - 1) / (64 * kWV);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.tables);
+        f32x4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * 64 * kWV;
+            v[k] = src[i < NV ? i : NV - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * 64 * kWV;
+            if (i < NV) reinterpret_cast<f32x4 *>(tab)[i] = v[k];
+        }
+    }
     __syncthreads();
 
     float mx = 0.f;

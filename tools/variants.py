@@ -47,6 +47,7 @@ VARIANTS = {
     # f16x3 kernels (kernel_front_split.hip, kernel_rec_split.hip).  VAD_ABLATE bits there: 1 no barriers,
     # 2 no FFT math, 4 no PCM loads, 8 no weight ring, 64 no matrix pipe, 128 one fragment read per unit.
     "abl_nomfma": ["-DVAD_ABLATE=64"],
+    "abl_notab": ["-DVAD_ABLATE=256"],
     "abl_nolds": ["-DVAD_ABLATE=128"],
     "abl_nomfma_nolds": ["-DVAD_ABLATE=192"],
     "abl_nofft_nomfma": ["-DVAD_ABLATE=66"],
