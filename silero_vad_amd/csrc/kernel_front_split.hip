@@ -24,7 +24,9 @@
 //   * the Nyquist bin (the 129th / 65th input channel of enc0, alone in a fifth K step) is applied as
 //     an fp32 rank-1 VALU update instead of an almost empty MFMA step;
 //   * activations are converted to (hi, lo) half pairs once, when produced (5 VALU per 2 values), and
-//     live in registers as the packed B operands of the next layer (chain layout, layout.hpp).
+//     live in registers as the packed B operands of the next layer (chain layout, layout.hpp);
+//   * the weight image streams L2 -> LDS through a ring of 4 x 16 KiB slots by a static schedule
+//     (make_sched), each unit requested three units ahead, with counted vmcnt waits (sring_wait).
 // BUILD REQUIREMENT -- no packed-fp32 VALU instructions in this translation unit
 // (__graft_entry__.py: -Xclang -target-feature -Xclang -packed-fp32-ops, and it disassembles the object
 // to check).  Measured on MI355X / ROCm 7.2: when one wave of a SIMD runs v_pk_fma_f32 / v_pk_mul_f32 /
