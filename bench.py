@@ -290,7 +290,7 @@ def run_stream(args, rank, world, local, dist):
         pool.tick_staged()
         k[0] += 1
 
-    for _ in range(max(args.warmup, 3)):
+    for _ in range(max(args.warmup, 3) + 1500):                # + DVFS ramp (~130 ms of ticks), see run_batch
         tick()
     steps = args.steps
     elapsed = timed(world, dist, dev, steps, tick)
