@@ -61,8 +61,8 @@ constexpr int first_unit_blocks(int M, int KS) {
 
 template <int BLOCKS>
 __device__ __forceinline__ void ring_issue(const Ring &r, long goff, int slot, const Lane &ln) {
-    // BLOCKS blocks of 1 KiB; wave w copies blocks w, w+4, ...  LDS destination = M0 (wave-uniform
-    // base) + lane*16, the layout global_load_lds requires.
+    // BLOCKS blocks of 1 KiB.  LDS destination = M0 (wave-uniform base) + instruction offset + lane*16, the
+    // layout global_load_lds requires.
     //
     // The LDS-DMA is issued from inline asm ON PURPOSE: while the compiler knows of a pending
     // global_load_lds it degrades every `s_waitcnt lgkmcnt(N)` to lgkmcnt(0), which serialises the
@@ -70,20 +70,40 @@ __device__ __forceinline__ void ring_issue(const Ring &r, long goff, int slot, c
     // protocol orders the DMA instead: ring_wait() = s_waitcnt vmcnt(0) before the unit's barrier.
     static_assert(BLOCKS % 4 == 0 && BLOCKS <= kSlotBlocks, "unit must be whole 4-block groups");
     if (VAD_ABLATE & 8) return;
-    const float *gbase = r.wfront + goff + (long)ln.wave * 256;           // wave-uniform
+    // Wave w copies the CONTIGUOUS blocks [w n, (w+1) n), n = BLOCKS / 4: one M0 value and one source base
+    // per group of up to 4 blocks, the instruction's immediate offset (which advances the global and the
+    // LDS address alike, 13 bits) selects the block within the group.
+    constexpr int PW = BLOCKS / 4;
+    const float *gbase = r.wfront + goff + (long)ln.wave * PW * 256;      // wave-uniform
     const unsigned voff = ln.lane * 16;                                    // bytes
     const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float *)(r.slots + slot * kRingSlotFloats))
-                           + (unsigned)ln.wave * 1024u;
+                           + (unsigned)ln.wave * PW * 1024u;
 #pragma unroll
-    for (int blk = 0; blk < BLOCKS; blk += 4) {
-        const float *src = gbase + (long)blk * 256;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lbase + (unsigned)blk * 1024u);
+    for (int grp = 0; grp < PW; grp += 4) {
+        const float *src = gbase + (long)grp * 256;
+        const unsigned dst = lbase + (unsigned)grp * 1024u;
+        const int n = PW - grp < 4 ? PW - grp : 4;
         unsigned keep_m0;                      // M0 is restored: the compiler may keep its own value there
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep_m0)
-                     : "v"(voff), "s"(src), "s"(dst)
-                     : "memory");
+        if (n == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep_m0) : "v"(voff), "s"(src), "s"(dst) : "memory");
+        else if (n == 3)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep_m0) : "v"(voff), "s"(src), "s"(dst) : "memory");
+        else if (n == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep_m0) : "v"(voff), "s"(src), "s"(dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep_m0) : "v"(voff), "s"(src), "s"(dst) : "memory");
     }
 }
 // All of this wave's ring DMA has landed in LDS (and everything else it had in flight on vmcnt).
