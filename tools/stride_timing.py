@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Does the PCM row stride matter (4096 rows x 512 KiB is a power-of-two stride)?  Times the kernels for several row
+paddings, alternating.  Round-1 answer: no -- what differs between the first and the later configurations of a run is
+the GPU's clock ramp (+4 %; bench.py therefore runs untimed ramp steps first), not the stride."""
 import json, sys, torch
 sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]))
 from silero_vad_amd import Engine
