@@ -1,37 +1,42 @@
 #!/usr/bin/env python3
 """Headline benchmark: speech-probability throughput of the Silero-VAD hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|8k|stream|corpus]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|8k|stream|corpus] [--precision fp32|f16x3]
 
-Default workload `c2` (BASELINE.json configs[1], SURVEY.md section 8d "C2"): synthetic 16 kHz
-PCM, 512-sample chunks, 4096 independent streams per GPU x 256 chunks per stream, fp32, already
-resident in HBM.  One "step" = one pass of the hot path over that batch = ONE vad_forward_audio call
-through the C ABI (zeroed context/state, like the reference's audio_forward).  Streams are sharded
-across ranks with no data-path collective (weak scaling: every rank owns 4096 streams); the only
-communication is the barrier + MAX-reduce of the elapsed time that the measurement contract asks
-for.  The other configs are extra evidence lines, not the headline:
-  8k      configs[2]: 8 kHz, 256-sample chunks, 4096 streams x 256 chunks (the 8 kHz net)
-  stream  configs[4]: 8192 live streams per GPU (65 536 per 8-GPU node), persistent state in HBM,
-          one hipGraph-captured vad_step per 32 ms tick; a step = one tick; also reports tick latency
-  corpus  configs[3] (bounded sample): ragged int16 recordings in host memory -> pinned staging ->
-          H2D overlapped with compute -> probs -> native batch segmenter.  PCIe-inclusive.
+`--gpus N` (N > 1) works both ways the driver may start it: under `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` (RANK/LOCAL_RANK/WORLD_SIZE in the environment), and as a plain
+`python bench.py --gpus N`, which re-executes itself under torch.distributed.run on 127.0.0.1.
 
-Prints ONE JSON line on rank 0.  `value` = chunks/s over the whole job.  Extra objects:
-  roofline      dominant kernel (frontend: STFT + encoder + W_ih GEMM) against the fp32 MFMA peak,
-                from hipEvents recorded by the engine around that kernel during the timed steps
-  cpu_baseline  the CPU oracle (a port of the reference's arithmetic) on this box's host cores,
-                on a bounded sample of the same workload (rank 0, N=1 only)
+Default workload `c2` (BASELINE.json configs[1], SURVEY.md section 8d "C2"): synthetic 16 kHz PCM, 512-sample
+chunks, 4096 independent streams per GPU x 256 chunks per stream, fp32, already resident in HBM, exact fp32
+arithmetic (`dtype: "f32"`, the reference's).  One "step" = one pass of the hot path over that batch = ONE
+vad_forward_audio call through the C ABI (zeroed context/state, like the reference's audio_forward).  Streams
+are sharded across ranks with no data-path collective (weak scaling: every rank owns 4096 streams); the only
+communication is the barrier + MAX-reduce of the elapsed time that the measurement contract asks for.
+
+At N = 1 the same JSON line also carries, for the record (none of them is the headline `value`):
+  other_precision  the opt-in f16x3 arithmetic on the same data, same ramp/steps protocol
+  other_configs    8k     configs[2]: 8 kHz, 256-sample chunks, 4096 streams x 256 chunks (the 8 kHz net)
+                   stream configs[4]: 8192 live streams per GPU (65 536 per 8-GPU node), persistent state in
+                          HBM, one hipGraph-captured vad_step per 32 ms tick; reports tick latency
+                   corpus configs[3] (bounded sample): ragged int16 recordings in host memory -> pinned staging
+                          -> H2D overlapped with compute -> probs -> native segmenter.  PCIe + host inclusive.
+  roofline         dominant kernel (frontend: STFT + encoder + W_ih GEMM): EXECUTED fp32 MFMA flops per launch /
+                   average launch duration (hipEvents recorded by the engine around that kernel on the launch
+                   stream during the timed steps) against the dense fp32 MFMA peak; always <= 1
+  cpu_baseline     the reference's own ATen CPU operators (oracle/aten_port.py, kind "aten-port") timed on this
+                   box's host cores under BASELINE.md section 3 protocols R1-R4 (rank 0, N = 1 only)
+`--config 8k|stream|corpus` runs one of the other configs as the main leg instead.
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import torch
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -39,101 +44,72 @@ sys.path.insert(0, str(ROOT))
 STREAMS = 4096           # per GPU (c2 / 8k)
 CHUNKS_PER_STREAM = 256  # per step
 LIVE_STREAMS = 8192      # per GPU (stream): 65 536 per 8-GPU node
-CLOCK_RAMP_STEPS = 40    # untimed steps (~130 ms) before the warm-up: DVFS ramp, see run_batch
+CLOCK_RAMP_STEPS = 40    # untimed steps before the warm-up: DVFS ramp, see run_batch
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
 PEAK_F16_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
-# Algorithmic work per chunk.  "dense" = exactly as the reference
-# computes it (DFT-basis conv, every tap); "mfma" = what our kernels execute on the matrix pipe
-# (rFFT frontend on the VALU instead of the basis conv, zero-padding taps skipped).
+# Work per chunk.  "flop"/"bytes": the reference's DENSE arithmetic and its I/O --
+# "useful reference work".  "front_mfma" / "rec_mfma": matrix flops our kernels EXECUTE (rFFT frontend on the VALU
+# instead of the DFT-basis conv, zero-padding taps skipped, K padded to the MFMA step) = MFMA instructions per
+# 16-chunk tile x 2048 flop / 16 -- the numerator of roofline.frac.  f16x3: three f16 products per product.
 WORK = {
     16000: {"chunk": 512, "flop": 1_359_104, "bytes": 2_052,
             "front_dense": 2 * (264_192 + 198_144 + 49_152 + 12_288 + 24_576 + 65_536),
             "front_mfma": 2 * (10 * 128 * 132 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
             "front_split_mfma": 2 * 3 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
-            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<32,float>",
-            "front_split_kernel": "front_split_kernel<32,float>"},
+            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<32, float>",
+            "front_split_kernel": "front_split_kernel<32, float>"},
     8000: {"chunk": 256, "flop": 767_232, "bytes": 1_028,
            "front_dense": 2 * (66_560 + 99_840 + 49_152 + 12_288 + 24_576 + 65_536),
            "front_mfma": 2 * (10 * 128 * 68 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
            "front_split_mfma": 2 * 3 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
-           "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<16,float>",
-           "front_split_kernel": "front_split_kernel<16,float>"},
+           "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<16, float>",
+           "front_split_kernel": "front_split_kernel<16, float>"},
 }
+GX_BYTES = 2048          # engine-internal: fp32 LSTM input-gate pre-activations per chunk, written and read once
 
 
-def cpu_baseline(sr, seconds_target=12.0):
-    """Time the oracle (kind 'port': plain-C restatement of the reference's dense arithmetic, OpenMP
-    over streams) on this host.  Bounded sample of the same workload: S streams x 32 chunks."""
-    import numpy as np
-    from oracle import Oracle
-    o = Oracle()
-    cores = len(os.sched_getaffinity(0))
-    rng = np.random.default_rng(17 + sr)
-    T, n = 32, WORK[sr]["chunk"]
-
-    def run(S):
-        pcm = (rng.standard_normal((S, T * n)) * 0.03).astype(np.float32)
-        t0 = time.perf_counter()
-        o.forward_audio(pcm, sr)
-        return S * T / (time.perf_counter() - t0)
-
-    rate = run(cores * 2)                          # warm-up + calibration
-    S = max(cores, int(rate * seconds_target / T) // cores * cores)
-    rate = run(S)
-    return {"value": round(rate, 1), "unit": "chunks/s", "cores": cores, "kind": "port",
-            "sample": f"{S} streams x {T} chunks of the same {sr // 1000} kHz synthetic workload, "
-                      f"oracle/vad_oracle.c (gcc -O3 -mavx2 -mfma, OpenMP over streams, {cores} threads)"}
-
-
-def pmc_traffic(kernel_key, sr, B, T):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc summary
-    (profiles/*_summary.json, written by tools/summarize_prof.py from a run of this same command):
-    FETCH_SIZE (KiB; doubled -- gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md "HBM")
-    + WRITE_SIZE (KiB).  None if no summary matches this workload."""
-    best = None
-    for f in sorted(glob.glob(str(ROOT / "profiles" / "*_summary.json"))):
-        try:
-            d = json.loads(Path(f).read_text())
-        except Exception:
-            continue
-        wl = d.get("workload", {"sr": 16000, "streams": 4096, "chunks": 256})
-        if (wl.get("sr"), wl.get("streams"), wl.get("chunks")) != (sr, B, T):
-            continue
-        for k, c in d.get("pmc", {}).items():
-            if k.replace(" ", "").startswith(kernel_key.replace(" ", "")) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                best = {"bytes": int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
-                        "fetch_bytes": int(2.0 * c["FETCH_SIZE"] * 1024), "write_bytes": int(c["WRITE_SIZE"] * 1024),
-                        "source": os.path.relpath(f, ROOT)}
-    return best
+# ---- launching --------------------------------------------------------------------------------------------
+def relaunch_distributed(args):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run --nproc-per-node N`."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def setup_dist(args):
+    import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dry:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     return rank, world, local, dist
 
 
-def timed(world, dist, dev, steps, fn):
+def timed(world, dist, dev, steps, fn, sync):
     """barrier + synchronize on both sides of exactly `steps` calls of fn; MAX over ranks."""
+    import torch
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -144,9 +120,58 @@ def timed(world, dist, dev, steps, fn):
     return elapsed
 
 
+def gpu_sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+# ---- evidence helpers -------------------------------------------------------------------------------------
+def cpu_baseline(sr, budget_s=24.0):
+    """The reference's CPU path on this box: oracle/aten_port.py issues the ATen operators the TorchScript model
+    dispatches to (bit-identical to it on the goldens, tests/test_oracle.py) under the reference's threading and
+    timing rules.  Runs in its own CPU-only process (it forks one worker per core for protocol R4)."""
+    r = subprocess.run([sys.executable, "-m", "oracle.aten_port", "--sr", str(sr), "--budget-s", str(budget_s)],
+                       cwd=str(ROOT), capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    line = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
+    if line is None:
+        return {"value": None, "unit": "chunks/s", "kind": "aten-port", "error": (r.stderr or r.stdout)[-400:]}
+    d = json.loads(line)
+    return {"value": d["value"], "unit": "chunks/s", "cores": d["nproc"], "kind": "aten-port",
+            "best_protocol": d["best"], "cpu_model": d["cpu_model"], "torch": d["torch"],
+            "runs": d["runs"],
+            "sample": f"same {sr // 1000} kHz synthetic workload (0.03 N(0,1)), audio_forward over B streams x T chunks "
+                      f"per run as listed under runs; warm-up {d['warmup']}, median of {d['trials']}; R1 = 1 thread B=1 "
+                      "(the reference's shipped default), R2 = 1 thread B=4096, R3 = nproc threads B=4096, "
+                      "R4 = nproc processes x 1 thread sharing the 4096 streams; value = the best of the four"}
+
+
+def pmc_traffic(kernel_key, sr, B, T):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 --pmc summary (profiles/*_summary.json,
+    written by tools/summarize_prof.py from a run of this same command): FETCH_SIZE (KiB; doubled -- gfx950 tallies
+    128-B requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KiB).  None if no summary matches."""
+    best = None
+    key = kernel_key.replace(" ", "")
+    for f in sorted(glob.glob(str(ROOT / "profiles" / "*_summary.json"))):
+        try:
+            d = json.loads(Path(f).read_text())
+        except Exception:
+            continue
+        wl = d.get("workload", {"sr": 16000, "streams": 4096, "chunks": 256})
+        if (wl.get("sr"), wl.get("streams"), wl.get("chunks")) != (sr, B, T):
+            continue
+        for k, c in d.get("pmc", {}).items():
+            if k.replace(" ", "").startswith(key) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                best = {"bytes": int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
+                        "fetch_bytes": int(2.0 * c["FETCH_SIZE"] * 1024), "write_bytes": int(c["WRITE_SIZE"] * 1024),
+                        "source": os.path.relpath(f, ROOT)}
+    return best
+
+
 def synth_pcm(B, L, sr, dev, seed):
     """0.03 * N(0,1) as in examples/onnx_sequence/run.py:159-162, plus a per-stream tone so that the
     operands are not sign-symmetric noise only (throughput is data independent; DVFS is not)."""
+    import torch
     gen = torch.Generator(device=dev).manual_seed(seed)
     pcm = torch.empty((B, L), dtype=torch.float32, device=dev)
     pcm.normal_(0.0, 0.03, generator=gen)
@@ -156,53 +181,89 @@ def synth_pcm(B, L, sr, dev, seed):
     return pcm
 
 
-def roofline(sr, chunks_per_launch, front_ms_avg, B, T, precision="fp32"):
-    """Dominant kernel = the frontend (STFT + encoder + W_ih).  `achieved` = the reference's DENSE flop
-    count for that part of the path per second, against the fp32 MFMA peak -- the precision
-    the result is delivered in.  `mfma_executed` is what the matrix pipe really runs (fp32 MFMA, or
-    3 f16 MFMA flops per algorithmic flop for precision=f16x3, against the f16 peak); `hbm` is the
-    same launch against the HBM roofline (PCM in + gx out, 2 x 2048 B per 16 kHz chunk)."""
+def roofline(sr, chunks_per_launch, front_ms_avg, rec_ms_avg, B, T, precision):
+    """Dominant kernel = the frontend (STFT + encoder + W_ih).  achieved = matrix flops the kernel EXECUTES per
+    launch / its average launch duration, peak = the dense peak of the pipe it runs on (fp32 MFMA 157.3 TF, or
+    the f16 peak for the opt-in f16x3 kernels): frac <= 1.  The reference's dense flop count for the same part of
+    the path ("useful work") is reported separately and is never divided into `frac`.  traffic = HBM bytes per
+    launch of this kernel from the committed PMC pass; `path` relates the whole path (both kernels) to the
+    algorithmic bytes of SURVEY 8(d)."""
     w = WORK[sr]
     split = precision == "f16x3"
     s = front_ms_avg / 1e3
-    dense = chunks_per_launch * w["front_dense"] / s / 1e12
     ex_flop = w["front_split_mfma"] if split else w["front_mfma"]
     ex_peak = PEAK_F16_TFLOPS if split else PEAK_F32_TFLOPS
     execd = chunks_per_launch * ex_flop / s / 1e12
     kname = w["front_split_kernel"] if split else w["front_kernel"]
-    tr = pmc_traffic(kname.split(",")[0], sr, B, T)
-    io_bytes = chunks_per_launch * (w["chunk"] * 4 + 2048)
-    hbm = io_bytes / s / 1e9
-    return {"bound": "mfma", "kernel": kname,
-            "achieved": round(dense, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(dense / PEAK_F32_TFLOPS, 4),
-            "note": "achieved/frac use the reference's DENSE flop count (SURVEY 8d) against the fp32 peak; the "
-                    "kernel replaces the DFT-basis conv by an rFFT, skips zero-pad taps and (f16x3) runs "
-                    "each product as 3 f16 MFMA products, so frac can exceed 1 -- mfma_executed is the "
-                    "matrix-pipe utilisation, hbm the same launch against the HBM roofline",
-            "flop_per_launch": chunks_per_launch * w["front_dense"],
-            "mfma_executed": {"flop_per_launch": chunks_per_launch * ex_flop, "dtype": "f16" if split else "f32",
-                              "achieved": round(execd, 3), "peak": ex_peak, "frac": round(execd / ex_peak, 4)},
-            "hbm": {"bytes_per_launch": io_bytes, "achieved": round(hbm, 1), "peak": PEAK_HBM_GBPS,
-                    "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBPS, 4)},
-            "avg_launch_ms": round(front_ms_avg, 4),
-            "traffic": tr["bytes"] if tr else None, "traffic_detail": tr}
+    rname = "rec_split_kernel" if split else "rec_kernel"
+    tr_f = pmc_traffic(kname.split(",")[0], sr, B, T)
+    tr_r = pmc_traffic(rname, sr, B, T)
+    alg = chunks_per_launch * w["bytes"]
+    kio = chunks_per_launch * (w["chunk"] * 4 + GX_BYTES)
+    path_traffic = (tr_f["bytes"] + tr_r["bytes"]) if (tr_f and tr_r) else None
+    out = {"bound": "mfma", "kernel": kname, "dtype": "f16" if split else "f32",
+           "achieved": round(execd, 3), "peak": ex_peak, "unit": "TFLOP/s", "frac": round(execd / ex_peak, 4),
+           "flop_per_launch": chunks_per_launch * ex_flop, "avg_launch_ms": round(front_ms_avg, 4),
+           "definition": "executed MFMA flops of the dominant kernel per launch / its hipEvent launch duration, "
+                         "against the dense peak of the matrix pipe it runs on",
+           "traffic": tr_f["bytes"] if tr_f else None, "traffic_detail": tr_f,
+           "kernel_io_bytes": kio,
+           "useful_dense": {"flop_per_launch": chunks_per_launch * w["front_dense"],
+                            "tflops": round(chunks_per_launch * w["front_dense"] / s / 1e12, 3),
+                            "note": "the reference's dense flop count for this part of the path (DFT-basis conv, every "
+                                    "tap); the kernel executes fewer -- not a utilisation figure"},
+           "hbm": {"achieved": round(kio / s / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                   "frac": round(kio / s / 1e9 / PEAK_HBM_GBPS, 4),
+                   "note": "this kernel's own I/O (PCM in + gx out) against the HBM roofline: far from binding"},
+           "path": {"algorithmic_bytes": alg, "algorithmic_bytes_per_chunk": w["bytes"],
+                    "traffic": path_traffic,
+                    "traffic_over_algorithmic": round(path_traffic / alg, 3) if path_traffic else None,
+                    "traffic_detail": {"front": tr_f, "rec": tr_r},
+                    "mfma_flop_per_chunk": ex_flop + w["rec_mfma"] * (3 if split else 1)}}
+    if rec_ms_avg:
+        rs = rec_ms_avg / 1e3
+        rflop = chunks_per_launch * w["rec_mfma"] * (3 if split else 1)
+        out["rec_kernel"] = {"kernel": rname, "avg_launch_ms": round(rec_ms_avg, 4),
+                             "mfma_frac": round(rflop / rs / 1e12 / ex_peak, 4),
+                             "gx_read_GBps": round(chunks_per_launch * GX_BYTES / rs / 1e9, 1),
+                             "hbm_frac": round(chunks_per_launch * GX_BYTES / rs / 1e9 / PEAK_HBM_GBPS, 4)}
+    return out
 
 
-def base_line(args, world, metric_sr, value, elapsed, steps):
+def base_line(args, world, metric_sr, value, elapsed, steps, precision):
     return {"metric": f"audio-chunks/sec (32 ms @ {metric_sr // 1000} kHz)", "value": round(value, 1),
             "unit": "chunks/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 sums of f16x3 split products",
-            "precision": args.precision, "data": "synthetic"}
+            "vs_baseline": None,
+            "dtype": "f32" if precision == "fp32" else "f16x3 (NOT fp32: 3-term fp16 split products, fp32 sums)",
+            "precision": precision, "data": "synthetic"}
 
 
 # ---- c2 / 8k: HBM-resident batch ------------------------------------------------------------------------
-def run_batch(args, sr, rank, world, local, dist):
+def time_batch(eng, precision, step, probs, world, dist, dev, steps, warmup):
+    """One arithmetic on one workload: clock ramp, warm-up, `steps` timed calls with the engine's hipEvents on."""
+    import torch
+    eng.set_precision(precision)
+    # the GPU takes some tens of milliseconds of load to reach its sustained clocks (measured: +4 % between the
+    # 4th and the 40th step): a fixed untimed ramp precedes the W warm-up steps so that K steps time steady state
+    for _ in range(max(0, CLOCK_RAMP_STEPS - warmup)):
+        step()
+    for _ in range(warmup):
+        step()
+    eng.set_option("profile", "1")
+    elapsed = timed(world, dist, dev, steps, step, gpu_sync)
+    front_ms, rec_ms, calls = eng.kernel_times()
+    eng.set_option("profile", "0")
+    ok = bool(torch.isfinite(probs).all().item())
+    c = max(calls, 1)
+    return elapsed, front_ms / c, rec_ms / c, ok
+
+
+def run_batch(args, sr, rank, world, local, dist, steps, with_other):
+    import torch
     from silero_vad_amd import Engine
     dev = torch.device("cuda", local)
     eng = Engine(device=local)
-    eng.set_precision(args.precision)
     n = WORK[sr]["chunk"]
     B, T = args.streams, args.chunks
     pcm = synth_pcm(B, T * n, sr, dev, 17 + sr + rank)
@@ -216,37 +277,24 @@ def run_batch(args, sr, rank, world, local, dist):
         state.zero_()
         eng.forward_audio(pcm, sr, ctx, state, probs)
 
-    # the GPU takes some tens of milliseconds of load to reach its sustained clocks (measured: +4 % between the
-    # 4th and the 40th step): a fixed untimed ramp precedes the W warm-up steps so that K steps time steady state
-    for _ in range(max(0, CLOCK_RAMP_STEPS - args.warmup)):
-        step()
-    for _ in range(args.warmup):
-        step()
-    eng.set_option("profile", "1")
-    elapsed = timed(world, dist, dev, args.steps, step)
-    front_ms, rec_ms, calls = eng.kernel_times()
-    eng.set_option("profile", "0")
-    ok = bool(torch.isfinite(probs).all().item())
+    elapsed, front_ms, rec_ms, ok = time_batch(eng, args.precision, step, probs, world, dist, dev, steps, args.warmup)
     other = None
-    if world == 1:                                     # the other arithmetic, same workload, for the record
+    if with_other and world == 1:                      # the other arithmetic, same data, same protocol, for the record
         alt = "fp32" if args.precision == "f16x3" else "f16x3"
         p_main = probs.clone()
-        eng.set_precision(alt)
-        for _ in range(2):
-            step()
-        eng.set_option("profile", "1")
-        e2 = timed(world, dist, dev, max(3, args.steps // 2), step)
-        f2, r2, c2 = eng.kernel_times()
-        eng.set_option("profile", "0")
-        other = {"precision": alt, "value": round(B * T * max(3, args.steps // 2) / e2, 1), "unit": "chunks/s",
-                 "kernel_ms": {"front": round(f2 / max(c2, 1), 4), "rec": round(r2 / max(c2, 1), 4)},
-                 "max_abs_prob_diff_vs_main": float((probs - p_main).abs().max().item())}
+        e2, f2, r2, ok2 = time_batch(eng, alt, step, probs, world, dist, dev, steps, args.warmup)
+        other = {"precision": alt, "dtype": base_line(args, 1, sr, 0, 1, 1, alt)["dtype"],
+                 "value": round(B * T * steps / e2, 1), "unit": "chunks/s", "steps": steps,
+                 "ms_per_step": round(e2 / steps * 1e3, 4), "kernel_ms": {"front": round(f2, 4), "rec": round(r2, 4)},
+                 "outputs_finite": ok2,
+                 "max_abs_prob_diff_vs_main": float((probs - p_main).abs().max().item()),
+                 "roofline": roofline(sr, B * T, f2, r2, B, T, alt)}
         eng.set_precision(args.precision)
     if rank != 0:
         return None
     w = WORK[sr]
-    value = B * T * world * args.steps / elapsed
-    out = base_line(args, world, sr, value, elapsed, args.steps)
+    value = B * T * world * steps / elapsed
+    out = base_line(args, world, sr, value, elapsed, steps, args.precision)
     cfg = "configs[1]" if sr == 16000 else "configs[2]"
     out["config"] = {"workload": f"{cfg}: synthetic {sr // 1000} kHz PCM resident in HBM, {n}-sample chunks, "
                                  f"{B} streams/GPU x {T} chunks/stream per step, zero initial state",
@@ -255,22 +303,21 @@ def run_batch(args, sr, rank, world, local, dist):
     out["realtime_factor"] = round(value * 0.032, 1)
     out["outputs_finite"] = ok
     out["clock_ramp_steps"] = max(0, CLOCK_RAMP_STEPS - args.warmup)
-    out["path_fraction"] = {"fp32_peak": round(value / world * w["flop"] / (PEAK_F32_TFLOPS * 1e12), 4),
-                            "hbm_peak": round(value / world * w["bytes"] / (PEAK_HBM_GBPS * 1e9), 6),
-                            "flop_per_chunk": w["flop"], "bytes_per_chunk": w["bytes"]}
-    c = max(calls, 1)
-    out["kernel_ms"] = {"front": round(front_ms / c, 4), "rec": round(rec_ms / c, 4)}
-    out["roofline"] = roofline(sr, B * T, front_ms / c, B, T, args.precision)
-    rs = rec_ms / c / 1e3
-    out["rec_kernel"] = {"gx_read_GBps": round(B * T * 2048 / rs / 1e9, 1),
-                         "hbm_frac": round(B * T * 2048 / rs / 1e9 / PEAK_HBM_GBPS, 4)}
+    out["timed_region_s"] = round(elapsed, 4)
+    out["path_fraction"] = {"dense_flop_vs_fp32_peak": round(value / world * w["flop"] / (PEAK_F32_TFLOPS * 1e12), 4),
+                            "algorithmic_bytes_vs_hbm_peak": round(value / world * w["bytes"] / (PEAK_HBM_GBPS * 1e9), 6),
+                            "flop_per_chunk": w["flop"], "bytes_per_chunk": w["bytes"],
+                            "note": "useful reference work (dense flops, SURVEY 8d) per second per GPU; informational"}
+    out["kernel_ms"] = {"front": round(front_ms, 4), "rec": round(rec_ms, 4)}
+    out["roofline"] = roofline(sr, B * T, front_ms, rec_ms, B, T, args.precision)
     if other:
         out["other_precision"] = other
     return out
 
 
 # ---- stream: live streams, hipGraph step -------------------------------------------------------------------
-def run_stream(args, rank, world, local, dist):
+def run_stream(args, rank, world, local, dist, steps):
+    import torch
     from silero_vad_amd import Engine, StreamPool
     sr = 16000
     dev = torch.device("cuda", local)
@@ -290,10 +337,9 @@ def run_stream(args, rank, world, local, dist):
         pool.tick_staged()
         k[0] += 1
 
-    for _ in range(max(args.warmup, 3) + 1500):                # + DVFS ramp (~130 ms of ticks), see run_batch
+    for _ in range(max(args.warmup, 3) + 1500):                # + DVFS ramp (~130 ms of ticks), see time_batch
         tick()
-    steps = args.steps
-    elapsed = timed(world, dist, dev, steps, tick)
+    elapsed = timed(world, dist, dev, steps, tick, gpu_sync)
     # latency of one tick, host-visible: input staged -> probabilities readable
     lat = []
     for _ in range(50):
@@ -312,7 +358,7 @@ def run_stream(args, rank, world, local, dist):
     if rank != 0:
         return None
     value = cap * world * steps / elapsed
-    out = base_line(args, world, sr, value, elapsed, steps)
+    out = base_line(args, world, sr, value, elapsed, steps, args.precision)
     out["config"] = {"workload": f"configs[4]: {cap} live 16 kHz streams/GPU ({cap * 8} per 8-GPU node), one "
                                  f"hipGraph-captured vad_step per 32 ms tick, (h,c)+context persistent in HBM",
                      "streams_per_gpu": cap, "sample_rate": sr, "step": "one tick (one chunk per stream)",
@@ -323,14 +369,16 @@ def run_stream(args, rank, world, local, dist):
                               "budget_ms": 32.0}
     c = max(calls, 1)
     out["kernel_ms"] = {"front": round(front_ms / c, 4), "rec": round(rec_ms / c, 4)}
-    out["roofline"] = roofline(sr, cap, front_ms / c, cap, 1, args.precision)
+    out["roofline"] = roofline(sr, cap, front_ms / c, rec_ms / c, cap, 1, args.precision)
     return out
 
 
 # ---- corpus: ragged recordings from host memory -------------------------------------------------------------
-def run_corpus(args, rank, world, local, dist):
+def run_corpus(args, rank, world, local, dist, steps):
     import numpy as np
+    import torch
     from silero_vad_amd import load_silero_vad, ragged_speech_segments
+    from silero_vad_amd import streams as S
     sr = 16000
     dev = torch.device("cuda", local)
     model = load_silero_vad(device=local, precision=args.precision)
@@ -340,35 +388,79 @@ def run_corpus(args, rank, world, local, dist):
     tt = np.arange(base_len, dtype=np.float32) / sr
     base = (0.03 * rng.standard_normal(base_len).astype(np.float32)
             + 0.2 * np.sin(2 * np.pi * 170.0 * tt) * (np.sin(2 * np.pi * 0.7 * tt) > 0))
-    base = torch.from_numpy((base * 32767.0).clip(-32768, 32767).astype(np.int16))
+    base_f = torch.from_numpy(base.astype(np.float32))
+    base_i = torch.from_numpy((base * 32767.0).clip(-32768, 32767).astype(np.int16))
     R = args.recordings
     lens = rng.integers(20 * sr, 40 * sr, size=R)              # 20-40 s recordings, ragged
     offs = rng.integers(0, base_len - 40 * sr, size=R)
-    audios = [base[o:o + m] for o, m in zip(offs, lens)]       # views: the "files" already decoded in RAM
     chunks = int(sum((m + n - 1) // n for m in lens))
-    nseg = [0]
+    hours = float(lens.sum()) / sr / 3600.0
+    legs = {}
+    for name, src in (("int16", base_i), ("fp32", base_f)):
+        audios = [src[o:o + m] for o, m in zip(offs, lens)]    # views: the "files" already decoded in RAM
+        nseg = [0]
+        S.STATS.clear()
 
-    def step():
-        segs = ragged_speech_segments(audios, model, sr, max_waste=0.1, max_bytes=256 << 20)
-        nseg[0] = sum(len(s) for s in segs)
+        def step():
+            segs = ragged_speech_segments(audios, model, sr, max_waste=0.1, max_bytes=256 << 20)
+            nseg[0] = sum(len(s) for s in segs)
 
-    for _ in range(max(1, min(args.warmup, 1))):
-        step()
-    steps = max(1, min(args.steps, 3))
-    elapsed = timed(world, dist, dev, steps, step)
+        step()                                                  # warm-up: pinned buffers, scratch
+        S.STATS.clear()
+        elapsed = timed(world, dist, dev, steps, step, gpu_sync)
+        st = dict(S.STATS)
+        bytes_in = float(lens.sum()) * (2 if name == "int16" else 4) * steps
+        legs[name] = {"value": round(chunks * world * steps / elapsed, 1), "unit": "chunks/s", "steps": steps,
+                      "s_per_step": round(elapsed / steps, 4), "segments_found_rank0": nseg[0],
+                      "ingest_GBps_per_gpu": round(bytes_in / elapsed / 1e9, 2),
+                      "h2d_GBps_while_copying": round(st.get("h2d_bytes", 0) / max(st.get("h2d_s", 0), 1e-9) / 1e9, 2),
+                      "host_stage_ms_per_step": round(st.get("stage_s", 0) / steps * 1e3, 2),
+                      "host_segmenter_ms_per_step": round(st.get("scan_s", 0) / steps * 1e3, 2),
+                      "buckets_per_step": int(st.get("buckets", 0) / steps),
+                      "padded_over_real_samples": round(st.get("padded", 0) / max(st.get("real", 1), 1), 4),
+                      "projected_10k_hours_s": round(10_000.0 / (hours * world * steps / elapsed), 1)}
     if rank != 0:
         return None
-    value = chunks * world * steps / elapsed
-    hours = float(lens.sum()) / sr / 3600.0
-    out = base_line(args, world, sr, value, elapsed, steps)
-    out["config"] = {"workload": f"configs[3] bounded sample: {R} ragged int16 recordings/GPU (20-40 s, {hours:.2f} h) "
+    main = legs["int16"]
+    out = base_line(args, world, sr, main["value"], main["s_per_step"] * steps, steps, args.precision)
+    out["config"] = {"workload": f"configs[3] bounded sample: {R} ragged recordings/GPU (20-40 s, {hours:.2f} h) "
                                  "in host RAM -> pinned staging -> H2D overlapped with compute -> probs -> "
-                                 "native batch segmenter; PCIe- and host-inclusive",
+                                 "native batch segmenter; PCIe- and host-inclusive; main leg int16 PCM",
                      "recordings_per_gpu": R, "audio_hours_per_gpu_per_step": round(hours, 3), "sample_rate": sr,
                      "sharding": f"recordings x{world}, no collectives"}
-    out["realtime_factor"] = round(value * 0.032, 1)
-    out["segments_found_rank0"] = nseg[0]
-    out["projected_10k_hours_s"] = round(10_000.0 / (hours * world * steps / elapsed), 1)
+    out["realtime_factor"] = round(main["value"] * 0.032, 1)
+    out["legs"] = legs
+    out["projected_10k_hours_s"] = main["projected_10k_hours_s"]
+    return out
+
+
+# ---- dry: the launch / reduce / print plumbing without a GPU (tests/test_sharding.py) -------------------------
+def run_dry(args, rank, world, dist):
+    import torch
+    acc = [0.0]
+
+    def step():
+        acc[0] += float(torch.ones(1000).sum())
+
+    elapsed = timed(world, dist, torch.device("cpu"), args.steps, step, lambda: None)
+    if rank != 0:
+        return None
+    out = base_line(args, world, 16000, 0.0, elapsed, args.steps, args.precision)
+    out.update({"dry": True, "metric": "dry run (no measurement)", "data": "none (dry run of the launch/reduce plumbing; no GPU work, not a measurement)",
+                "config": {"workload": "dry", "sharding": f"streams x{world}, no collectives"}})
+    return out
+
+
+def small(d):
+    """The part of a config's line that is kept when it is nested under other_configs."""
+    if d is None:
+        return None
+    keep = ("value", "unit", "steps", "ms_per_step", "dtype", "kernel_ms", "tick_latency_ms", "legs",
+            "projected_10k_hours_s", "outputs_finite", "realtime_factor", "timed_region_s")
+    out = {k: d[k] for k in keep if k in d}
+    out["workload"] = d["config"]["workload"]
+    if "roofline" in d:
+        out["roofline"] = {k: d["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
     return out
 
 
@@ -378,37 +470,61 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["c2", "8k", "stream", "corpus"], default="c2")
-    ap.add_argument("--precision", choices=["f16x3", "fp32"], default="f16x3",
-                    help="f16x3 (default): fp16x3 split products on the f16 matrix cores, fp32 sums; "
-                         "fp32: exact v_mfma_f32_16x16x4_f32 chain")
+    ap.add_argument("--precision", choices=["fp32", "f16x3"], default="fp32",
+                    help="fp32 (default): exact v_mfma_f32_16x16x4_f32 chain, the reference's arithmetic; "
+                         "f16x3: opt-in fp16x3 split products on the f16 matrix cores (narrower than fp32)")
     ap.add_argument("--streams", type=int, default=STREAMS, help=argparse.SUPPRESS)
     ap.add_argument("--chunks", type=int, default=CHUNKS_PER_STREAM, help=argparse.SUPPRESS)
     ap.add_argument("--live", type=int, default=LIVE_STREAMS, help=argparse.SUPPRESS)
     ap.add_argument("--recordings", type=int, default=1024, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-extras", action="store_true", help="N=1: skip other_precision / other_configs")
+    ap.add_argument("--dry", action="store_true", help="no GPU: exercise launch/barrier/reduce/print only (gloo)")
     args = ap.parse_args()
+    default_steps = {"c2": 200, "8k": 200, "stream": 2000, "corpus": 2}
     if args.steps is None:
-        args.steps = {"c2": 20, "8k": 20, "stream": 200, "corpus": 2}[args.config]
+        args.steps = default_steps[args.config]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_distributed(args)                      # does not return
+
+    # the CPU baseline runs first, in its own CPU-only process, before this process touches the GPU
+    want_cpu = int(os.environ.get("WORLD_SIZE", 1)) == 1 and not args.no_cpu_baseline and not args.dry
+    cpu = cpu_baseline(16000 if args.config != "8k" else 8000) if want_cpu else None
+
+    import torch
     rank, world, local, dist = setup_dist(args)
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.set_device(torch.device("cuda", local))
-
-    if args.config in ("c2", "8k"):
-        sr = 16000 if args.config == "c2" else 8000
-        out = run_batch(args, sr, rank, world, local, dist)
-    elif args.config == "stream":
-        sr, out = 16000, run_stream(args, rank, world, local, dist)
+    if args.dry:
+        out = run_dry(args, rank, world, dist)
     else:
-        sr, out = 16000, run_corpus(args, rank, world, local, dist)
+        import __graft_entry__ as ge
+        if rank == 0:
+            ge.build()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.set_device(torch.device("cuda", local))
+        extras = world == 1 and not args.no_extras
+        if args.config in ("c2", "8k"):
+            sr = 16000 if args.config == "c2" else 8000
+            out = run_batch(args, sr, rank, world, local, dist, args.steps, with_other=extras)
+        elif args.config == "stream":
+            out = run_stream(args, rank, world, local, dist, args.steps)
+        else:
+            out = run_corpus(args, rank, world, local, dist, max(1, min(args.steps, 3)))
+        if extras and args.config == "c2":              # the other BASELINE configs, short, for the record
+            oc = {}
+            for name, fn in (("8k", lambda: run_batch(args, 8000, rank, world, local, dist, 100, with_other=False)),
+                             ("stream", lambda: run_stream(args, rank, world, local, dist, 1000)),
+                             ("corpus", lambda: run_corpus(args, rank, world, local, dist, 1))):
+                try:
+                    oc[name] = small(fn())
+                except Exception as e:                  # an extra must never cost the headline line
+                    oc[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            out["other_configs"] = oc
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sr)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

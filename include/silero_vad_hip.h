@@ -15,9 +15,9 @@
  *     asynchronous with respect to the host unless stated otherwise;
  *   - one engine per GPU; an engine is not thread-safe (the reference model object is not
  *     either: src/silero_vad/utils_vad.py:51-92 mutates _state/_context per call);
- *   - all sums are fp32 and all operands carry >= 22 significant bits (option
- *     "precision" below); sample rates 16000 (chunk N=512, context
- *     C=64) and 8000 (N=256, C=32).
+ *   - the arithmetic is fp32 throughout, as in the reference (the opt-in
+ *     alternative is described under option "precision" below); sample rates 16000 (chunk N=512,
+ *     context C=64) and 8000 (N=256, C=32).
  */
 #ifndef SILERO_VAD_HIP_H
 #define SILERO_VAD_HIP_H
@@ -61,13 +61,17 @@ int  vad_geometry(int sr, int *chunk, int *context);
 /* Options (strings so that bindings need no enum mirror):
  *   "impl"      = "mfma" (default, the product path) | "reference" (slow all-VALU kernels kept
  *                 as an on-device A/B for tests; never the default)
- *   "precision" = "f16x3" (default) | "fp32".  f16x3: every product of the matrix contractions is
- *                 evaluated as a 3-term fp16 split (a_hi b_hi + a_hi b_lo + a_lo b_hi; 22-bit operands)
- *                 on the f16 matrix cores with fp32 accumulation -- the same <= 1e-5 agreement with the
- *                 reference as exact fp32, at 5x the matrix rate.  Its activations must stay below the
- *                 fp16 range (65504): true for |pcm| <= 1 with a 12x margin on every signal tried; a
- *                 stream that leaves the range gets NaN probabilities (never a wrong number) from that
- *                 chunk on and must be rerun with "fp32" (exact v_mfma_f32_16x16x4_f32 chain, no limit).
+ *   "precision" = "fp32" (default) | "f16x3".  fp32: every contraction is an exact
+ *                 v_mfma_f32_16x16x4_f32 chain (bitwise an fmaf chain) -- the reference's arithmetic.
+ *                 f16x3 (OPT-IN, narrower than fp32): every product is evaluated as a 3-term fp16 split
+ *                 (a_hi b_hi + a_hi b_lo + a_lo b_hi, x_hi = fp16(x), x_lo = fp16(x - x_hi)) on the f16
+ *                 matrix cores with fp32 accumulation.  An operand keeps max(2^-22 |x|, 2^-25) absolute
+ *                 accuracy: 22 significant bits for |x| >= 2^-3, fewer below (x_lo falls into the fp16
+ *                 subnormals), so this is an absolute-error approximation, NOT fp32-equivalent; measured
+ *                 |dp| <= 1.2e-5 against the reference on the fixtures.  Its activations must stay below
+ *                 the fp16 range (65504): a stream that leaves it gets NaN probabilities from that chunk
+ *                 on and must be rerun with "fp32".  It also requires a single-tenant GPU: see DESIGN.md
+ *                 section 4.2b (packed-fp32 VALU in a co-resident wave corrupts f16 MFMA results).
  *   "gx_cap_mib"= cap, in MiB, of the engine's scratch for the LSTM input-gate pre-activations (default 6144);
  *                 a call whose B x T needs more is processed in time slabs, transparently
  *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)
@@ -108,6 +112,12 @@ int  vad_forward_audio_i16(vad_engine *e, int sr, int B, long L, const int16_t *
  * before capturing vad_step/vad_forward_audio into a hipGraph).  Synchronous.                    */
 int  vad_reserve(vad_engine *e, int sr, int B, long T);
 size_t vad_scratch_bytes(const vad_engine *e);
+/* The engine's scratch only ever grows; when a later call (or vad_reserve) needs more than it has, the
+ * buffers are freed and reallocated (synchronously, and never while a stream is being captured:
+ * VAD_ERR_CAPTURE).  A hipGraph that captured vad_step / vad_forward_audio holds the OLD device addresses,
+ * so it MUST be re-captured after such a growth: this counter changes exactly when that happened.
+ * (silero_vad_amd/streams.py StreamPool checks it before every replay.)                               */
+unsigned long vad_scratch_generation(const vad_engine *e);
 
 /* With option profile=1 the engine brackets its kernels with hipEvents on the caller's stream
  * (no host synchronisation at record time).  This call waits for them and returns the GPU time in

@@ -1,0 +1,210 @@
+"""The reference's arithmetic on the reference's own CPU kernels -- TEST INFRASTRUCTURE / CPU BASELINE ONLY.
+
+The reference model is a TorchScript archive (src/silero_vad/data/silero_vad.jit) that cannot travel to
+the GPU box; what it executes, though, is a handful of ATen CPU operators.  This module issues exactly
+those operators, in the same order, from the weights container the engine loads:
+
+    torch.nn.functional.pad(reflect)      JIT!/torch/nn/modules/padding/___torch_mangle_8.py:6,10
+    torch.conv1d(basis, stride = hop)     JIT!/vad/utils/pytorch_stft.py:17-34   (+ sqrt(re^2 + im^2))
+    4 x relu(torch.conv1d(k=3, pad=1))    JIT!/vad/utils/model_utils.py:19-25
+    torch.lstm_cell                       JIT!/torch/nn/modules/rnn.py:69
+    relu -> conv1d(128, 1, 1) -> sigmoid  JIT!/torch/nn/modules/container/___torch_mangle_7.py:10-19
+
+so `AtenVAD` (a) is a second, independent checker next to the plain-C oracle (pinned to the same goldens
+in tests/test_oracle.py: bit-level agreement with the JIT is expected, it IS the same kernels), and (b) is
+what bench.py times as `cpu_baseline` (kind "aten-port"): the reference's CPU path on this box's host cores
+under the reference's own threading rules (src/silero_vad/model.py:3 `torch.set_num_threads(1)`) and timing
+protocol (examples/onnx_sequence/run.py:172-194: warm-up, then the median of 5 trials).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+    python -m oracle.aten_port --sr 16000 [--budget-s 25]     prints one JSON object (protocols R1..R4)
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.nn.functional as F
+
+HERE = Path(__file__).resolve().parent
+WEIGHTS = HERE.parent / "silero_vad_amd" / "data" / "silero_vad_v6.weights"
+
+
+def _tensors(prefix, blob=None):
+    from .weights import read_container
+    d = read_container(blob if blob is not None else WEIGHTS.read_bytes())
+    return {k[len(prefix) + 1:]: torch.from_numpy(v.copy()) for k, v in d.items() if k.startswith(prefix + ".")}
+
+
+class AtenNet:
+    """One sample rate's network: forward(x1[B, C+N], state[2, B, 128]) -> (prob[B, 1], state')."""
+
+    def __init__(self, sr, blob=None):
+        w = _tensors("_model" if sr == 16000 else "_model_8k", blob)
+        self.basis = w["stft.forward_basis_buffer"]
+        self.F = self.basis.shape[-1]
+        self.hop = self.F // 2
+        self.K = self.basis.shape[0] // 2
+        self.enc = [(w[f"encoder.{i}.reparam_conv.weight"], w[f"encoder.{i}.reparam_conv.bias"], s)
+                    for i, s in enumerate((1, 2, 2, 1))]
+        self.w_ih, self.w_hh = w["decoder.rnn.weight_ih"], w["decoder.rnn.weight_hh"]
+        self.b_ih, self.b_hh = w["decoder.rnn.bias_ih"], w["decoder.rnn.bias_hh"]
+        self.w_out, self.b_out = w["decoder.decoder.2.weight"], w["decoder.decoder.2.bias"]
+
+    @torch.no_grad()
+    def forward(self, x1, state):
+        x = F.pad(x1.unsqueeze(1), (0, self.F // 4), mode="reflect")
+        y = torch.conv1d(x, self.basis, stride=self.hop)
+        re, im = y[:, :self.K], y[:, self.K:]
+        x = torch.sqrt(re * re + im * im)
+        for w, b, s in self.enc:
+            x = torch.relu(torch.conv1d(x, w, b, stride=s, padding=1))
+        x = x.squeeze(-1)
+        if state.numel() == 0:
+            state = torch.zeros((2, x.shape[0], 128))
+        h, c = torch.lstm_cell(x, (state[0], state[1]), self.w_ih, self.w_hh, self.b_ih, self.b_hh)
+        out = torch.sigmoid(torch.conv1d(torch.relu(h).unsqueeze(-1), self.w_out, self.b_out))
+        return out.mean(dim=2), torch.stack([h, c])
+
+
+class AtenVAD:
+    """The reference model protocol (JIT!/vad/model/vad_annotator.py:14-162) over AtenNet."""
+    sample_rates = [8000, 16000]
+
+    def __init__(self, blob=None):
+        self.nets = {16000: AtenNet(16000, blob), 8000: AtenNet(8000, blob)}
+        self.reset_states()
+
+    def reset_states(self, batch_size=1):
+        self._state = torch.zeros(0)
+        self._context = torch.zeros(0)
+        self._last_sr = 0
+        self._last_batch_size = 0
+
+    @torch.no_grad()
+    def __call__(self, x, sr):
+        x = torch.as_tensor(x, dtype=torch.float32)
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        if sr != 16000 and sr % 16000 == 0:
+            x = x[:, ::sr // 16000]
+            sr = 16000
+        n = 512 if sr == 16000 else 256
+        if x.shape[-1] != n:
+            raise ValueError(f"Provided number of samples is {x.shape[-1]} (Supported values: 256 for 8000 "
+                             f"sample rate, 512 for 16000)")
+        B = x.shape[0]
+        if (self._last_sr and self._last_sr != sr) or (self._last_batch_size and self._last_batch_size != B):
+            self.reset_states()
+        if not len(self._context):
+            self._context = torch.zeros((B, n // 8))
+        x1 = torch.cat([self._context, x], dim=1)
+        out, self._state = self.nets[sr].forward(x1, self._state)
+        self._context = x1[:, -(n // 8):]
+        self._last_sr, self._last_batch_size = sr, B
+        return out
+
+    @torch.no_grad()
+    def audio_forward(self, x, sr):
+        x = torch.as_tensor(x, dtype=torch.float32)
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        if sr != 16000 and sr % 16000 == 0:
+            x = x[:, ::sr // 16000]
+            sr = 16000
+        n = 512 if sr == 16000 else 256
+        self.reset_states()
+        if x.shape[1] % n:
+            x = F.pad(x, (0, n - x.shape[1] % n))
+        outs = [self(x[:, i:i + n], sr) for i in range(0, x.shape[1], n)]
+        return torch.cat(outs, dim=1)
+
+
+# ---- the CPU baseline bench.py reports ---------------------------------------------------------------------
+def _timed_forward(model, pcm, sr, warmup, trials):
+    """examples/onnx_sequence/run.py:172-194: warm-up runs, then `trials` timed runs; returns the median seconds."""
+    for _ in range(warmup):
+        model.audio_forward(pcm, sr)
+    ts = []
+    for _ in range(trials):
+        t0 = time.perf_counter()
+        model.audio_forward(pcm, sr)
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts)
+
+
+def _synth(B, T, sr, seed):
+    n = 512 if sr == 16000 else 256
+    g = torch.Generator().manual_seed(seed)
+    return 0.03 * torch.randn((B, T * n), generator=g)            # run.py:159-162
+
+
+def _worker(args):
+    sr, B, T, warmup, trials, seed = args
+    torch.set_num_threads(1)
+    m = AtenVAD()
+    dt = _timed_forward(m, _synth(B, T, sr, seed), sr, warmup, trials)
+    return B * T / dt
+
+
+def baseline(sr=16000, budget_s=25.0, trials=5, warmup=3):
+    """R1..R4 of BASELINE.md section 3 / SURVEY.md section 8(d) "CPU baseline beside it"."""
+    nproc = len(os.sched_getaffinity(0))
+    out = {"nproc": nproc, "torch": torch.__version__, "trials": trials, "warmup": warmup,
+           "protocol": "examples/onnx_sequence/run.py:172-194 (median of trials after warm-up); "
+                       "audio_forward = T sequential forward() calls, vad_annotator.py:128-156"}
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        out["cpu_model"] = cpu[0] if cpu else "unknown"
+    except OSError:
+        out["cpu_model"] = "unknown"
+    share = budget_s / 4.0 / (warmup + trials)                     # seconds per run and protocol
+    m = AtenVAD()
+    res = {}
+
+    def sized(B, rate_guess):
+        return max(2, min(256, int(rate_guess * share / B)))
+
+    # R1: 1 thread, B = 1 (the reference's shipped default, model.py:3)
+    torch.set_num_threads(1)
+    T = sized(1, 2000.0)
+    res["R1_1thread_B1"] = {"chunks_per_s": round(T / _timed_forward(m, _synth(1, T, sr, 1), sr, warmup, trials), 1),
+                            "B": 1, "T": T, "threads": 1}
+    # R2: 1 thread, B = 4096
+    T = sized(4096, 30000.0)
+    res["R2_1thread_B4096"] = {"chunks_per_s": round(4096 * T / _timed_forward(m, _synth(4096, T, sr, 2), sr, warmup, trials), 1),
+                               "B": 4096, "T": T, "threads": 1}
+    # R3: nproc threads, B = 4096
+    torch.set_num_threads(nproc)
+    T = sized(4096, 30000.0 * min(nproc, 16))
+    res["R3_nproc_threads_B4096"] = {"chunks_per_s": round(4096 * T / _timed_forward(m, _synth(4096, T, sr, 3), sr, warmup, trials), 1),
+                                     "B": 4096, "T": T, "threads": nproc}
+    torch.set_num_threads(1)
+    # R4: nproc processes x 1 thread, one model each (examples/parallel_example.ipynb cells 5, 7); every worker
+    # owns a slice of the same 4096 streams (at least 1).  fork: this process never touched a GPU runtime.
+    import multiprocessing as mp
+    Bp = max(1, 4096 // nproc)
+    T = sized(Bp, 2000.0 * min(Bp, 16))
+    with mp.get_context("fork").Pool(nproc) as pool:
+        rates = pool.map(_worker, [(sr, Bp, T, warmup, trials, 100 + i) for i in range(nproc)])
+    res["R4_nproc_procs_1thread"] = {"chunks_per_s": round(sum(rates), 1), "B_per_proc": Bp, "T": T,
+                                     "procs": nproc, "threads": 1}
+    out["runs"] = res
+    best = max(res, key=lambda k: res[k]["chunks_per_s"])
+    out["best"] = best
+    out["value"] = res[best]["chunks_per_s"]
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sr", type=int, default=16000)
+    ap.add_argument("--budget-s", type=float, default=25.0)
+    a = ap.parse_args()
+    sys.path.insert(0, str(HERE.parent))
+    print(json.dumps(baseline(a.sr, a.budget_s)))

@@ -47,6 +47,7 @@ SYMBOLS = {
                                       c_void_p, c_void_p, c_long, c_void_p]),
     "vad_reserve": (c_int, [c_void_p, c_int, c_int, c_long]),
     "vad_scratch_bytes": (c_size_t, [c_void_p]),
+    "vad_scratch_generation": (ctypes.c_ulong, [c_void_p]),
     "vad_kernel_times": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_long)]),
     "vad_segment_params_default": (None, [POINTER(SegmentParams), c_int]),
     "vad_segment_probs": (c_long, [f32p, c_long, c_long, POINTER(SegmentParams), POINTER(Segment), c_long]),

@@ -20,8 +20,8 @@ struct vad_engine {
     int device = -1;
     std::string err;
     bool impl_reference = false;
-    bool split = true;                              // precision: fp16x3 split MFMA (default) | exact fp32 MFMA
-    bool split_rec = true;                          // (bring-up: the two kernels can be chosen separately)
+    bool split = false;                             // precision: exact fp32 MFMA (default) | fp16x3 split MFMA (opt-in)
+    bool split_rec = false;                         // (bring-up: the two kernels can be chosen separately)
     bool profile = false;
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
 
@@ -42,6 +42,8 @@ struct vad_engine {
     size_t realign_bytes = 0;
     void *d_decim = nullptr;                        // 16 kHz copy of a 32/48/... kHz input
     size_t decim_bytes = 0;
+    unsigned long scratch_gen = 0;                  // bumped whenever a scratch buffer is reallocated: a hipGraph that
+                                                    // captured calls of this engine holds the OLD addresses (vad_scratch_generation)
     long slab_steps = 0;                            // time steps per gx slab for the last reserve
     size_t gx_cap = 6ull << 30;                     // cap of the gx scratch; longer inputs are slabbed (option gx_cap_mib)
 
@@ -86,6 +88,7 @@ int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
         if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
             return fail(e, VAD_ERR_CAPTURE, "scratch must grow during stream capture; call vad_reserve first");
         HIP_TRY(e, hipDeviceSynchronize());
+        e->scratch_gen++;
         if (need_gx > e->gx_floats) {
             if (e->d_gx) (void)hipFree(e->d_gx);
             e->d_gx = nullptr;
@@ -136,6 +139,7 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
             if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
                 return fail(e, VAD_ERR_CAPTURE, "decimation scratch must grow during stream capture");
             HIP_TRY(e, hipDeviceSynchronize());
+            e->scratch_gen++;
             if (e->d_decim) (void)hipFree(e->d_decim);
             e->d_decim = nullptr;
             e->decim_bytes = 0;
@@ -176,6 +180,7 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
             if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
                 return fail(e, VAD_ERR_CAPTURE, "misaligned input needs scratch during capture");
             HIP_TRY(e, hipDeviceSynchronize());
+            e->scratch_gen++;
             if (e->d_realign) (void)hipFree(e->d_realign);
             e->d_realign = nullptr;
             e->realign_bytes = 0;
@@ -424,6 +429,8 @@ int vad_reserve(vad_engine *e, int sr, int B, long T) {
     HIP_TRY(e, hipSetDevice(e->device));
     return ensure_scratch(e, sr, B, T, nullptr);
 }
+
+unsigned long vad_scratch_generation(const vad_engine *e) { return e ? e->scratch_gen : 0; }
 
 size_t vad_scratch_bytes(const vad_engine *e) {
     return e ? (e->gx_floats + e->ctx_floats) * sizeof(float) : 0;

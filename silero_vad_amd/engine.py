@@ -14,6 +14,7 @@ done by the gfx950 kernels behind the C ABI (include/silero_vad_hip.h); PyTorch 
 device memory and streams.  There is no CPU fallback: constructing the model without a usable
 GPU raises.
 """
+import contextlib
 import ctypes
 import os
 
@@ -46,7 +47,7 @@ class Engine:
         impl = os.environ.get("SILERO_VAD_AMD_IMPL")
         if impl:
             self.set_option("impl", impl)
-        self.precision = "f16x3"                     # the engine's default (include/silero_vad_hip.h)
+        self.precision = "fp32"                      # the engine's default (include/silero_vad_hip.h)
         prec = os.environ.get("SILERO_VAD_AMD_PRECISION")
         if prec:
             self.set_precision(prec)
@@ -65,12 +66,17 @@ class Engine:
         check(self._h, lib().vad_set_option(self._h, name.encode(), str(value).encode()))
 
     def set_precision(self, precision):
-        """"f16x3" (fp16 x 3 split products on the f16 matrix cores, fp32 sums) | "fp32" (exact)."""
+        """"fp32" (exact, the default) | "f16x3" (opt-in: fp16 x 3 split products on the f16 matrix
+        cores, fp32 sums; narrower than fp32, see include/silero_vad_hip.h)."""
         self.set_option("precision", precision)
         self.precision = precision
 
     def reserve(self, sr, B, T):
         check(self._h, lib().vad_reserve(self._h, sr, B, T))
+
+    def scratch_generation(self):
+        """Changes whenever the engine reallocated scratch: captured hipGraphs must then be re-captured."""
+        return int(lib().vad_scratch_generation(self._h))
 
     def kernel_times(self):
         """(front_ms, rec_ms, calls): kernel GPU time summed over the calls since the last query."""
@@ -118,19 +124,39 @@ class Engine:
 class HipSileroVAD:
     """Drop-in for the reference's model object (TorchScript `VADRNNJITMerge` / `OnnxWrapper`)."""
 
-    def __init__(self, device=0, engine=None, precision="auto"):
-        """precision: "auto" (default) runs the f16x3 kernels and transparently reruns a call in exact
-        fp32 if it reports an out-of-fp16-range input (NaN probability; include/silero_vad_hip.h,
-        option "precision"); "f16x3" / "fp32" pin one implementation."""
+    def __init__(self, device=0, engine=None, precision="fp32"):
+        """precision: "fp32" (default) = the reference's arithmetic on the exact fp32 matrix kernels.
+        Opt-in: "f16x3" pins the fp16x3 split kernels (narrower than fp32; include/silero_vad_hip.h,
+        option "precision"); "auto" runs f16x3 and transparently reruns a call in fp32 if it reports an
+        out-of-fp16-range input (NaN probability)."""
         if precision not in ("auto", "f16x3", "fp32"):
             raise ValueError("precision must be auto|f16x3|fp32")
         self.engine = engine or Engine(device)
         self.precision = precision
-        if precision != "auto":
+        if engine is None and precision != "auto":
             self.engine.set_precision(precision)
-        self.device = torch.device("cuda", self.engine.device)
+        self.device = getattr(self.engine, "torch_device", None) or torch.device("cuda", self.engine.device)
         self.sample_rates = [8000, 16000]
         self.reset_states()
+
+    def _device_ctx(self):
+        # tests drive the host logic with a stand-in engine on the CPU (tests/replay_engine.py); the product
+        # engine is always a GPU (Engine() raises otherwise)
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
+
+    @contextlib.contextmanager
+    def _selected(self):
+        """An engine may be shared by several wrappers (and by direct users): select this wrapper's kernels
+        for the duration of one call and put the engine back the way it was found."""
+        want = "f16x3" if self.precision == "auto" else self.precision
+        before = self.engine.precision
+        if before != want:
+            self.engine.set_precision(want)
+        try:
+            yield
+        finally:
+            if self.engine.precision != before:
+                self.engine.set_precision(before)
 
     def _guarded(self, run):
         """Run `run()` (which advances self._state / self._context in place and returns probabilities);
@@ -198,7 +224,7 @@ class HipSileroVAD:
             raise ValueError(_MSG_SAMPLES.format(x.shape[-1]))
         batch_size = x.shape[0]
         self._ensure_state(sr, batch_size)
-        with torch.cuda.device(self.device):
+        with self._device_ctx(), self._selected():
             xd = self._to_device(x)
             if xd.dtype == torch.int16:
                 xd = xd.to(torch.float32) / 32768.0
@@ -212,15 +238,19 @@ class HipSileroVAD:
 
     # -- reference: vad_annotator.py:128-156 (returns a CPU tensor, like the reference) ----------------
     def audio_forward(self, x, sr: int):
-        return self.audio_forward_device(x, sr, guarded=True).cpu()
+        return self.audio_forward_device(x, sr).cpu()
 
-    def audio_forward_device(self, x, sr: int, guarded=False):
-        """audio_forward that leaves the probabilities in HBM (no host sync unless `guarded`)."""
+    def audio_forward_device(self, x, sr: int, guarded=None):
+        """audio_forward that leaves the probabilities in HBM.  No host synchronisation -- except in "auto" mode,
+        where the f16x3 range check has to read them back (pass guarded=False to skip the check and handle flagged
+        rows yourself, as the ragged corpus path does)."""
+        if guarded is None:
+            guarded = self.precision == "auto"
         x, sr = self._validate_input(x, sr)
         self.reset_states()
         batch_size = x.shape[0]
         self._ensure_state(sr, batch_size)
-        with torch.cuda.device(self.device):
+        with self._device_ctx(), self._selected():
             xd = self._to_device(x)
             run = lambda: self.engine.forward_audio(xd, sr, self._context, self._state)
             probs = self._guarded(run) if guarded else run()
@@ -229,7 +259,7 @@ class HipSileroVAD:
         return probs
 
 
-def load_silero_vad(onnx=False, opset_version=16, device=0, precision="auto"):
+def load_silero_vad(onnx=False, opset_version=16, device=0, precision="fp32"):
     """Reference signature (src/silero_vad/model.py:6) plus `device` and `precision`.
     `onnx`/`opset_version` are accepted for source compatibility and ignored: there is one backend,
     the HIP engine."""

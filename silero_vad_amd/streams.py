@@ -17,7 +17,9 @@
 * ``BatchVADIterator`` -- the reference's streaming event logic (``VADIterator``,
   src/silero_vad/utils_vad.py:507-549) for all slots of a pool at once, vectorised on the host.
 """
+import collections
 import ctypes
+import time
 from typing import List, Sequence
 
 import numpy as np
@@ -25,6 +27,12 @@ import torch
 
 from . import _lib
 from ._lib import lib
+
+
+# Cumulative counters of the corpus path since the last STATS.clear() (bench.py --config corpus reads them):
+# stage_s host packing into pinned memory, h2d_bytes / h2d_s the H2D copies themselves (hipEvents on the copy
+# stream), scan_s the native segmenter, buckets, padded / real samples staged.
+STATS = collections.defaultdict(float)
 
 
 def chunk_size(sr: int) -> int:
@@ -90,7 +98,15 @@ class _StagePool:
         if self.host[i] is None or self.host[i].numel() < nbytes:
             cap = max(nbytes, 1 << 20)
             self.host[i] = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
-            self.dev[i] = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            # The device buffer is written on self.stream first: allocate it there, so that a block the caching
+            # allocator recycles is ordered after its previous use on that stream, and make self.stream wait for
+            # whatever the consumer stream still has in flight (the block may come from its pool, e.g. the
+            # previous call's probs during their D2H copy).  Consumers call record_stream() on their views.
+            cur = torch.cuda.current_stream(self.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self.dev[i] = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            self.consumed[i] = None
         return i
 
 
@@ -118,7 +134,7 @@ def _stage_into(audios, idxs, width, dtype, dst: torch.Tensor):
 
 
 def _repair_out_of_range(audios, idxs, probs, model, sampling_rate, n):
-    """The default f16x3 kernels answer NaN for a recording whose activations leave the fp16 range
+    """The opt-in f16x3 kernels answer NaN for a recording whose activations leave the fp16 range
     (include/silero_vad_hip.h, option "precision"; |pcm| far above 1).  With the wrapper's "auto" policy such
     rows are recomputed one by one through the guarded `audio_forward`, which falls back to the fp32 kernels."""
     if getattr(model, "precision", None) != "auto":
@@ -157,6 +173,7 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     if pool is None:
         pool = model._stage_pool = _StagePool(dev)
     cur = torch.cuda.current_stream(dev)
+    copies = []                                           # (start event, end event) of every H2D copy, for STATS
 
     def stage(k):
         idxs = plan.buckets[k]
@@ -165,14 +182,23 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         nbytes = len(idxs) * width * esz
         i = pool.get(k, nbytes)
         host = pool.host[i][:nbytes].view(dtype).view(len(idxs), width)
+        t0 = time.perf_counter()
         _stage_into(audios, idxs, width, dtype, host)
+        STATS["stage_s"] += time.perf_counter() - t0
+        STATS["h2d_bytes"] += nbytes
+        STATS["buckets"] += 1
+        STATS["padded"] += len(idxs) * width
+        STATS["real"] += sum(plan.lengths[j] for j in idxs)
         d = pool.dev[i][:nbytes].view(dtype).view(len(idxs), width)
         if pool.consumed[i] is not None:                  # the device buffer's previous reader is done
             pool.stream.wait_event(pool.consumed[i])
         with torch.cuda.stream(pool.stream):
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(pool.stream)
             d.copy_(host, non_blocking=True)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)
             ev.record(pool.stream)
+        copies.append((ev0, ev))
         pool.done[i] = ev
         return d, ev, i
 
@@ -181,7 +207,8 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     for k, idxs in enumerate(plan.buckets):
         x, ev, slot = staged
         cur.wait_event(ev)
-        probs = fast(x, sampling_rate)                    # async: kernels of bucket k
+        x.record_stream(cur)                              # allocated on pool.stream, read on `cur`
+        probs = fast(x, sampling_rate, guarded=False)     # async: kernels of bucket k (flagged rows: _repair_...)
         pool.consumed[slot] = torch.cuda.Event()
         pool.consumed[slot].record(cur)
         out = torch.empty(probs.shape, dtype=torch.float32, pin_memory=True)
@@ -195,6 +222,9 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         prev = (idxs, out, done)
     if prev is not None:
         prev[2].synchronize()
+        for a, b in copies:
+            b.synchronize()
+            STATS["h2d_s"] += a.elapsed_time(b) / 1e3
         yield prev[0], _repair_out_of_range(audios, prev[0], prev[1], model, sampling_rate, n)
 
 
@@ -224,8 +254,10 @@ def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
     out: List[list] = [[] for _ in audios]
     for idxs, probs in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes):
         lens = [lengths[i] for i in idxs]
+        t0 = time.perf_counter()
         segs = segment_probs_batch(probs, [(m + n - 1) // n for m in lens], lens, sampling_rate,
                                    threads=threads, **scan_kw)
+        STATS["scan_s"] += time.perf_counter() - t0
         for row, i in enumerate(idxs):
             out[i] = segs[row]
     return out
@@ -254,25 +286,29 @@ def segment_probs_batch(probs: torch.Tensor, n_chunks, audio_lengths, sampling_r
     if nck.shape != (B,) or alen.shape != (B,):
         raise ValueError("n_chunks and audio_lengths need one entry per row of probs")
     cap = T // 2 + 2
-    segs = np.zeros((B, cap, 2), dtype=np.int64)
-    counts = np.zeros(B, dtype=np.int64)
     lp = ctypes.POINTER(ctypes.c_long)
-    rc = lib().vad_segment_probs_batch(
-        ctypes.cast(probs.data_ptr(), _lib.f32p) if B * T else None, T, B,
-        nck.ctypes.data_as(lp), alen.ctypes.data_as(lp), ctypes.byref(p),
-        ctypes.cast(segs.ctypes.data, ctypes.POINTER(_lib.Segment)), cap, counts.ctypes.data_as(lp),
-        int(threads))
-    if rc < 0:
-        raise ValueError("vad_segment_probs_batch: bad arguments" if rc == -1 else
-                         "Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates")
+    while True:     # counts[] may exceed cap (e.g. min_silence 0 with a small max_speech): grow and rescan
+        segs = np.zeros((B, cap, 2), dtype=np.int64)
+        counts = np.zeros(B, dtype=np.int64)
+        rc = lib().vad_segment_probs_batch(
+            ctypes.cast(probs.data_ptr(), _lib.f32p) if B * T else None, T, B,
+            nck.ctypes.data_as(lp), alen.ctypes.data_as(lp), ctypes.byref(p),
+            ctypes.cast(segs.ctypes.data, ctypes.POINTER(_lib.Segment)), cap, counts.ctypes.data_as(lp),
+            int(threads))
+        if rc < 0:
+            from .timestamps import _raise_scan_error
+            _raise_scan_error(rc)
+        if B == 0 or int(counts.max()) <= cap:
+            break
+        cap = int(counts.max())
     return [[{"start": int(s), "end": int(e)} for s, e in segs[i, : counts[i]]] for i in range(B)]
 
 
 # ---- live streams --------------------------------------------------------------------------------------
-# Live streams: StreamPool drives the engine directly (no host synchronisation per tick), so the wrapper's
-# "auto" fallback does not apply; with the default f16x3 arithmetic a stream whose input leaves the fp16
-# range (|pcm| far above 1) reports NaN from that tick on until it is reset.  Construct the Engine with
-# set_precision("fp32") for inputs that are not normalised.
+# Live streams: StreamPool drives the engine directly (no host synchronisation per tick) with whatever arithmetic
+# the engine is set to -- fp32 by default.  The wrapper's "auto" fallback does not apply here: with the opt-in
+# f16x3 arithmetic a stream whose input leaves the fp16 range (|pcm| far above 1) reports NaN from that tick on
+# until it is reset.
 class StreamPool:
     """`capacity` concurrently live streams on one GPU, one `tick` per 32 ms chunk.
 
@@ -295,6 +331,7 @@ class StreamPool:
         self.open_mask = np.zeros(self.capacity, dtype=bool)
         self._free = list(range(self.capacity - 1, -1, -1))
         self._graph = None
+        self._graph_gen = None
         engine.reserve(self.sr, self.capacity, 1)
         if graph:
             self._capture()
@@ -303,7 +340,13 @@ class StreamPool:
         self.engine.step(self.pcm, self.sr, self.ctx, self.state, self.prob)
 
     def _capture(self):
+        """Capture one step into a hipGraph.  The graph bakes in the engine's scratch addresses, so it is tied to
+        the engine's scratch generation (include/silero_vad_hip.h, vad_scratch_generation) and is captured again,
+        with the carried state preserved, when another user of the same engine made the scratch grow."""
         with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            keep_ctx, keep_state = self.ctx.clone(), self.state.clone()
+            self.engine.reserve(self.sr, self.capacity, 1)
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
@@ -313,9 +356,10 @@ class StreamPool:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._launch()
-            self.ctx.zero_()                               # the warm-up step advanced them
-            self.state.zero_()
+            self.ctx.copy_(keep_ctx)                       # the warm-up step advanced them
+            self.state.copy_(keep_state)
             self._graph = g
+            self._graph_gen = self.engine.scratch_generation()
 
     # -- slots ---------------------------------------------------------------------------------------
     def open(self) -> int:
@@ -351,6 +395,8 @@ class StreamPool:
         """One step over whatever `self.pcm` holds (for callers that write the staging buffer
         themselves, e.g. a device-side audio source)."""
         if self._graph is not None:
+            if self.engine.scratch_generation() != self._graph_gen:
+                self._capture()                            # the engine's scratch moved: the old graph is stale
             self._graph.replay()
         else:
             self._launch()

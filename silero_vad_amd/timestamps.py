@@ -28,7 +28,7 @@ def _speech_probs(audio, model, sampling_rate, window, progress_cb):
         x = audio.unsqueeze(0)
         if n < window:      # the reference pads every chunk to a full window (utils_vad.py:326-327), so a
             x = torch.nn.functional.pad(x, (0, window - n))   # recording shorter than one window is legal here
-        probs = fast(x, sampling_rate)[0].cpu()
+        probs = fast(x, sampling_rate)[0].cpu()          # (a HipSileroVAD in "auto" mode applies its fp32 rerun here)
     else:
         model.reset_states()
         vals = []
@@ -61,13 +61,24 @@ def segment_probs(probs, audio_length_samples, sampling_rate=16000, threshold=0.
     p.min_silence_at_max_speech_ms = int(min_silence_at_max_speech)
     p.use_max_poss_sil_at_max_speech = 1 if use_max_poss_sil_at_max_speech else 0
     n = probs.numel()
-    cap = n // 2 + 2
-    out = (_lib.Segment * cap)()
     ptr = ctypes.cast(probs.data_ptr(), _lib.f32p) if n else None
-    m = lib().vad_segment_probs(ptr, n, int(audio_length_samples), ctypes.byref(p), out, cap)
-    if m < 0:
+    cap = n // 2 + 2
+    while True:     # the scanner reports how many segments it found: a too small buffer is grown and the scan redone
+        out = (_lib.Segment * cap)()
+        m = lib().vad_segment_probs(ptr, n, int(audio_length_samples), ctypes.byref(p), out, cap)
+        if m <= cap:
+            break
+        cap = int(m)
+    _raise_scan_error(m)
+    return [{"start": int(out[i].start), "end": int(out[i].end)} for i in range(m)]
+
+
+def _raise_scan_error(rc):
+    """Negative return codes of the native scanner (csrc/segmenter.cpp)."""
+    if rc == -2:
         raise ValueError("Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates")
-    return [{"start": int(out[i].start), "end": int(out[i].end)} for i in range(min(m, cap))]
+    if rc < 0:
+        raise ValueError(f"native segmenter: bad arguments (code {rc})")
 
 
 @torch.no_grad()
@@ -198,8 +209,8 @@ def _bounds(ts, seconds, sampling_rate):
     if seconds and not sampling_rate:
         raise ValueError('sampling_rate must be provided when seconds is True')
     for seg in ts:
-        if seconds:
-            yield int(seg['start'] * sampling_rate), int(seg['end'] * sampling_rate)
+        if seconds:          # round(), like the reference's _seconds_to_samples_tss (utils_vad.py:648-655)
+            yield round(seg['start'] * sampling_rate), round(seg['end'] * sampling_rate)
         else:
             yield seg['start'], seg['end']
 
@@ -208,7 +219,7 @@ def collect_chunks(tss: List[dict], wav: torch.Tensor, seconds: bool = False,
                    sampling_rate: int = None) -> torch.Tensor:
     """Concatenate the audio inside the given segments (reference: utils_vad.py:552-600)."""
     parts = [wav[a:b] for a, b in _bounds(tss, seconds, sampling_rate)]
-    return torch.cat(parts) if parts else wav[:0]
+    return torch.cat(parts)        # an empty list raises, as in the reference (utils_vad.py:594)
 
 
 def drop_chunks(tss: List[dict], wav: torch.Tensor, seconds: bool = False,

@@ -81,3 +81,33 @@ def test_edge_cases(oracle):
     # a single sample is zero-padded to one chunk
     p, _, _ = oracle.forward_audio(np.full((1, 1), 0.5, np.float32), 16000)
     assert p.shape == (1, 1) and 0 < p[0, 0] < 1
+
+
+# ---- the ATen port (oracle/aten_port.py): the reference's operators issued from the weights container -----
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_aten_port_is_the_reference(golden, tag):
+    """Same ATen kernels in the same order as the TorchScript archive => the goldens recorded from the
+    reference are reproduced to the last ulp-level digit (this is what bench.py times as cpu_baseline)."""
+    import torch
+    from oracle.aten_port import AtenVAD
+    g, sr = golden[tag], SRS[tag]
+    keep = torch.get_num_threads()
+    torch.set_num_threads(1)                                   # the reference's setting (src/silero_vad/model.py:3)
+    try:
+        m = AtenVAD()
+        probs = m.audio_forward(torch.from_numpy(g["wav"]), sr)[0].numpy()
+        assert np.abs(probs - g["probs_wav"]).max() <= 1e-6
+        assert state_err(m._state.numpy(), g["state_wav"]) <= 1e-6
+        assert np.array_equal(m._context.numpy(), g["ctx_wav"])
+        B, T, L, stride = (int(v) for v in g["batch_meta"])
+        rows = np.stack([np.roll(g["wav"], -b * stride)[:L] for b in range(B)])
+        pb = m.audio_forward(torch.from_numpy(rows), sr).numpy()
+        assert pb.shape == (B, T) and np.abs(pb - g["probs_batch"]).max() <= 1e-6
+        assert state_err(m._state.numpy(), g["state_batch"]) <= 1e-5
+        # per-chunk stateful protocol, and agreement with the plain-C oracle's tolerance band
+        n = 512 if sr == 16000 else 256
+        m.reset_states()
+        p = [m(torch.from_numpy(g["wav"][s:s + n]), sr).item() for s in range(0, 40 * n, n)]
+        assert np.abs(np.asarray(p, np.float32) - g["probs_wav"][:40]).max() <= 1e-6
+    finally:
+        torch.set_num_threads(keep)

@@ -81,3 +81,34 @@ def test_world_size_2_gloo_matches_single_process(built):
         p.join(timeout=300)
         assert p.exitcode == 0
     assert got == single
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_multi_gpu_launch_plumbing(launcher):
+    """`bench.py --gpus 2` as the driver may start it -- plain (it re-executes itself under torch.distributed.run)
+    and under an explicit torch.distributed.run -- with --dry: gloo, no GPU, no VAD work; checks rendezvous on
+    127.0.0.1, barrier + MAX-reduce timing, and that exactly one JSON line with n_gpus = 2 comes out of rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    tail = [str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    env = {k: v for k, v in __import__("os").environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["dry"] is True and d["scaling"] == "weak"
