@@ -191,6 +191,11 @@ int  vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, 
  * arithmetic relies on.  Synchronous.                                                           */
 int  vad_debug_mfma_f16(vad_engine *e, const uint16_t *a, const uint16_t *b, float *d);
 
+/* Device: launch a "foreign tenant" on `stream`: `blocks` one-wave workgroups that execute nothing but fp32
+ * VALU FMAs for `iters` rounds (kind 0: packed v_pk_fma_f32, kind 1: scalar v_fma_f32).  The GPU tests run
+ * it beside the engine's kernels to check their results under a co-resident foreign kernel.  Asynchronous. */
+int  vad_debug_foreign_load(vad_engine *e, int kind, int blocks, long iters, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

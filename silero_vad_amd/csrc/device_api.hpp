@@ -66,6 +66,9 @@ hipError_t launch_rec_split(int sr, const RecArgs &a, hipStream_t s);
 // one v_mfma_f32_16x16x32_f16: a, b device [64 lanes][8 halves], d device [64 lanes][4 floats]
 hipError_t launch_mfma_f16_probe(const void *a, const void *b, float *d, hipStream_t s);
 
+// test hook: VALU-only spinner (kind 0 packed fp32, 1 scalar fp32), `blocks` one-wave workgroups
+hipError_t launch_foreign_spin(float *sink, int blocks, long iters, int kind, hipStream_t s);
+
 // gx (fragment order) -> row-major [B][T][512] for vad_debug_frontend
 hipError_t launch_unpack_gx(const float *gx, float *out, int B, long T, hipStream_t s);
 

@@ -497,6 +497,14 @@ int vad_debug_mfma_f16(vad_engine *e, const uint16_t *a, const uint16_t *b, floa
     return VAD_OK;
 }
 
+int vad_debug_foreign_load(vad_engine *e, int kind, int blocks, long iters, void *stream) {
+    if (!e || kind < 0 || kind > 1 || blocks < 0 || iters < 0) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, vad::launch_foreign_spin(e->d_tables[0], blocks, iters, kind, (hipStream_t)stream));
+    return VAD_OK;
+}
+
 int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, long ld,
                        const float *ctx, float *gx, void *stream_v) {
     if (!e) return VAD_ERR_ARG;

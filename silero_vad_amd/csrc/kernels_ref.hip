@@ -151,6 +151,34 @@ hipError_t launch_decimate(const PcmT *src, long lds, PcmT *dst, long ldd, int B
 template hipError_t launch_decimate<float>(const float *, long, float *, long, int, long, int, hipStream_t);
 template hipError_t launch_decimate<int16_t>(const int16_t *, long, int16_t *, long, int, long, int, hipStream_t);
 
+// ---- test hook: a "foreign tenant" ------------------------------------------------------------------------
+// A kernel that does nothing but VALU fp32 FMAs for `iters` rounds, in one-wave workgroups with a handful of
+// registers, so that its waves fit beside anything.  kind 0: packed fp32 (v_pk_fma_f32), kind 1: scalar fp32
+// (v_fma_f32).  tests/test_gpu_parity.py launches it on a second stream while the engine runs, to pin down
+// whether another tenant's packed-fp32 VALU work disturbs the f16 matrix pipe.
+__global__ void __launch_bounds__(64) foreign_spin_kernel(float *sink, long iters, int kind) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a{1.0f + threadIdx.x * 1e-3f, 0.5f}, b{0.25f, 0.75f};
+    const f2 m{0.999f, 1.0001f}, c{1e-3f, -1e-3f};
+    if (kind == 0) {
+        for (long i = 0; i < iters; ++i)
+            asm volatile("v_pk_fma_f32 %0, %0, %2, %3\n\tv_pk_fma_f32 %1, %1, %2, %3\n\t"
+                         "v_pk_fma_f32 %0, %0, %2, %3\n\tv_pk_fma_f32 %1, %1, %2, %3"
+                         : "+v"(a), "+v"(b) : "v"(m), "v"(c));
+    } else {
+        for (long i = 0; i < iters; ++i)
+            asm volatile("v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3\n\t"
+                         "v_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %2, %3"
+                         : "+v"(a.x), "+v"(b.x) : "v"(m.x), "v"(c.x));
+    }
+    if (a.x + a.y + b.x + b.y == 123.456f) sink[0] = a.x;             // keep the chain alive
+}
+hipError_t launch_foreign_spin(float *sink, int blocks, long iters, int kind, hipStream_t s) {
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(foreign_spin_kernel, dim3((unsigned)blocks), dim3(64), 0, s, sink, iters, kind);
+    return hipGetLastError();
+}
+
 template hipError_t launch_ref_forward<float>(const RefNet &, int, int, long, const float *, long,
                                               float *, float *, float *, long, hipStream_t);
 template hipError_t launch_ref_forward<int16_t>(const RefNet &, int, int, long, const int16_t *,

@@ -162,17 +162,17 @@ def test_batch_ragged_audio_forward(model, golden, tag):
 
 @pytest.mark.parametrize("tag", ["16k", "8k"])
 def test_vad_iterator_events(model, golden, tag):
+    """Every chunk of the fixture through VADIterator -> model(chunk, sr).item(): the full event lists must EQUAL
+    the ones the reference's VADIterator produced with the reference's model (all three recorded variants)."""
     from silero_vad_amd import VADIterator
     sr, g = SRS[tag], golden[tag]
     n = chunk_of(sr)
-    wav = torch.from_numpy(g["wav"][: 600 * n])
-    rec = golden["segments"][tag]["iterator"]["default"]
-    it = VADIterator(model, sampling_rate=sr)
-    ev = [e for s in range(0, len(wav), n) if (e := it(wav[s:s + n]))]
-    limit = 600 * n
-    want = [e for e in rec["events"] if list(e.values())[0] <= limit]
-    assert ev[:len(want) - 1] == want[:len(want) - 1]
-    assert len(ev) >= len(want) - 1 and len(ev) > 4
+    wav = torch.from_numpy(g["wav"])
+    for name, rec in golden["segments"][tag]["iterator"].items():
+        it = VADIterator(model, sampling_rate=sr, **rec["init"])
+        ev = [e for s in range(0, len(wav) - n + 1, n) if (e := it(wav[s:s + n], **rec["call"]))]
+        assert ev == rec["events"], f"{tag}/{name}"
+    assert len(golden["segments"][tag]["iterator"]["default"]["events"]) == {"16k": 39, "8k": 92}[tag]
 
 
 # ---- (2) oracle on seeded inputs: shapes and entry points the goldens do not cover -------------------
@@ -227,7 +227,7 @@ def test_carried_state_across_calls(model, golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["16k", "8k"])
-def test_int16_ingest(model, golden, tag):
+def test_int16_ingest(model, oracle, golden, tag):
     sr, g = SRS[tag], golden[tag]
     n = chunk_of(sr)
     B, L = 4, 50 * n + 5
@@ -235,10 +235,12 @@ def test_int16_ingest(model, golden, tag):
     p_i, c_i, s_i = run_engine(model, rows_i, sr)
     p_f, c_f, s_f = run_engine(model, rows_i.astype(np.float32) / 32768.0, sr)
     assert np.array_equal(p_i, p_f) and np.array_equal(s_i, s_f) and np.array_equal(c_i, c_f)
+    want, wctx, wst = oracle.forward_audio(rows_i.astype(np.float32) / 32768.0, sr)
+    assert np.abs(p_i - want).max() < TIGHT and state_err(s_i, wst) < TOL and np.array_equal(c_i, wctx)
 
 
 @pytest.mark.parametrize("k", [2, 3])
-def test_sample_rate_front_door(model, golden, k):
+def test_sample_rate_front_door(model, oracle, golden, k):
     """32 / 48 kHz input through the C ABI: decimated on the device exactly like the reference's
     x[:, ::sr // 16000] (vad_annotator.py:104-112), then the 16 kHz path -- bit-identical to handing over
     the decimated signal, for float and int16 PCM and for single steps."""
@@ -261,6 +263,10 @@ def test_sample_rate_front_door(model, golden, k):
             outs.append((p.clone(), st.clone(), ctx.clone()))
         for a, b in zip(*outs):
             assert torch.equal(a, b)
+        xd_f = xd.cpu().numpy().astype(np.float32) / (32768.0 if xd.dtype == torch.int16 else 1.0)
+        want, wctx, wst = oracle.forward_audio(xd_f, 16000)             # the oracle on the reference's x[:, ::k]
+        assert np.abs(outs[0][0].cpu().numpy() - want).max() < TIGHT
+        assert state_err(outs[0][1].cpu().numpy(), wst) < TOL and np.array_equal(outs[0][2].cpu().numpy(), wctx)
     # one step: a 512 k-sample chunk
     x = torch.from_numpy(np.stack([np.roll(golden["16k"]["wav"], -b * 77)[:512 * k] for b in range(B)])).to(dev)
     res = []
@@ -279,7 +285,7 @@ def test_sample_rate_front_door(model, golden, k):
 
 
 @pytest.mark.parametrize("tag", ["16k", "8k"])
-def test_time_slabs_are_transparent(model, golden, tag):
+def test_time_slabs_are_transparent(model, oracle, golden, tag):
     """An input whose gate pre-activations exceed the scratch cap is processed in time slabs (here: cap 1 MiB,
     33 streams -> 10 steps per slab, 47 chunks -> 5 slabs); results are bit-identical to the un-slabbed call."""
     sr = SRS[tag]
@@ -294,6 +300,8 @@ def test_time_slabs_are_transparent(model, golden, tag):
         model.engine.set_option("gx_cap_mib", 6144)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+    wp, wctx, wst = oracle.forward_audio(rows, sr)
+    assert np.abs(got[0] - wp).max() < TIGHT and np.array_equal(got[1], wctx) and state_err(got[2], wst) < TOL
 
 
 def test_misaligned_rows_are_handled(model, oracle, golden):
@@ -420,7 +428,7 @@ def test_streaming_step_in_hip_graph(model, oracle, golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["16k", "8k"])
-def test_ragged_corpus_equals_single_recording_runs(model, golden, tag):
+def test_ragged_corpus_equals_single_recording_runs(model, oracle, golden, tag):
     """configs[3] plumbing: recordings of different lengths bucketed into lock-step batches give
     bit-identical probabilities and identical segments to one-recording-at-a-time calls."""
     from silero_vad_amd import batch_speech_timestamps, get_speech_timestamps, ragged_probs
@@ -438,6 +446,10 @@ def test_ragged_corpus_equals_single_recording_runs(model, golden, tag):
                 a = torch.nn.functional.pad(a, (0, n - len(a)))
             want = model.audio_forward(a[None], sr)[0]
             assert torch.equal(p, want)
+        for i in (0, 7, 23, len(audios) - 1):                 # and against the oracle, one recording at a time
+            a = audios[i].numpy().astype(np.float32) / (32768.0 if kind == "i16" else 1.0)
+            a = np.pad(a, (0, max(0, n - len(a))))
+            assert np.abs(got[i].numpy() - oracle.audio_forward(a[None], sr)[0]).max() < TIGHT
     audios = [torch.from_numpy(g["wav"][s:s + m].copy()) for s, m in zip(starts, lens)]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -570,3 +582,206 @@ def test_full_size_launches_are_bit_stable(model, golden):
     finally:
         eng.set_precision("f16x3" if other == "fp32" else "fp32")
     assert float((q - p0).abs().max()) < TIGHT
+
+
+# ---- (6) BASELINE.json configs[1] / configs[2] at their exact shape, against the oracle --------------------------
+def _strided_rows(wav_dev, B, L, stride):
+    """x[b] = circular read of the fixture from offset b * stride (SURVEY 8d input sets (i)/(iii)), built without a
+    [B, L] index tensor: an overlapping strided view of the tiled recording, materialised once."""
+    reps = (stride * (B - 1) + L) // len(wav_dev) + 2
+    tiled = wav_dev.repeat(reps)
+    return tiled.as_strided((B, L), (stride, 1)).contiguous()
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_c2_c3_exact_shape_vs_oracle(model, oracle, golden, tag):
+    """4096 streams x 256 chunks (the bench workload's shape): streams 0..63 and 4032..4095, ALL 256 steps,
+    probabilities <= 1e-4 and the final (h, c) against the oracle (protocol examples/openvino/verify.py:157-181),
+    for input set (iii) real speech (stream b = fixture from offset b * 7919) and set (i) the synthetic mix
+    (offset b * 4001)."""
+    sr = SRS[tag]
+    n = chunk_of(sr)
+    B, T = 4096, 256
+    dev = model.device
+    sets = {"speech": (torch.from_numpy(golden[tag]["wav"]).to(dev), 7919),
+            "synthetic": (torch.from_numpy(synthetic_audio(sr, np.random.default_rng(42))).to(dev), 4001)}
+    for name, (src, stride) in sets.items():
+        x = _strided_rows(src, B, T * n, stride)
+        ctx = torch.zeros((B, n // 8), device=dev)
+        st = torch.zeros((2, B, 128), device=dev)
+        p = model.engine.forward_audio(x, sr, ctx, st)
+        torch.cuda.synchronize()
+        assert torch.isfinite(p).all()
+        for sub in (slice(0, 64), slice(4032, 4096)):
+            want, wctx, wst = oracle.forward_audio(x[sub].cpu().numpy(), sr)
+            err = np.abs(p[sub].cpu().numpy() - want).max()
+            assert err < TOL, (name, sub, err)
+            assert err < TIGHT, (name, sub, err)
+            assert state_err(st[:, sub].cpu().numpy(), wst) < TOL, (name, sub)
+            assert np.array_equal(ctx[sub].cpu().numpy(), wctx)
+        if name == "speech":
+            assert float((p > 0.5).float().mean()) > 0.3          # not a saturated-sigmoid test
+        del x
+
+
+def test_long_recurrence_full_batch(model, oracle, golden):
+    """The whole 60 s fixture (1875 chunks) on 4096 streams at once: the recurrence carried over 1875 steps and 3
+    time slabs, 16 streams checked against the oracle over all steps, final state included."""
+    sr, n, B = 16000, 512, 4096
+    dev = model.device
+    wav = torch.from_numpy(golden["16k"]["wav"]).to(dev)
+    L = len(wav) // n * n
+    x = _strided_rows(wav, B, L, 7919)
+    ctx = torch.zeros((B, n // 8), device=dev)
+    st = torch.zeros((2, B, 128), device=dev)
+    p = model.engine.forward_audio(x, sr, ctx, st)
+    torch.cuda.synchronize()
+    assert p.shape == (B, L // n) and torch.isfinite(p).all()
+    rows = [0, 1, 2, 3, 1000, 1001, 2047, 2048, 3000, 4090, 4091, 4092, 4093, 4094, 4095, 17]
+    want, _, wst = oracle.forward_audio(x[rows].cpu().numpy(), sr)
+    assert np.abs(p[rows].cpu().numpy() - want).max() < TIGHT
+    assert state_err(st[:, rows].cpu().numpy(), wst) < TOL
+    assert torch.equal(p[0], model.audio_forward(wav[None, :L], sr)[0].to(dev))    # == the single-stream run
+
+
+# ---- (7) adversarial inputs inside the reference's input contract (|pcm| <= 1) ---------------------------------
+def _adversarial(sr, T):
+    n = chunk_of(sr)
+    L = T * n
+    t = np.arange(L)
+    rng = np.random.default_rng(7)
+    rows = {
+        "square_fullscale_1k": np.sign(np.sin(2 * np.pi * 1000.0 * t / sr) + 1e-9),
+        "square_fullscale_50": np.sign(np.sin(2 * np.pi * 50.0 * t / sr) + 1e-9),
+        "dc_plus_one": np.ones(L),
+        "dc_minus_one": -np.ones(L),
+        "alternating_pm1": np.where(t % 2 == 0, 1.0, -1.0),          # Nyquist at full scale
+        "impulses": (t % 997 == 0).astype(np.float64),
+        "single_impulse": (t == 3 * n + 5).astype(np.float64),
+        "near_silent_1e-5": 1e-5 * rng.standard_normal(L),
+        "denormal_level": 1e-39 * rng.standard_normal(L),
+        "zeros": np.zeros(L),
+        "uniform_fullscale": rng.uniform(-1, 1, L),
+        "sine_fullscale_440": np.sin(2 * np.pi * 440.0 * t / sr),
+        "chirp_fullscale": np.sin(2 * np.pi * (20 + (sr / 2 - 40) * t / L / 2) * t / sr),
+        "step_silence_to_fullscale": np.where(t > L // 2, rng.uniform(-1, 1, L), 0.0),
+        "int16_extremes": np.where(rng.random(L) < 0.5, -1.0, 32767.0 / 32768.0),
+        "speech_like_am": 0.8 * np.sin(2 * np.pi * 180 * t / sr) * (0.5 + 0.5 * np.sin(2 * np.pi * 3 * t / sr)),
+    }
+    return list(rows), np.stack([rows[k] for k in rows]).astype(np.float32)
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_adversarial_inputs_vs_oracle(model, oracle, tag):
+    """Full-scale square waves, DC, +-1 alternation, impulses, near-silent and denormal-level PCM ...: both
+    arithmetic implementations must stay within the contract (and finite) on every legal input, not only on speech
+    and noise.  40 chunks each, probabilities and final state vs the oracle."""
+    sr = SRS[tag]
+    names, rows = _adversarial(sr, 40)
+    probs, ctx, st = run_engine(model, rows, sr)
+    want, wctx, wst = oracle.forward_audio(rows, sr)
+    assert np.isfinite(probs).all(), [names[i] for i in np.flatnonzero(~np.isfinite(probs).all(1))]
+    err = np.abs(probs - want).max(1)
+    assert err.max() < TOL, dict(zip(names, err))
+    assert state_err(st, wst) < TOL
+    assert np.array_equal(ctx, wctx)
+    if model.engine.precision == "fp32":
+        assert err.max() < TIGHT, dict(zip(names, err))
+
+
+def test_get_speech_timestamps_on_unnormalised_audio(model, golden):
+    """Float audio at int16 scale (x 100 here) is outside the reference's input contract but the reference still
+    answers finite probabilities.  fp32 (the default) simply computes; the opt-in "auto" wrapper must notice the
+    f16x3 range flag inside get_speech_timestamps (not only in audio_forward) and rerun in fp32."""
+    from silero_vad_amd import HipSileroVAD, get_speech_timestamps
+    sr = 16000
+    wav = torch.from_numpy(golden["16k"]["wav"][:200 * 512]) * 100.0
+    exact = HipSileroVAD(engine=model.engine, precision="fp32")
+    want = get_speech_timestamps(wav, exact, sampling_rate=sr)
+    auto = HipSileroVAD(engine=model.engine, precision="auto")
+    got = get_speech_timestamps(wav, auto, sampling_rate=sr)
+    assert got == want and len(want) >= 1
+    assert torch.isfinite(auto.audio_forward(wav, sr)).all()
+    assert model.engine.precision == model.precision                # shared engine left as it was found
+
+
+def test_stream_pool_recaptures_after_scratch_growth(model, oracle, golden):
+    """A hipGraph captured by StreamPool bakes in the engine's scratch addresses.  A later, larger call on the SAME
+    engine reallocates that scratch (vad_scratch_generation changes); the pool must re-capture instead of replaying
+    a graph that points at freed memory, and its streams must carry on exactly."""
+    from silero_vad_amd import Engine, StreamPool
+    sr, n, cap, T = 16000, 512, 48, 10
+    eng = Engine(device=model.device.index)
+    eng.set_precision(model.engine.precision)
+    rows = rolled_rows(golden["16k"]["wav"], cap, T * n, 1733)
+    pool = StreamPool(eng, sr, capacity=cap, graph=True)
+    for _ in range(cap):
+        pool.open()
+    gen0 = eng.scratch_generation()
+    got = np.zeros((cap, T), np.float32)
+    for t in range(T):
+        if t == 4:                                                     # another user of the engine grows the scratch
+            big = torch.zeros((2048, 64 * n), device=model.device)
+            eng.forward_audio(big, sr, torch.zeros((2048, 64), device=model.device),
+                              torch.zeros((2, 2048, 128), device=model.device))
+            torch.cuda.synchronize()
+            assert eng.scratch_generation() != gen0
+        got[:, t] = pool.tick(torch.from_numpy(rows[:, t * n:(t + 1) * n]).to(model.device)).cpu().numpy()
+    assert pool._graph_gen == eng.scratch_generation()
+    want, _, wst = oracle.forward_audio(rows, sr)
+    assert np.abs(got - want).max() < TIGHT
+    assert state_err(pool.state.cpu().numpy(), wst) < TOL
+
+
+# ---- (8) a foreign tenant on the same GPU -----------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["pk_fma_spinner", "scalar_fma_spinner", "torch_elementwise"])
+def test_bit_stable_under_foreign_load(model, golden, kind):
+    """Full-size launches while ANOTHER stream keeps the CUs busy with fp32 VALU work: a hand-written
+    v_pk_fma_f32 spinner in one-wave workgroups (fits beside anything), its scalar twin (control), and a torch
+    a*b+c loop.  The exact-fp32 kernels (the default) must be bit-stable.  For the opt-in f16x3 kernels this is the
+    open question of DESIGN.md section 4.2b (packed-fp32 VALU in a co-resident wave vs f16 MFMAs in flight): the
+    outcome is written to gpurun_out/foreign_load_<precision>.json and a corruption is reported as xfail -- f16x3 is
+    documented as single-tenant only until this passes."""
+    import json
+    import os
+    from silero_vad_amd import _lib
+    sr, n, B, T = 16000, 512, 4096, 64
+    dev = model.device
+    x = _strided_rows(torch.from_numpy(golden["16k"]["wav"]).to(dev), B, T * n, 7919)
+    eng = model.engine
+    side = torch.cuda.Stream(dev)
+    a = torch.randn(1 << 24, device=dev)
+    b = torch.randn(1 << 24, device=dev)
+    c = torch.zeros(1 << 24, device=dev)
+
+    def run():
+        ctx = torch.zeros((B, n // 8), device=dev)
+        st = torch.zeros((2, B, 128), device=dev)
+        p = eng.forward_audio(x, sr, ctx, st)
+        return p, st
+
+    p0, s0 = run()
+    torch.cuda.synchronize()
+    bad, launches = 0, 100
+    for i in range(launches):
+        with torch.cuda.stream(side):                                 # keep ~2 launches worth of foreign work queued
+            if kind == "torch_elementwise":
+                for _ in range(6):
+                    c = torch.addcmul(c, a, b)
+            else:
+                _lib.check(eng._h, _lib.lib().vad_debug_foreign_load(
+                    eng._h, 0 if kind == "pk_fma_spinner" else 1, 8192, 20000, side.cuda_stream))
+        p, s = run()
+        bad += int(not (torch.equal(p, p0) and torch.equal(s, s0)))
+    torch.cuda.synchronize()
+    out = {"precision": eng.precision, "foreign": kind, "launches": launches, "launches_differing": bad,
+           "tiles_per_launch": B // 16 * T}
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = f"gpurun_out/foreign_load_{eng.precision}.json"
+    prev = json.load(open(path)) if os.path.exists(path) else {}
+    prev[kind] = out
+    json.dump(prev, open(path, "w"), indent=1)
+    if eng.precision == "fp32":
+        assert bad == 0, out
+    elif bad:
+        pytest.xfail(f"f16x3 is not bit-stable beside a foreign tenant ({out}): single-tenant only")

@@ -10,9 +10,7 @@ python __graft_entry__.py > "$out/build.log" 2>&1
 timeout 1500 python -m pytest tests -m gpu -q --timeout 300 --timeout-method=thread -p no:cacheprovider > "$out/pytest_gpu.log" 2>&1
 echo "pytest rc=$?" >> "$out/pytest_gpu.log"
 tail -n 40 "$out/pytest_gpu.log"
-timeout 400 python bench.py > "$out/bench_c2.log" 2>&1; tail -n 3 "$out/bench_c2.log" | cut -c1-3000
-timeout 300 python bench.py --config 8k --no-cpu-baseline > "$out/bench_8k.log" 2>&1; tail -n 2 "$out/bench_8k.log" | cut -c1-1500
-timeout 300 python bench.py --config stream --no-cpu-baseline > "$out/bench_stream.log" 2>&1; tail -n 2 "$out/bench_stream.log" | cut -c1-1500
+timeout 900 python bench.py > "$out/bench_c2.log" 2>&1; tail -n 3 "$out/bench_c2.log" | cut -c1-6000
 if [ -n "$prof" ]; then
   bash tools/profile.sh "$tag" > "$out/profile.log" 2>&1
   python tools/summarize_prof.py "gpurun_out/prof_$tag" "gpurun_out/$tag/summary" >> "$out/profile.log" 2>&1

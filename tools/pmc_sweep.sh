@@ -4,7 +4,7 @@ set -u
 name=$1; shift
 out=$PWD/gpurun_out/pmc_$name
 mkdir -p "$out"; export TMPDIR=/tmp
-args="--no-cpu-baseline --steps 3 --warmup 1 $*"
+args="--no-cpu-baseline --no-extras --steps 6 --warmup 1 $*"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue

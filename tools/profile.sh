@@ -9,7 +9,9 @@ name=$1; shift
 out=$PWD/gpurun_out/prof_$name
 mkdir -p "$out"
 export TMPDIR=/tmp
-args="--no-cpu-baseline --steps 4 --warmup 2 $*"
+# the bench's own protocol: 40 untimed clock-ramp steps, 2 warm-up, then 20 timed (= profiled) steps; the summary
+# reports median / min / mean over the LAST 20 dispatches of each kernel (tools/summarize_prof.py)
+args="--no-cpu-baseline --no-extras --steps 20 --warmup 2 $*"
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o trace --output-format csv -- python bench.py $args > "$out/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o fetch --output-format csv -- python bench.py $args > "$out/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o write --output-format csv -- python bench.py $args > "$out/write.log" 2>&1

@@ -41,6 +41,25 @@ def main(src, dst_prefix, workload=(16000, 4096, 256)):
             t = out["kernel_trace"][k]
             lines.append(f"| {k} | {t['calls']} | {t['avg_ms']:.4f} | {t['min_ms']:.4f} | {t['max_ms']:.4f} | {t['pct']:.2f} |")
         lines.append("")
+    # per-dispatch durations: statistics over the LAST `tail` dispatches of each kernel (the bench's timed steps,
+    # after its clock ramp) -- what has to agree with the hipEvent time bench.py prints
+    tail = 20
+    for f in glob.glob(str(src / "trace" / "**" / "*_kernel_trace.csv"), recursive=True):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k:
+                per[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        lines += [f"## kernel trace, last {tail} dispatches of each kernel (the timed steps after the ramp)", "",
+                  "| kernel | dispatches | median ms | min ms | mean ms | max ms |", "|---|---|---|---|---|---|"]
+        for k, v in per.items():
+            v.sort()
+            d = sorted((e - s0) / 1e6 for s0, e in v[-tail:])
+            st = {"dispatches": len(d), "median_ms": d[len(d) // 2], "min_ms": d[0], "mean_ms": sum(d) / len(d),
+                  "max_ms": d[-1]}
+            out.setdefault("kernel_trace_tail", {})[k] = st
+            lines.append(f"| {k} | {st['dispatches']} | {st['median_ms']:.4f} | {st['min_ms']:.4f} | {st['mean_ms']:.4f} | {st['max_ms']:.4f} |")
+        lines.append("")
     for f in sorted(glob.glob(str(src / "*" / "**" / "*_counter_collection.csv"), recursive=True)):
         agg = collections.defaultdict(list)
         meta = {}
@@ -65,7 +84,7 @@ def main(src, dst_prefix, workload=(16000, 4096, 256)):
         for line in open(log, errors="ignore"):
             if line.startswith('{"metric"'):
                 d = json.loads(line)
-                out.setdefault("bench_lines", {})[log.stem] = {k: d[k] for k in ("value", "ms_per_step", "kernel_ms")}
+                out.setdefault("bench_lines", {})[log.stem] = {k: d[k] for k in ("value", "ms_per_step", "kernel_ms", "dtype") if k in d}
     if "bench_lines" in out:
         lines += ["## bench.py line printed inside each profiled run (hipEvent timing, same process)", ""]
         for k, v in out["bench_lines"].items():

@@ -126,7 +126,8 @@ def run(names):
             r["parity"] = next((float(l.split()[1]) for l in chk.stdout.splitlines() if l.startswith("PARITY")), None)
             if r["parity"] is None:
                 r["error"] = chk.stderr[-500:]
-        b = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--steps", "8", "--warmup", "2"],
+        b = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--no-extras", "--steps", "60", "--warmup", "2"]
+                           + (["--precision", os.environ["VARIANT_PRECISION"]] if os.environ.get("VARIANT_PRECISION") else []),
                            env=env, capture_output=True, text=True, timeout=600)
         line = next((l for l in b.stdout.splitlines() if l.startswith('{"metric"')), None)
         if line:
