@@ -161,6 +161,17 @@ long vad_segment_probs_batch(const float *probs, long ldp, long n_streams, const
                              const long *audio_len, const vad_segment_params *p, vad_segment *out,
                              long cap_per_stream, long *counts, int threads);
 
+/* The same scan ON THE DEVICE, for probabilities that vad_forward_audio just left in HBM: one GPU lane per
+ * stream, so that only the segment lists cross PCIe (16 B per segment) instead of every probability, and the host
+ * does no per-chunk work (the reference does it in a Python loop per file: utils_vad.py:348-440).  All pointers
+ * are DEVICE pointers except `p`.  n_chunks may be NULL: every stream then has n_chunks_all (<= ldp) entries.
+ * Stream i's segments go to out[i * cap_per_stream ...], their number (may exceed cap_per_stream: grow and call
+ * again) to counts[i].  Asynchronous on `stream`.  Same results as vad_segment_probs_batch, bit for bit (one
+ * source, csrc/scanner.hpp).                                                                        */
+int  vad_segment_probs_device(vad_engine *e, const float *probs, long ldp, long n_streams, const long *n_chunks,
+                              long n_chunks_all, const long *audio_len, const vad_segment_params *p,
+                              vad_segment *out, long cap_per_stream, long *counts, void *stream);
+
 /* ---- host-side ingest ---------------------------------------------------------------------------------
  * Pack n recordings of different lengths (lens[i] samples of elem_size 2 = int16 or 4 = float32 at
  * rows[i]) into one zero-padded row-major [n][width] batch at dst (typically pinned host memory that

@@ -150,9 +150,13 @@ def _repair_out_of_range(audios, idxs, probs, model, sampling_rate, n):
 
 
 def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
-                   max_bytes: int = 256 << 20, plan: RaggedPlan = None):
+                   max_bytes: int = 256 << 20, plan: RaggedPlan = None, post=None):
     """Generator over the plan's buckets: yields (indices, probs[len(indices), T_bucket] on the CPU).
-    Recording i of a bucket owns the first ceil(len_i / N) entries of its row."""
+    Recording i of a bucket owns the first ceil(len_i / N) entries of its row.
+
+    `post` (GPU models only): a function (probs_dev, indices) -> list of device tensors that is enqueued right after
+    the bucket's kernels; the generator then yields (indices, [those tensors on the CPU], probs_dev) and the
+    probabilities themselves never leave the GPU (ragged_speech_segments scans them there)."""
     n = chunk_size(sampling_rate)
     as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
     dtype = torch.int16 if as_i16 else torch.float32
@@ -202,6 +206,12 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         pool.done[i] = ev
         return d, ev, i
 
+    def finish(done_bucket):
+        idxs, outs, _, probs_dev = done_bucket
+        if post is None:
+            return idxs, _repair_out_of_range(audios, idxs, outs[0], model, sampling_rate, n)
+        return idxs, outs, probs_dev
+
     staged = stage(0) if plan.buckets else None
     prev = None
     for k, idxs in enumerate(plan.buckets):
@@ -211,21 +221,26 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         probs = fast(x, sampling_rate, guarded=False)     # async: kernels of bucket k (flagged rows: _repair_...)
         pool.consumed[slot] = torch.cuda.Event()
         pool.consumed[slot].record(cur)
-        out = torch.empty(probs.shape, dtype=torch.float32, pin_memory=True)
-        out.copy_(probs, non_blocking=True)
+        back = [probs] if post is None else post(probs, idxs)
+        outs = []
+        for o in back:                                    # pinned blocks come from torch's caching host allocator
+            h = torch.empty(o.shape, dtype=o.dtype, pin_memory=True)
+            h.copy_(o, non_blocking=True)
+            STATS["d2h_bytes"] += h.numel() * h.element_size()
+            outs.append(h)
         done = torch.cuda.Event()
         done.record(cur)
         staged = stage(k + 1) if k + 1 < len(plan.buckets) else None   # CPU packs k+1 meanwhile
         if prev is not None:
             prev[2].synchronize()
-            yield prev[0], _repair_out_of_range(audios, prev[0], prev[1], model, sampling_rate, n)
-        prev = (idxs, out, done)
+            yield finish(prev)
+        prev = (idxs, outs, done, probs)
     if prev is not None:
         prev[2].synchronize()
         for a, b in copies:
             b.synchronize()
             STATS["h2d_s"] += a.elapsed_time(b) / 1e3
-        yield prev[0], _repair_out_of_range(audios, prev[0], prev[1], model, sampling_rate, n)
+        yield finish(prev)
 
 
 def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
@@ -246,12 +261,46 @@ def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste:
 
 
 def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
-                           max_bytes: int = 256 << 20, threads: int = 0, **scan_kw) -> List[list]:
-    """Speech segments (sample indices) of many recordings: bucketed GPU batches + the native
-    threaded scanner per bucket.  scan_kw: the threshold/duration arguments of get_speech_timestamps."""
+                           max_bytes: int = 256 << 20, threads: int = 0, device_scan: bool = None,
+                           **scan_kw) -> List[list]:
+    """Speech segments (sample indices) of many recordings: bucketed GPU batches, then the segmenter.
+    scan_kw: the threshold/duration arguments of get_speech_timestamps.
+
+    device_scan (default: on for a GPU model with pinned arithmetic): the scan runs on the GPU right behind the
+    kernels of its bucket (vad_segment_probs_device, one lane per recording) and only counts + segment lists come
+    back over PCIe; otherwise the probabilities are copied to the host and scanned by the native threaded scanner.
+    Both give the same segments (one source, csrc/scanner.hpp)."""
     n = chunk_size(sampling_rate)
     lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
     out: List[list] = [[] for _ in audios]
+    dev = getattr(model, "device", None)
+    on_gpu = dev is not None and torch.device(dev).type == "cuda"
+    if device_scan is None:
+        device_scan = on_gpu and getattr(model, "precision", None) != "auto"
+    if device_scan:
+        params = _segment_params(sampling_rate, **scan_kw)
+        cap0 = 24                                              # segments per recording copied back optimistically
+
+        def post(probs_dev, idxs):
+            lens = torch.tensor([lengths[i] for i in idxs], dtype=torch.int64)
+            nck = (lens + n - 1) // n
+            both = torch.stack([nck, lens]).to(probs_dev.device, non_blocking=True)
+            counts, segs = _device_scan(model.engine, probs_dev, both[0], both[1], params, cap0)
+            return [counts, segs]
+
+        for idxs, (counts, segs), probs_dev in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes, post=post):
+            t0 = time.perf_counter()
+            cnt = counts.numpy()
+            if len(cnt) and int(cnt.max()) > cap0:             # rare: rescan this bucket with room for all
+                lens = torch.tensor([lengths[i] for i in idxs], dtype=torch.int64)
+                both = torch.stack([(lens + n - 1) // n, lens]).to(probs_dev.device)
+                c2, s2 = _device_scan(model.engine, probs_dev, both[0], both[1], params, int(cnt.max()))
+                cnt, segs = c2.cpu().numpy(), s2.cpu()
+            sg = segs.numpy()
+            for row, i in enumerate(idxs):
+                out[i] = [{"start": int(a), "end": int(b)} for a, b in sg[row, : cnt[row]]]
+            STATS["scan_s"] += time.perf_counter() - t0
+        return out
     for idxs, probs in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes):
         lens = [lengths[i] for i in idxs]
         t0 = time.perf_counter()
@@ -263,14 +312,9 @@ def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
     return out
 
 
-def segment_probs_batch(probs: torch.Tensor, n_chunks, audio_lengths, sampling_rate=16000, threshold=0.5,
-                        neg_threshold=None, min_speech_duration_ms=250,
-                        max_speech_duration_s=float("inf"), min_silence_duration_ms=100,
-                        speech_pad_ms=30, min_silence_at_max_speech=98,
-                        use_max_poss_sil_at_max_speech=True, threads=0) -> List[list]:
-    """`timestamps.segment_probs` for every row of probs[B, T] in one native call (host threads)."""
-    probs = torch.as_tensor(probs, dtype=torch.float32).contiguous().cpu()
-    B, T = probs.shape
+def _segment_params(sampling_rate=16000, threshold=0.5, neg_threshold=None, min_speech_duration_ms=250,
+                    max_speech_duration_s=float("inf"), min_silence_duration_ms=100, speech_pad_ms=30,
+                    min_silence_at_max_speech=98, use_max_poss_sil_at_max_speech=True):
     p = _lib.SegmentParams()
     lib().vad_segment_params_default(ctypes.byref(p), int(sampling_rate))
     p.threshold = float(threshold)
@@ -281,6 +325,57 @@ def segment_probs_batch(probs: torch.Tensor, n_chunks, audio_lengths, sampling_r
     p.speech_pad_ms = int(speech_pad_ms)
     p.min_silence_at_max_speech_ms = int(min_silence_at_max_speech)
     p.use_max_poss_sil_at_max_speech = 1 if use_max_poss_sil_at_max_speech else 0
+    return p
+
+
+def _device_scan(engine, probs_dev, n_chunks_dev, audio_len_dev, params, cap):
+    """Enqueue the GPU scan of probs_dev[B, T] on the current stream -> (counts[B], segs[B, cap, 2]) int64, device."""
+    B, T = probs_dev.shape
+    counts = torch.empty((B,), dtype=torch.int64, device=probs_dev.device)
+    segs = torch.empty((B, max(cap, 1), 2), dtype=torch.int64, device=probs_dev.device)
+    _lib.check(engine._h, lib().vad_segment_probs_device(
+        engine._h, probs_dev.data_ptr(), probs_dev.stride(0) if B > 1 else T, B,
+        n_chunks_dev.data_ptr() if n_chunks_dev is not None else None, T, audio_len_dev.data_ptr(),
+        ctypes.byref(params), segs.data_ptr(), segs.shape[1], counts.data_ptr(),
+        ctypes.c_void_p(torch.cuda.current_stream(probs_dev.device).cuda_stream)))
+    return counts, segs
+
+
+def segment_probs_batch_device(engine, probs_dev: torch.Tensor, n_chunks, audio_lengths, sampling_rate=16000,
+                               **scan_kw) -> List[list]:
+    """`segment_probs_batch` for probabilities that are already on the GPU (probs_dev[B, T], CUDA): the scan runs
+    there (vad_segment_probs_device) and only the segment lists are copied back."""
+    B, T = probs_dev.shape
+    params = _segment_params(sampling_rate, **scan_kw)
+    both = torch.stack([torch.as_tensor(n_chunks, dtype=torch.int64), torch.as_tensor(audio_lengths, dtype=torch.int64)])
+    if both.shape != (2, B):
+        raise ValueError("n_chunks and audio_lengths need one entry per row of probs")
+    if int(both[0].max() if B else 0) > T or int(both.min() if B else 0) < 0:
+        raise ValueError("n_chunks must lie in [0, T] and audio lengths must not be negative")
+    both = both.to(probs_dev.device)
+    cap = 24
+    while True:
+        counts, segs = _device_scan(engine, probs_dev.contiguous(), both[0], both[1], params, cap)
+        cnt = counts.cpu().numpy()
+        if B == 0 or int(cnt.max()) <= cap:
+            break
+        cap = int(cnt.max())
+    m = int(cnt.max()) if B else 0
+    sg = segs[:, :max(m, 1)].cpu().numpy()
+    return [[{"start": int(a), "end": int(b)} for a, b in sg[i, : cnt[i]]] for i in range(B)]
+
+
+def segment_probs_batch(probs: torch.Tensor, n_chunks, audio_lengths, sampling_rate=16000, threshold=0.5,
+                        neg_threshold=None, min_speech_duration_ms=250,
+                        max_speech_duration_s=float("inf"), min_silence_duration_ms=100,
+                        speech_pad_ms=30, min_silence_at_max_speech=98,
+                        use_max_poss_sil_at_max_speech=True, threads=0) -> List[list]:
+    """`timestamps.segment_probs` for every row of probs[B, T] in one native call (host threads)."""
+    probs = torch.as_tensor(probs, dtype=torch.float32).contiguous().cpu()
+    B, T = probs.shape
+    p = _segment_params(sampling_rate, threshold, neg_threshold, min_speech_duration_ms, max_speech_duration_s,
+                        min_silence_duration_ms, speech_pad_ms, min_silence_at_max_speech,
+                        use_max_poss_sil_at_max_speech)
     nck = np.ascontiguousarray(n_chunks, dtype=np.int64)
     alen = np.ascontiguousarray(audio_lengths, dtype=np.int64)
     if nck.shape != (B,) or alen.shape != (B,):

@@ -785,3 +785,72 @@ def test_bit_stable_under_foreign_load(model, golden, kind):
         assert bad == 0, out
     elif bad:
         pytest.xfail(f"f16x3 is not bit-stable beside a foreign tenant ({out}): single-tenant only")
+
+
+# ---- (9) the segmenter on the device ----------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_device_scan_reproduces_reference_segments(model, golden, tag):
+    """vad_segment_probs_device on the reference's own probabilities: every recorded get_speech_timestamps variant
+    (thresholds, pads, min/max durations, legacy max-speech cut) must come out identical to the reference's output."""
+    from silero_vad_amd import segment_probs_batch_device
+    sr, g = SRS[tag], golden[tag]
+    info = golden["segments"][tag]
+    probs = torch.from_numpy(g["probs_wav"]).to(model.device)[None].repeat(3, 1).contiguous()
+    n = chunk_of(sr)
+    for name, rec in info["timestamps"].items():
+        kw = {k: v for k, v in rec["kwargs"].items() if k not in ("return_seconds", "time_resolution", "sampling_rate")}
+        if name == "sr32000" or "return_seconds" in rec["kwargs"]:
+            continue
+        T = probs.shape[1]
+        got = segment_probs_batch_device(model.engine, probs, [T, T, T // 2], [info["n_samples"]] * 2 + [T // 2 * n],
+                                         sr, **kw)
+        assert got[0] == rec["out"] and got[1] == rec["out"], f"{tag}/{name}"
+        assert len(got[2]) >= 1 and got[2][-1]["end"] <= T // 2 * n
+
+
+def test_device_scan_equals_host_scan_fuzz(model):
+    """Random-walk probabilities x awkward parameter sets (min_silence 0, tiny max_speech, neg_threshold above
+    threshold ...): the device scan and the host scan are the same source and must agree exactly, including the
+    overflow protocol (more segments than the optimistic buffer)."""
+    from silero_vad_amd import segment_probs_batch, segment_probs_batch_device
+    rng = np.random.default_rng(3)
+    B, T = 300, 500
+    walk = np.cumsum(rng.standard_normal((B, T)) * 0.25, axis=1)
+    probs = (1.0 / (1.0 + np.exp(-walk + rng.standard_normal((B, 1))))).astype(np.float32)
+    probs[7] = 0.0
+    probs[8] = 1.0
+    probs[9, ::2] = 0.9
+    probs[9, 1::2] = 0.0                                              # a segment candidate every other chunk
+    nck = rng.integers(0, T + 1, size=B)
+    nck[:10] = T
+    for sr in (16000, 8000):
+        n = chunk_of(sr)
+        alen = np.maximum(nck * n - rng.integers(0, n, size=B), 0)
+        dev = torch.from_numpy(probs).to(model.device)
+        for kw in ({}, {"min_silence_duration_ms": 0, "min_speech_duration_ms": 0, "speech_pad_ms": 0},
+                   {"max_speech_duration_s": 1.0}, {"max_speech_duration_s": 0.5, "use_max_poss_sil_at_max_speech": False},
+                   {"max_speech_duration_s": 2.0, "min_silence_at_max_speech": 10, "min_silence_duration_ms": 400},
+                   {"threshold": 0.3, "neg_threshold": 0.6, "speech_pad_ms": 200},
+                   {"threshold": 0.9, "min_speech_duration_ms": 1000}):
+            want = segment_probs_batch(probs, nck, alen, sr, **kw)
+            got = segment_probs_batch_device(model.engine, dev, nck, alen, sr, **kw)
+            assert got == want, (sr, kw)
+    assert max(len(s) for s in want) >= 0
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_ragged_segments_device_scan_equals_host_scan(model, golden, tag):
+    from silero_vad_amd import get_speech_timestamps, ragged_speech_segments
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    rng = np.random.default_rng(21)
+    lens = [int(v) for v in rng.integers(n, 200 * n, size=30)] + [n // 2, 3]
+    starts = rng.integers(0, len(g["wav"]) - 200 * n, size=len(lens))
+    audios = [torch.from_numpy(g["pcm_i16"][s:s + m].copy()) for s, m in zip(starts, lens)]
+    for kw in ({}, {"threshold": 0.4, "max_speech_duration_s": 2.0}):
+        a = ragged_speech_segments(audios, model, sr, max_waste=0.2, max_bytes=1 << 20, device_scan=True, **kw)
+        b = ragged_speech_segments(audios, model, sr, max_waste=0.2, max_bytes=1 << 20, device_scan=False, **kw)
+        assert a == b
+        one = get_speech_timestamps(audios[3].float() / 32768.0, model, sampling_rate=sr, **kw)
+        assert a[3] == one
+    assert sum(len(s) for s in a) > 10

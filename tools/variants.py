@@ -19,7 +19,7 @@ ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
 HIP = ["engine.hip", "kernel_front.hip", "kernel_rec.hip", "kernel_front_split.hip", "kernel_rec_split.hip",
-       "kernels_ref.hip"]
+       "kernels_ref.hip", "kernel_scan.hip"]
 CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
 VARIANTS = {
