@@ -23,6 +23,7 @@ struct vad_engine {
     bool split = false;                             // precision: exact fp32 MFMA (default) | fp16x3 split MFMA (opt-in)
     bool split_rec = false;                         // (bring-up: the two kernels can be chosen separately)
     bool profile = false;
+    bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the fp32 frontend's loads (option "fused_decimation")
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
 
     // device images
@@ -118,53 +119,33 @@ int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
     return VAD_OK;
 }
 
+// Grow-only scratch buffer (never while a stream is being captured); bumps the scratch generation.
+int grow(vad_engine *e, void **buf, size_t *have, size_t need, hipStream_t stream, const char *what) {
+    if (need <= *have) return VAD_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(e, VAD_ERR_CAPTURE, std::string(what) + " scratch must grow during stream capture");
+    HIP_TRY(e, hipDeviceSynchronize());
+    e->scratch_gen++;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    if (hipMalloc(buf, need) != hipSuccess) return fail(e, VAD_ERR_ALLOC, std::string("cannot allocate ") + what + " scratch");
+    *have = need;
+    return VAD_OK;
+}
+
+// L, ld: samples per row / row stride of `pcm` AS HANDED OVER (raw rate).  dec = 1: pcm is at the net's rate `sr`.
+// dec = 2, 3: pcm is at dec x 16 kHz and the frontend reads every dec-th sample itself (sample-rate front door
+// folded into the load; fp32 frontend).
 template <typename PcmT>
-int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld, float *ctx,
-                 float *state, float *probs, long ldp, void *stream_v) {
-    if (!e) return VAD_ERR_ARG;
-    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
-    if (B < 0 || L < 0 || (B > 0 && L > 0 && (!pcm || !ctx || !state || !probs)) || ld < L)
-        return fail(e, VAD_ERR_ARG, "bad argument");
-    if (sr > 16000 && sr % 16000 == 0) {
-        // sample-rate front door: a multiple of 16 kHz is decimated to 16 kHz, x[:, ::sr/16000], exactly as the
-        // reference does (vad_annotator.py:104-112), then takes the 16 kHz path
-        if (B == 0 || L == 0) return VAD_OK;
-        const int k = sr / 16000;
-        const long Ld = (L + k - 1) / k, ldd = (Ld + 15) / 16 * 16;
-        const size_t need = (size_t)B * ldd * sizeof(PcmT);
-        hipStream_t stream = (hipStream_t)stream_v;
-        HIP_TRY(e, hipSetDevice(e->device));
-        if (need > e->decim_bytes) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-                return fail(e, VAD_ERR_CAPTURE, "decimation scratch must grow during stream capture");
-            HIP_TRY(e, hipDeviceSynchronize());
-            e->scratch_gen++;
-            if (e->d_decim) (void)hipFree(e->d_decim);
-            e->d_decim = nullptr;
-            e->decim_bytes = 0;
-            if (hipMalloc(&e->d_decim, need) != hipSuccess)
-                return fail(e, VAD_ERR_ALLOC, "cannot allocate decimation scratch");
-            e->decim_bytes = need;
-        }
-        PcmT *dec = reinterpret_cast<PcmT *>(e->d_decim);
-        HIP_TRY(e, vad::launch_decimate<PcmT>(pcm, ld, dec, ldd, B, Ld, k, stream));
-        return forward_impl<PcmT>(e, 16000, B, Ld, dec, ldd, ctx, state, probs, ldp, stream_v);
-    }
+int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm, long ld, float *ctx,
+                 float *state, float *probs, long ldp, hipStream_t stream) {
     const int ni = net_index(sr);
-    if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000] (or multiply of 16000)");
-    if (B == 0 || L == 0) return VAD_OK;
     const int N = sr == 16000 ? 512 : 256, C = N / 8;
-    const long T = (L + N - 1) / N;
+    const long Ld = (L + dec - 1) / dec;                 // samples per row at the net's rate
+    const long T = (Ld + N - 1) / N;
     if (ldp < T) return fail(e, VAD_ERR_ARG, "ldp < T");
-    hipStream_t stream = (hipStream_t)stream_v;
-    HIP_TRY(e, hipSetDevice(e->device));
-
-    if (e->impl_reference) {
-        HIP_TRY(e, vad::launch_ref_forward<PcmT>(e->ref[ni], sr, B, L, pcm, ld, ctx, state, probs, ldp, stream));
-        return VAD_OK;
-    }
-
     if (((size_t)ctx & 15) || ((size_t)state & 15))
         return fail(e, VAD_ERR_ARG, "ctx and state must be 16-byte aligned");
     int rc = ensure_scratch(e, sr, B, T, stream);
@@ -174,31 +155,25 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
     const size_t esz = sizeof(PcmT);
     if (((size_t)pcm & 15) || (B > 1 && (ld * esz) % 16)) {
         const long ldA = (L + 15) / 16 * 16;
-        const size_t need = (size_t)B * ldA * esz;
-        if (need > e->realign_bytes) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-                return fail(e, VAD_ERR_CAPTURE, "misaligned input needs scratch during capture");
-            HIP_TRY(e, hipDeviceSynchronize());
-            e->scratch_gen++;
-            if (e->d_realign) (void)hipFree(e->d_realign);
-            e->d_realign = nullptr;
-            e->realign_bytes = 0;
-            if (hipMalloc(&e->d_realign, need) != hipSuccess)
-                return fail(e, VAD_ERR_ALLOC, "cannot allocate realign scratch");
-            e->realign_bytes = need;
-        }
+        rc = grow(e, &e->d_realign, &e->realign_bytes, (size_t)B * ldA * esz, stream, "realign");
+        if (rc) return rc;
         HIP_TRY(e, hipMemcpy2DAsync(e->d_realign, ldA * esz, pcm, ld * esz, L * esz, B,
                                     hipMemcpyDeviceToDevice, stream));
         pcm = reinterpret_cast<const PcmT *>(e->d_realign);
         ld = ldA;
     }
+    // The last chunk is handed to the kernel as a zero-padded copy when it is partial -- or, with dec > 1, when its
+    // vector loads (which cover whole groups of dec raw samples) would run past the end of the row.
     const void *tail = nullptr;
-    if (L % N) {
-        const long rem = L - (T - 1) * N;
+    if (Ld % N || Ld * dec > L) {
+        const long rem = Ld - (T - 1) * N;               // samples of the last chunk at the net's rate
         HIP_TRY(e, hipMemsetAsync(e->d_tail, 0, (size_t)B * N * esz, stream));
-        HIP_TRY(e, hipMemcpy2DAsync(e->d_tail, N * esz, pcm + (T - 1) * N, ld * esz, rem * esz, B,
-                                    hipMemcpyDeviceToDevice, stream));
+        if (dec == 1)
+            HIP_TRY(e, hipMemcpy2DAsync(e->d_tail, N * esz, pcm + (T - 1) * N, ld * esz, rem * esz, B,
+                                        hipMemcpyDeviceToDevice, stream));
+        else
+            HIP_TRY(e, vad::launch_decimate<PcmT>(pcm + (T - 1) * N * dec, ld, reinterpret_cast<PcmT *>(e->d_tail), N,
+                                                  B, rem, dec, stream));
         tail = e->d_tail;
     }
     const long slab = e->slab_steps;
@@ -211,11 +186,12 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
         fa.tables = e->d_tables[ni];
         fa.pcm = pcm;
         fa.tail = tail;
-        fa.ld = ld; fa.L = L; fa.T = T; fa.t0 = t0; fa.nt = nt;
+        fa.ld = ld; fa.L = Ld; fa.T = T; fa.t0 = t0; fa.nt = nt;
         fa.ctx_in = ctx;
         fa.ctx_out = e->d_ctx_new;
         fa.gx = e->d_gx;
         fa.B = B;
+        fa.dec = dec;
         fa.trace = e->trace;
         vad::RecArgs ra{};
         ra.whh = e->split_rec ? reinterpret_cast<const float *>(e->d_whh_split[ni]) : e->d_whh[ni];
@@ -244,6 +220,44 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
     }
     HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return VAD_OK;
+}
+
+template <typename PcmT>
+int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld, float *ctx,
+                 float *state, float *probs, long ldp, void *stream_v) {
+    if (!e) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    if (B < 0 || L < 0 || (B > 0 && L > 0 && (!pcm || !ctx || !state || !probs)) || ld < L)
+        return fail(e, VAD_ERR_ARG, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (sr > 16000 && sr % 16000 == 0) {
+        // sample-rate front door: a multiple of 16 kHz is decimated to 16 kHz, x[:, ::sr/16000], exactly as the
+        // reference does (vad_annotator.py:104-112), and takes the 16 kHz path.  For 32 and 48 kHz the fp32 frontend
+        // does it while loading (no extra pass over HBM); other multiples, the f16x3 frontend and impl=reference
+        // go through a decimated copy in engine scratch.
+        if (B == 0 || L == 0) return VAD_OK;
+        const int k = sr / 16000;
+        HIP_TRY(e, hipSetDevice(e->device));
+        if (k <= 3 && !e->split && !e->impl_reference && e->fused_decimation)
+            return forward_core<PcmT>(e, 16000, k, B, L, pcm, ld, ctx, state, probs, ldp, stream);
+        const long Ld = (L + k - 1) / k, ldd = (Ld + 15) / 16 * 16;
+        int rc = grow(e, &e->d_decim, &e->decim_bytes, (size_t)B * ldd * sizeof(PcmT), stream, "decimation");
+        if (rc) return rc;
+        PcmT *dec = reinterpret_cast<PcmT *>(e->d_decim);
+        HIP_TRY(e, vad::launch_decimate<PcmT>(pcm, ld, dec, ldd, B, Ld, k, stream));
+        return forward_impl<PcmT>(e, 16000, B, Ld, dec, ldd, ctx, state, probs, ldp, stream_v);
+    }
+    const int ni = net_index(sr);
+    if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000] (or multiply of 16000)");
+    if (B == 0 || L == 0) return VAD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (e->impl_reference) {
+        const int N = sr == 16000 ? 512 : 256;
+        if (ldp < (L + N - 1) / N) return fail(e, VAD_ERR_ARG, "ldp < T");
+        HIP_TRY(e, vad::launch_ref_forward<PcmT>(e->ref[ni], sr, B, L, pcm, ld, ctx, state, probs, ldp, stream));
+        return VAD_OK;
+    }
+    return forward_core<PcmT>(e, sr, 1, B, L, pcm, ld, ctx, state, probs, ldp, stream);
 }
 
 template <typename T>
@@ -384,6 +398,10 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
     if (n == "precision_front" || n == "precision_rec") {   // bring-up: mix the two kernels
         if (v != "f16x3" && v != "fp32") return fail(e, VAD_ERR_OPTION, "precision must be f16x3|fp32");
         (n == "precision_front" ? e->split : e->split_rec) = (v == "f16x3");
+        return VAD_OK;
+    }
+    if (n == "fused_decimation") {                   // "0": always decimate into scratch first (A/B for tests)
+        e->fused_decimation = (v != "0");
         return VAD_OK;
     }
     if (n == "gx_cap_mib") {                         // scratch cap (MiB); inputs longer than it allows run in time slabs

@@ -65,37 +65,56 @@ __device__ __forceinline__ void cvt8(const u32x4 v, float *o) {       // 8 x int
         o[2 * k + 1] = (float)hi * (1.0f / 32768.0f);
     }
 }
-template <int SL>
+// s[i] = p[i * DEC], i < SL.  DEC > 1 is the sample-rate front door folded into the load: the reference decimates
+// 32 / 48 kHz input with x[:, ::DEC] (JIT!/vad/model/vad_annotator.py:104-112, src/silero_vad/utils_vad.py:39-42);
+// here the lane reads the DEC-times longer raw span with the same 16-byte vector loads and keeps every DEC-th
+// element (selection by compile-time index: no extra instructions beyond the loads).
+template <int SL, int DEC>
 __device__ __forceinline__ void load_vec(const float *p, float (&s)[SL]) {
 #pragma unroll
-    for (int k = 0; k < SL / 4; ++k) {
+    for (int k = 0; k < SL * DEC / 4; ++k) {
         const f32x4 v = VAD_NT_PCM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p) + k)
                                    : reinterpret_cast<const f32x4 *>(p)[k];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
+        for (int e = 0; e < 4; ++e)
+            if ((4 * k + e) % DEC == 0) s[(4 * k + e) / DEC] = v[e];
     }
 }
-template <int SL>
+template <int SL, int DEC>
 __device__ __forceinline__ void load_vec(const int16_t *p, float (&s)[SL]) {
+    if (DEC == 1) {
 #pragma unroll
-    for (int k = 0; k < SL / 8; ++k)
-        cvt8(VAD_NT_PCM ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p) + k)
-                        : reinterpret_cast<const u32x4 *>(p)[k], &s[8 * k]);
+        for (int k = 0; k < SL / 8; ++k)
+            cvt8(VAD_NT_PCM ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p) + k)
+                            : reinterpret_cast<const u32x4 *>(p)[k], &s[8 * k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SL * DEC / 8; ++k) {
+            const u32x4 v = reinterpret_cast<const u32x4 *>(p)[k];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if ((8 * k + e) % DEC == 0) {
+                    const unsigned w = v[e >> 1];
+                    const int x = (e & 1) ? (int)w >> 16 : (int)(w << 16) >> 16;
+                    s[(8 * k + e) / DEC] = (float)x * (1.0f / 32768.0f);
+                }
+        }
+    }
 }
 
 // slice V of the lane: s[i] = x[2Q*(2V+g) + i], x = ctx | chunk (| reflected tail for V==3,g==3).
 // Vector loads only: the engine guarantees 16-byte aligned rows, and hands the (zero padded) last
 // chunk of every stream in `tail` when L is not a multiple of the chunk size.
-template <int Q, int V, typename PcmT>
+template <int Q, int V, typename PcmT, int DEC>
 __device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a, const Lane &ln) {
     constexpr int SL = 2 * Q, N = 16 * Q;
     const PcmT *row = reinterpret_cast<const PcmT *>(a.pcm) + (size_t)ln.b * a.ld;
     const int sigma = 2 * V + ln.g;
     const int sg = (V == 3 && sigma > 8) ? 8 : sigma;
-    const long p0 = (long)SL * (8 * ln.t - 1 + sg);          // stream-absolute index of s[0]
-    const PcmT *src = row + p0;
-    const PcmT *esrc = row + ((long)N * ln.t + N - SL - 1);   // x[16Q-1], for the reflect pad
-    if (ln.from_tail) {                                       // wave-uniform
+    const long p0 = (long)SL * (8 * ln.t - 1 + sg);          // stream-absolute index of s[0] (in 16 / 8 kHz samples)
+    const PcmT *src = row + p0 * DEC;
+    const PcmT *esrc = row + ((long)N * ln.t + N - SL - 1) * DEC;   // x[16Q-1], for the reflect pad
+    if (ln.from_tail) {                                       // wave-uniform; the tail copy is already decimated
         const PcmT *trow = reinterpret_cast<const PcmT *>(a.tail) + (size_t)ln.b * N;
         if (sg > 0) src = trow + SL * (sg - 1);
         esrc = trow + (N - SL - 1);
@@ -119,8 +138,9 @@ __device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
         }
-    } else if (V == 0 && ln.t == 0 && ln.g == 0) load_vec<SL>(a.ctx_in + (size_t)ln.b * SL, s);
-    else load_vec<SL>(src, s);
+    } else if (V == 0 && ln.t == 0 && ln.g == 0) load_vec<SL, 1>(a.ctx_in + (size_t)ln.b * SL, s);
+    else if (DEC == 1 || (ln.from_tail && sg > 0)) load_vec<SL, 1>(src, s);
+    else load_vec<SL, DEC>(src, s);
     if (V == 3) {
         // context for the next call = last C = 2Q samples of the (zero padded) last chunk = slice 8
         if (a.ctx_out && ln.t == a.T - 1 && ln.g == 2 && ln.tile_valid &&
@@ -181,7 +201,7 @@ __device__ __forceinline__ void fft_inlane(f32x2 (&z)[Q]) {
 }
 
 // One frame (V) of 16 chunks: X[s] (s < Q): |Y[4s + P[g]]|;  X[Q]: |Y[4Q]| in group 0, 0 elsewhere.
-template <int Q, int V, typename PcmT>
+template <int Q, int V, typename PcmT, int DEC = 1>
 __device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, const float *tab_lds,
                                          const Lane &ln) {
     constexpr int SL = 2 * Q;
@@ -192,7 +212,7 @@ __device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, 
 #pragma unroll
         for (int i = 0; i < SL; ++i) s[i] = (float)(ln.lane + i) * 1e-3f;
     } else {
-        load_slice<Q, V, PcmT>(s, a, ln);
+        load_slice<Q, V, PcmT, DEC>(s, a, ln);
     }
     if (VAD_ABLATE & 2) {
 #pragma unroll

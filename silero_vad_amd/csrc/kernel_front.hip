@@ -198,7 +198,7 @@ __device__ __forceinline__ void relu(f32x4 (&acc)[M]) {
 #else
 #define TRACE(i) do {} while (0)
 #endif
-template <int Q, typename PcmT>
+template <int Q, typename PcmT, int DEC>
 __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
     using namespace vadl;
     constexpr Tab tb = make_tab(8 * Q, Q);
@@ -269,11 +269,11 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
 
     float X0[Q + 1], X1[Q + 1], X2[Q + 1], X3[Q + 1];
     TRACE(1);
-    fft_pass<Q, 0, PcmT>(X0, a, tab, ln);
+    fft_pass<Q, 0, PcmT, DEC>(X0, a, tab, ln);
     TRACE(2);
-    fft_pass<Q, 1, PcmT>(X1, a, tab, ln);
+    fft_pass<Q, 1, PcmT, DEC>(X1, a, tab, ln);
     TRACE(3);
-    fft_pass<Q, 2, PcmT>(X2, a, tab, ln);
+    fft_pass<Q, 2, PcmT, DEC>(X2, a, tab, ln);
     TRACE(4);
 
     auto bX0 = [&](int s) { return X0[s]; };
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
     ring.span += __builtin_readcyclecounter() - ring.last;
     ring.last = 0;
 #endif
-    fft_pass<Q, 3, PcmT>(X3, a, tab, ln);
+    fft_pass<Q, 3, PcmT, DEC>(X3, a, tab, ln);
     TRACE(6);
 
     // enc0 frame 2 -> enc1 out 1 tap 1
@@ -388,8 +388,12 @@ hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s) {
     if (a.B <= 0 || a.nt <= 0) return hipSuccess;
     const long nst = (a.B + 15) / 16, total = nst * a.nt;
     const unsigned grid = (unsigned)((total + 3) / 4);
-    if (sr == 16000) hipLaunchKernelGGL((front_kernel<32, PcmT>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((front_kernel<16, PcmT>), dim3(grid), dim3(256), 0, s, a);
+    // a.dec > 1: 32 / 48 kHz input, decimation folded into the loads (16 kHz net only)
+    if (sr == 16000 && a.dec == 2) hipLaunchKernelGGL((front_kernel<32, PcmT, 2>), dim3(grid), dim3(256), 0, s, a);
+    else if (sr == 16000 && a.dec == 3) hipLaunchKernelGGL((front_kernel<32, PcmT, 3>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.dec > 1) return hipErrorInvalidValue;
+    else if (sr == 16000) hipLaunchKernelGGL((front_kernel<32, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((front_kernel<16, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 template hipError_t launch_front<float>(int, const FrontArgs &, hipStream_t);

@@ -253,20 +253,47 @@ def test_sample_rate_front_door(model, oracle, golden, k):
         x = torch.from_numpy(np.stack([np.roll(src, -b * 3001)[:L] for b in range(B)])).to(dev).contiguous()
         xd = x[:, ::k].contiguous()
         outs = []
-        for inp, sr in ((x, 16000 * k), (xd, 16000)):
+        # raw input with decimation folded into the frontend's loads (fp32 default), raw input through the separate
+        # decimation pass, and the pre-decimated signal: all three must agree bit for bit
+        for inp, sr, fused in ((x, 16000 * k, "1"), (x, 16000 * k, "0"), (xd, 16000, "1")):
             ctx = torch.zeros((B, 64), device=dev)
             st = torch.zeros((2, B, 128), device=dev)
             p = torch.empty((B, T), device=dev)
-            _lib.check(eng._h, fn(eng._h, sr, B, inp.shape[1], inp.data_ptr(), inp.stride(0), ctx.data_ptr(),
-                                   st.data_ptr(), p.data_ptr(), T, None))
+            eng.set_option("fused_decimation", fused)
+            try:
+                _lib.check(eng._h, fn(eng._h, sr, B, inp.shape[1], inp.data_ptr(), inp.stride(0), ctx.data_ptr(),
+                                       st.data_ptr(), p.data_ptr(), T, None))
+            finally:
+                eng.set_option("fused_decimation", "1")
             torch.cuda.synchronize()
             outs.append((p.clone(), st.clone(), ctx.clone()))
-        for a, b in zip(*outs):
-            assert torch.equal(a, b)
+        for a, b, c in zip(*outs):
+            assert torch.equal(a, c) and torch.equal(b, c)
         xd_f = xd.cpu().numpy().astype(np.float32) / (32768.0 if xd.dtype == torch.int16 else 1.0)
         want, wctx, wst = oracle.forward_audio(xd_f, 16000)             # the oracle on the reference's x[:, ::k]
         assert np.abs(outs[0][0].cpu().numpy() - want).max() < TIGHT
         assert state_err(outs[0][1].cpu().numpy(), wst) < TOL and np.array_equal(outs[0][2].cpu().numpy(), wctx)
+    # lengths around the edge cases of the folded decimation: L % k != 0 with a full last chunk, one raw sample short
+    for L2 in (k * 3 * 512, k * 3 * 512 - 1, k * 3 * 512 - k, k * 2 * 512 + 1, k * 512):
+        x2 = torch.from_numpy(np.stack([np.roll(golden["16k"]["wav"], -b * 911)[:L2] for b in range(3)])).to(dev).contiguous()
+        T2 = ((L2 + k - 1) // k + 511) // 512
+        res = []
+        for fused in ("1", "0"):
+            ctx = torch.zeros((3, 64), device=dev)
+            st = torch.zeros((2, 3, 128), device=dev)
+            p = torch.empty((3, T2), device=dev)
+            eng.set_option("fused_decimation", fused)
+            try:
+                _lib.check(eng._h, _lib.lib().vad_forward_audio(eng._h, 16000 * k, 3, L2, x2.data_ptr(), x2.stride(0),
+                                                                ctx.data_ptr(), st.data_ptr(), p.data_ptr(), T2, None))
+            finally:
+                eng.set_option("fused_decimation", "1")
+            torch.cuda.synchronize()
+            res.append((p.clone(), st.clone(), ctx.clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b), L2
+        want, _, _ = oracle.forward_audio(x2[:, ::k].cpu().numpy(), 16000)
+        assert np.abs(res[0][0].cpu().numpy() - want).max() < TIGHT
     # one step: a 512 k-sample chunk
     x = torch.from_numpy(np.stack([np.roll(golden["16k"]["wav"], -b * 77)[:512 * k] for b in range(B)])).to(dev)
     res = []
