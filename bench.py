@@ -130,15 +130,19 @@ def cpu_baseline(sr, budget_s=24.0):
     """The reference's CPU path on this box: oracle/aten_port.py issues the ATen operators the TorchScript model
     dispatches to (bit-identical to it on the goldens, tests/test_oracle.py) under the reference's threading and
     timing rules.  Runs in its own CPU-only process (it forks one worker per core for protocol R4)."""
-    r = subprocess.run([sys.executable, "-m", "oracle.aten_port", "--sr", str(sr), "--budget-s", str(budget_s)],
-                       cwd=str(ROOT), capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
-    line = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
+    try:        # every protocol runs in its own process with its own time limit (oracle/aten_port.py baseline())
+        r = subprocess.run([sys.executable, "-m", "oracle.aten_port", "--sr", str(sr), "--budget-s", str(budget_s)],
+                           cwd=str(ROOT), capture_output=True, text=True, timeout=8 * budget_s + 240,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        line = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
+        err = (r.stderr or r.stdout)[-400:]
+    except subprocess.TimeoutExpired as e:
+        line, err = None, f"timed out: {e}"
     if line is None:
-        return {"value": None, "unit": "chunks/s", "kind": "aten-port", "error": (r.stderr or r.stdout)[-400:]}
+        return {"value": None, "unit": "chunks/s", "kind": "aten-port", "error": err}
     d = json.loads(line)
-    return {"value": d["value"], "unit": "chunks/s", "cores": d["nproc"], "kind": "aten-port",
-            "best_protocol": d["best"], "cpu_model": d["cpu_model"], "torch": d["torch"],
+    return {"value": d["value"], "unit": "chunks/s", "cores": d["nproc"], "affinity_cpus": d["affinity_cpus"],
+            "kind": "aten-port", "best_protocol": d["best"], "cpu_model": d["cpu_model"], "torch": d["torch"],
             "runs": d["runs"],
             "sample": f"same {sr // 1000} kHz synthetic workload (0.03 N(0,1)), audio_forward over B streams x T chunks "
                       f"per run as listed under runs; warm-up {d['warmup']}, median of {d['trials']}; R1 = 1 thread B=1 "

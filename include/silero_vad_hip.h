@@ -168,11 +168,13 @@ long vad_segment_probs_batch(const float *probs, long ldp, long n_streams, const
  * stream, so that only the segment lists cross PCIe (16 B per segment) instead of every probability, and the host
  * does no per-chunk work (the reference does it in a Python loop per file: utils_vad.py:348-440).  All pointers
  * are DEVICE pointers except `p`.  n_chunks may be NULL: every stream then has n_chunks_all (<= ldp) entries.
+ * row_offsets may be NULL: stream i's probabilities then start at probs[i * ldp]; otherwise at probs[row_offsets[i]]
+ * (ragged rows packed back to back, as the continuous-refill scheduler leaves them).
  * Stream i's segments go to out[i * cap_per_stream ...], their number (may exceed cap_per_stream: grow and call
  * again) to counts[i].  Asynchronous on `stream`.  Same results as vad_segment_probs_batch, bit for bit (one
  * source, csrc/scanner.hpp).                                                                        */
-int  vad_segment_probs_device(vad_engine *e, const float *probs, long ldp, long n_streams, const long *n_chunks,
-                              long n_chunks_all, const long *audio_len, const vad_segment_params *p,
+int  vad_segment_probs_device(vad_engine *e, const float *probs, long ldp, const long *row_offsets, long n_streams,
+                              const long *n_chunks, long n_chunks_all, const long *audio_len, const vad_segment_params *p,
                               vad_segment *out, long cap_per_stream, long *counts, void *stream);
 
 /* ---- host-side ingest ---------------------------------------------------------------------------------

@@ -126,6 +126,25 @@ class AtenVAD:
 
 
 # ---- the CPU baseline bench.py reports ---------------------------------------------------------------------
+def effective_cpus():
+    """Host cores this process may really use: the affinity mask, cut down by a cgroup CPU quota if there is one
+    (a container may show 256 CPUs in its mask and be throttled to a fraction of them; sizing thread pools by the mask
+    then oversubscribes the quota and OpenMP's spinning workers make things pathologically slow)."""
+    n = len(os.sched_getaffinity(0))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            q, per = parse(open(path).read())
+            if per is None:
+                per = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if q not in ("max", "-1"):
+                n = max(1, min(n, int(float(q) / float(per))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 def _timed_forward(model, pcm, sr, warmup, trials):
     """examples/onnx_sequence/run.py:172-194: warm-up runs, then `trials` timed runs; returns the median seconds."""
     for _ in range(warmup):
@@ -144,18 +163,59 @@ def _synth(B, T, sr, seed):
     return 0.03 * torch.randn((B, T * n), generator=g)            # run.py:159-162
 
 
-def _worker(args):
-    sr, B, T, warmup, trials, seed = args
-    torch.set_num_threads(1)
+def _measure(sr, B, threads, share_s, warmup, trials, seed):
+    """chunks/s of audio_forward over B streams: T is sized from a one-step calibration so that a run takes about
+    share_s / (warmup + trials) seconds."""
+    torch.set_num_threads(threads)
     m = AtenVAD()
+    m.audio_forward(_synth(B, 1, sr, seed), sr)                     # first touch (allocations, thread pool)
+    t0 = time.perf_counter()
+    m.audio_forward(_synth(B, 2, sr, seed), sr)
+    per_step = (time.perf_counter() - t0) / 2
+    T = int(max(2, min(256, share_s / (warmup + trials) / max(per_step, 1e-6))))
     dt = _timed_forward(m, _synth(B, T, sr, seed), sr, warmup, trials)
-    return B * T / dt
+    return B * T / dt, T
+
+
+def _worker(args):
+    sr, B, share_s, warmup, trials, seed = args
+    return _measure(sr, B, 1, share_s, warmup, trials, seed)
+
+
+def run_protocol(name, sr, share_s, trials=5, warmup=3):
+    """One of R1..R4 of BASELINE.md section 3 / SURVEY.md section 8(d) "CPU baseline beside it"."""
+    ncpu = effective_cpus()
+    if name == "R1_1thread_B1":                       # the reference's shipped default (src/silero_vad/model.py:3)
+        rate, T = _measure(sr, 1, 1, share_s, warmup, trials, 1)
+        return {"chunks_per_s": round(rate, 1), "B": 1, "T": T, "threads": 1}
+    if name == "R2_1thread_B4096":
+        rate, T = _measure(sr, 4096, 1, share_s, warmup, trials, 2)
+        return {"chunks_per_s": round(rate, 1), "B": 4096, "T": T, "threads": 1}
+    if name == "R3_nproc_threads_B4096":
+        rate, T = _measure(sr, 4096, ncpu, share_s, warmup, trials, 3)
+        return {"chunks_per_s": round(rate, 1), "B": 4096, "T": T, "threads": ncpu}
+    if name == "R4_nproc_procs_1thread":
+        # one model per worker process, one thread each (examples/parallel_example.ipynb cells 5, 7); every worker owns a
+        # slice of the same 4096 streams.  fork: this process has not run a multi-threaded region nor touched a GPU.
+        import multiprocessing as mp
+        torch.set_num_threads(1)
+        Bp = max(1, 4096 // ncpu)
+        with mp.get_context("fork").Pool(ncpu) as pool:
+            res = pool.map(_worker, [(sr, Bp, share_s, warmup, trials, 100 + i) for i in range(ncpu)])
+        return {"chunks_per_s": round(sum(r[0] for r in res), 1), "B_per_proc": Bp, "T": res[0][1], "procs": ncpu,
+                "threads": 1}
+    raise ValueError(name)
+
+
+PROTOCOLS = ("R1_1thread_B1", "R2_1thread_B4096", "R3_nproc_threads_B4096", "R4_nproc_procs_1thread")
 
 
 def baseline(sr=16000, budget_s=25.0, trials=5, warmup=3):
-    """R1..R4 of BASELINE.md section 3 / SURVEY.md section 8(d) "CPU baseline beside it"."""
-    nproc = len(os.sched_getaffinity(0))
-    out = {"nproc": nproc, "torch": torch.__version__, "trials": trials, "warmup": warmup,
+    """All four protocols, each in its own CPU-only process with a hard time limit: a protocol that misbehaves on
+    some host (oversubscribed thread pool, ...) is reported as an error instead of taking the benchmark down."""
+    import subprocess
+    out = {"nproc": effective_cpus(), "affinity_cpus": len(os.sched_getaffinity(0)), "torch": torch.__version__,
+           "trials": trials, "warmup": warmup,
            "protocol": "examples/onnx_sequence/run.py:172-194 (median of trials after warm-up); "
                        "audio_forward = T sequential forward() calls, vad_annotator.py:128-156"}
     try:
@@ -163,41 +223,23 @@ def baseline(sr=16000, budget_s=25.0, trials=5, warmup=3):
         out["cpu_model"] = cpu[0] if cpu else "unknown"
     except OSError:
         out["cpu_model"] = "unknown"
-    share = budget_s / 4.0 / (warmup + trials)                     # seconds per run and protocol
-    m = AtenVAD()
+    share = budget_s / len(PROTOCOLS)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_WAIT_POLICY="passive",
+               KMP_BLOCKTIME="0", GOMP_SPINCOUNT="0")
     res = {}
-
-    def sized(B, rate_guess):
-        return max(2, min(256, int(rate_guess * share / B)))
-
-    # R1: 1 thread, B = 1 (the reference's shipped default, model.py:3)
-    torch.set_num_threads(1)
-    T = sized(1, 2000.0)
-    res["R1_1thread_B1"] = {"chunks_per_s": round(T / _timed_forward(m, _synth(1, T, sr, 1), sr, warmup, trials), 1),
-                            "B": 1, "T": T, "threads": 1}
-    # R2: 1 thread, B = 4096
-    T = sized(4096, 30000.0)
-    res["R2_1thread_B4096"] = {"chunks_per_s": round(4096 * T / _timed_forward(m, _synth(4096, T, sr, 2), sr, warmup, trials), 1),
-                               "B": 4096, "T": T, "threads": 1}
-    # R3: nproc threads, B = 4096
-    torch.set_num_threads(nproc)
-    T = sized(4096, 30000.0 * min(nproc, 16))
-    res["R3_nproc_threads_B4096"] = {"chunks_per_s": round(4096 * T / _timed_forward(m, _synth(4096, T, sr, 3), sr, warmup, trials), 1),
-                                     "B": 4096, "T": T, "threads": nproc}
-    torch.set_num_threads(1)
-    # R4: nproc processes x 1 thread, one model each (examples/parallel_example.ipynb cells 5, 7); every worker
-    # owns a slice of the same 4096 streams (at least 1).  fork: this process never touched a GPU runtime.
-    import multiprocessing as mp
-    Bp = max(1, 4096 // nproc)
-    T = sized(Bp, 2000.0 * min(Bp, 16))
-    with mp.get_context("fork").Pool(nproc) as pool:
-        rates = pool.map(_worker, [(sr, Bp, T, warmup, trials, 100 + i) for i in range(nproc)])
-    res["R4_nproc_procs_1thread"] = {"chunks_per_s": round(sum(rates), 1), "B_per_proc": Bp, "T": T,
-                                     "procs": nproc, "threads": 1}
+    for name in PROTOCOLS:
+        try:
+            r = subprocess.run([sys.executable, "-m", "oracle.aten_port", "--sr", str(sr), "--protocol", name,
+                                "--share-s", str(share)], cwd=str(HERE.parent), env=env, capture_output=True,
+                               text=True, timeout=4 * share + 45)
+            line = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
+            res[name] = json.loads(line) if line else {"error": (r.stderr or "no output")[-300:]}
+        except subprocess.TimeoutExpired:
+            res[name] = {"error": f"timed out after {4 * share + 45:.0f} s"}
     out["runs"] = res
-    best = max(res, key=lambda k: res[k]["chunks_per_s"])
-    out["best"] = best
-    out["value"] = res[best]["chunks_per_s"]
+    ok = {k: v for k, v in res.items() if "chunks_per_s" in v}
+    out["best"] = max(ok, key=lambda k: ok[k]["chunks_per_s"]) if ok else None
+    out["value"] = ok[out["best"]]["chunks_per_s"] if ok else None
     return out
 
 
@@ -205,6 +247,10 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--sr", type=int, default=16000)
     ap.add_argument("--budget-s", type=float, default=25.0)
+    ap.add_argument("--protocol", default=None)
+    ap.add_argument("--share-s", type=float, default=6.0)
     a = ap.parse_args()
-    sys.path.insert(0, str(HERE.parent))
-    print(json.dumps(baseline(a.sr, a.budget_s)))
+    if a.protocol:
+        print(json.dumps(run_protocol(a.protocol, a.sr, a.share_s)))
+    else:
+        print(json.dumps(baseline(a.sr, a.budget_s)))

@@ -54,7 +54,7 @@ SYMBOLS = {
     "vad_segment_probs_batch": (c_long, [f32p, c_long, c_long, POINTER(c_long), POINTER(c_long),
                                          POINTER(SegmentParams), POINTER(Segment), c_long,
                                          POINTER(c_long), c_int]),
-    "vad_segment_probs_device": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_void_p,
+    "vad_segment_probs_device": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p,
                                          POINTER(SegmentParams), c_void_p, c_long, c_void_p, c_void_p]),
     "vad_stage_rows": (c_int, [POINTER(c_void_p), POINTER(c_long), c_long, c_long, c_size_t, c_void_p, c_int]),
     "vad_debug_packed_floats": (c_long, [c_void_p, c_int, c_int]),

@@ -70,9 +70,10 @@ hipError_t launch_rec_split(int sr, const RecArgs &a, hipStream_t s);
 // one v_mfma_f32_16x16x32_f16: a, b device [64 lanes][8 halves], d device [64 lanes][4 floats]
 hipError_t launch_mfma_f16_probe(const void *a, const void *b, float *d, hipStream_t s);
 
-// Segmenter on the device (kernel_scan.hip): lane i scans probs[i * ldp ...], n_chunks[i] entries (or n_chunks_all
-// if n_chunks is null), writes its segments to out[i * cap ...] and their number (may exceed cap) to counts[i].
-hipError_t launch_scan(const float *probs, long ldp, long n_streams, const long *n_chunks, long n_chunks_all,
+// Segmenter on the device (kernel_scan.hip): lane i scans probs[i * ldp ...] (or probs[row_off[i] ...] if row_off is
+// not null), n_chunks[i] entries (or n_chunks_all if n_chunks is null), writes its segments to out[i * cap ...] and
+// their number (may exceed cap) to counts[i].
+hipError_t launch_scan(const float *probs, long ldp, const long *row_off, long n_streams, const long *n_chunks, long n_chunks_all,
                        const long *audio_len, const vad_segment_params &p, vad_segment *out, long cap, long *counts,
                        hipStream_t s);
 

@@ -439,7 +439,8 @@ int vad_forward_audio_i16(vad_engine *e, int sr, int B, long L, const int16_t *p
     return forward_impl<int16_t>(e, sr, B, L, pcm, ld, ctx, state, probs, ldp, stream);
 }
 
-int vad_segment_probs_device(vad_engine *e, const float *probs, long ldp, long n_streams, const long *n_chunks,
+int vad_segment_probs_device(vad_engine *e, const float *probs, long ldp, const long *row_offsets, long n_streams,
+                             const long *n_chunks,
                              long n_chunks_all, const long *audio_len, const vad_segment_params *p,
                              vad_segment *out, long cap_per_stream, long *counts, void *stream) {
     if (!e) return VAD_ERR_ARG;
@@ -449,9 +450,9 @@ int vad_segment_probs_device(vad_engine *e, const float *probs, long ldp, long n
         return fail(e, VAD_ERR_ARG, "bad argument");
     if (p->sampling_rate != 8000 && p->sampling_rate != 16000)
         return fail(e, VAD_ERR_SAMPLE_RATE, "Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates");
-    if (!n_chunks && n_chunks_all > ldp) return fail(e, VAD_ERR_ARG, "n_chunks_all > ldp");
+    if (!n_chunks && !row_offsets && n_chunks_all > ldp) return fail(e, VAD_ERR_ARG, "n_chunks_all > ldp");
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, vad::launch_scan(probs, ldp, n_streams, n_chunks, n_chunks_all, audio_len, *p, out, cap_per_stream,
+    HIP_TRY(e, vad::launch_scan(probs, ldp, row_offsets, n_streams, n_chunks, n_chunks_all, audio_len, *p, out, cap_per_stream,
                                 counts, (hipStream_t)stream));
     return VAD_OK;
 }

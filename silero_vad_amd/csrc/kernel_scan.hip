@@ -16,14 +16,14 @@
 namespace vad {
 namespace {
 
-__global__ void __launch_bounds__(64) scan_kernel(const float *probs, long ldp, long n_streams, const long *n_chunks,
+__global__ void __launch_bounds__(64) scan_kernel(const float *probs, long ldp, const long *row_off, long n_streams, const long *n_chunks,
                                                   long n_chunks_all, const long *audio_len, vad_segment_params p,
                                                   vad_segment *out, long cap, long *counts) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_streams) return;
     const long n = n_chunks ? n_chunks[i] : n_chunks_all;
     Scanner sc(p, audio_len[i], out + i * cap, cap);
-    const float *row = probs + i * ldp;
+    const float *row = probs + (row_off ? row_off[i] : i * ldp);
     long t = 0;
     if ((((size_t)row) & 15) == 0) {
         for (; t + 4 <= n; t += 4) {
@@ -40,11 +40,11 @@ __global__ void __launch_bounds__(64) scan_kernel(const float *probs, long ldp, 
 
 }  // namespace
 
-hipError_t launch_scan(const float *probs, long ldp, long n_streams, const long *n_chunks, long n_chunks_all,
+hipError_t launch_scan(const float *probs, long ldp, const long *row_off, long n_streams, const long *n_chunks, long n_chunks_all,
                        const long *audio_len, const vad_segment_params &p, vad_segment *out, long cap, long *counts,
                        hipStream_t s) {
     if (n_streams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)((n_streams + 63) / 64)), dim3(64), 0, s, probs, ldp, n_streams,
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)((n_streams + 63) / 64)), dim3(64), 0, s, probs, ldp, row_off, n_streams,
                        n_chunks, n_chunks_all, audio_len, p, out, cap, counts);
     return hipGetLastError();
 }

@@ -18,6 +18,7 @@
   src/silero_vad/utils_vad.py:507-549) for all slots of a pool at once, vectorised on the host.
 """
 import collections
+import contextlib
 import ctypes
 import time
 from typing import List, Sequence
@@ -328,13 +329,17 @@ def _segment_params(sampling_rate=16000, threshold=0.5, neg_threshold=None, min_
     return p
 
 
-def _device_scan(engine, probs_dev, n_chunks_dev, audio_len_dev, params, cap):
-    """Enqueue the GPU scan of probs_dev[B, T] on the current stream -> (counts[B], segs[B, cap, 2]) int64, device."""
+def _device_scan(engine, probs_dev, n_chunks_dev, audio_len_dev, params, cap, row_offsets=None):
+    """Enqueue the GPU scan of probs_dev[B, T] on the current stream -> (counts[B], segs[B, cap, 2]) int64, device.
+    With `row_offsets` (device int64[B]) stream i's probabilities start at probs_dev.flatten()[row_offsets[i]]."""
     B, T = probs_dev.shape
+    if row_offsets is not None:
+        B = row_offsets.shape[0]
     counts = torch.empty((B,), dtype=torch.int64, device=probs_dev.device)
     segs = torch.empty((B, max(cap, 1), 2), dtype=torch.int64, device=probs_dev.device)
     _lib.check(engine._h, lib().vad_segment_probs_device(
-        engine._h, probs_dev.data_ptr(), probs_dev.stride(0) if B > 1 else T, B,
+        engine._h, probs_dev.data_ptr(), probs_dev.stride(0) if probs_dev.shape[0] > 1 else T,
+        row_offsets.data_ptr() if row_offsets is not None else None, B,
         n_chunks_dev.data_ptr() if n_chunks_dev is not None else None, T, audio_len_dev.data_ptr(),
         ctypes.byref(params), segs.data_ptr(), segs.shape[1], counts.data_ptr(),
         ctypes.c_void_p(torch.cuda.current_stream(probs_dev.device).cuda_stream)))
@@ -397,6 +402,198 @@ def segment_probs_batch(probs: torch.Tensor, n_chunks, audio_lengths, sampling_r
             break
         cap = int(counts.max())
     return [[{"start": int(s), "end": int(e)} for s, e in segs[i, : counts[i]]] for i in range(B)]
+
+
+# ---- offline: continuous refill ------------------------------------------------------------------------------------
+class RefillPlan:
+    """A fixed number of stream slots, processed in time slabs of `slab_chunks` chunks; a slot whose recording ends
+    inside a slab is handed the next recording at the following slab boundary (state and context reset) instead of
+    idling until the longest member of a bucket is done.  This is the reference's padded lock-step batch
+    (`SileroVadPadder`, tuning/utils.py:146-160; bounded blocks, examples/onnx_sequence/run.py:34-56) with rows
+    retired and re-admitted: the waste per recording is below one slab, whatever the spread of the lengths.
+
+    The schedule depends on the lengths only, so it is computed up front: `slabs` is a list of
+    (slot, recording, first_sample, n_samples, reset) tuples per slab.  Recordings are admitted longest first."""
+
+    def __init__(self, lengths: Sequence[int], slots: int, slab_chunks: int, chunk: int):
+        self.lengths = [int(n) for n in lengths]
+        self.slots, self.slab_chunks, self.chunk = int(slots), int(slab_chunks), int(chunk)
+        if self.slots < 1 or self.slab_chunks < 1:
+            raise ValueError("slots and slab_chunks must be positive")
+        width = self.slab_chunks * self.chunk
+        queue = sorted((i for i, n in enumerate(self.lengths) if n > 0), key=lambda i: -self.lengths[i])
+        self.empty = [i for i, n in enumerate(self.lengths) if n <= 0]
+        cur = [None] * self.slots                      # (recording, next sample) per slot
+        self.slabs: List[list] = []
+        qi = 0
+        while True:
+            entries = []
+            for sl in range(self.slots):
+                reset = False
+                if cur[sl] is None and qi < len(queue):
+                    cur[sl] = (queue[qi], 0)
+                    qi += 1
+                    reset = True
+                if cur[sl] is None:
+                    continue
+                rec, at = cur[sl]
+                take = min(width, self.lengths[rec] - at)
+                entries.append((sl, rec, at, take, reset))
+                cur[sl] = (rec, at + take) if at + take < self.lengths[rec] else None
+            if not entries:
+                break
+            self.slabs.append(entries)
+
+    def n_chunks(self, i: int) -> int:
+        return (self.lengths[i] + self.chunk - 1) // self.chunk
+
+    def padded_chunks(self) -> int:
+        return len(self.slabs) * self.slots * self.slab_chunks
+
+    def real_chunks(self) -> int:
+        return sum(self.n_chunks(i) for i in range(len(self.lengths)) if self.lengths[i] > 0)
+
+
+def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int = 1024, slab_chunks: int = 32,
+                 plan: RefillPlan = None, _keep_on_device: bool = False):
+    """Speech probabilities of many recordings of different lengths through `slots` persistent stream slots
+    (RefillPlan).  Returns one 1-D CPU float tensor per recording, bit-identical to
+    ``model.audio_forward(audio[None], sr)[0]``: the state and context a slot carries from slab to slab are exactly
+    what a single call carries from chunk to chunk, and a re-admitted slot starts from zeros like `reset_states()`.
+    Staging of slab k+1 (native threaded copy into pinned memory + H2D on a side stream) overlaps the kernels of
+    slab k.  `audios`: float tensors in [-1, 1] or int16 PCM (all of one kind)."""
+    n = chunk_size(sampling_rate)
+    eng = model.engine
+    dev = torch.device(getattr(eng, "torch_device", None) or torch.device("cuda", eng.device))
+    on_gpu = dev.type == "cuda"
+    as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
+    dtype, esz = (torch.int16, 2) if as_i16 else (torch.float32, 4)
+    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
+    slots = max(1, min(int(slots), sum(1 for m in lengths if m > 0)))
+    plan = plan or RefillPlan(lengths, slots, slab_chunks, n)
+    B, S, width = plan.slots, plan.slab_chunks, plan.slab_chunks * n
+    host_audio = []
+    for a in audios:                                   # contiguous CPU tensors of one dtype (views are fine)
+        a = a if torch.is_tensor(a) else torch.as_tensor(a)
+        if a.dim() != 1:
+            raise ValueError("More than one dimension in audio. Are you trying to process audio with 2 channels?")
+        if a.dtype != dtype or not a.is_contiguous() or a.is_cuda:
+            if as_i16:
+                raise TypeError("mixed int16 / float recordings in one call")
+            a = a.to("cpu", dtype).contiguous()
+        host_audio.append(a)
+    base = np.zeros(len(audios) + 1, dtype=np.int64)   # recording i owns out_flat[base[i] : base[i] + n_chunks(i)]
+    for i in range(len(audios)):
+        base[i + 1] = base[i] + (plan.n_chunks(i) if lengths[i] > 0 else 0)
+    total = int(base[-1])
+    out_flat = torch.zeros(total + 1, dtype=torch.float32, device=dev)      # [+1]: sink for the padding chunks
+    ctx = torch.zeros((B, n // 8), dtype=torch.float32, device=dev)
+    state = torch.zeros((2, B, 128), dtype=torch.float32, device=dev)
+    done = np.zeros(len(audios), dtype=np.int64)       # chunks of each recording already produced
+    cols = np.arange(S, dtype=np.int64)[None, :]
+    ctxm = contextlib.nullcontext() if not on_gpu else torch.cuda.device(dev)
+    with ctxm:
+        if on_gpu:
+            pool = getattr(model, "_stage_pool", None)
+            if pool is None:
+                pool = model._stage_pool = _StagePool(dev)
+            cur = torch.cuda.current_stream(dev)
+        STATS["padded"] += plan.padded_chunks() * n
+        STATS["real"] += sum(m for m in lengths if m > 0)
+
+        def stage(k):
+            entries = plan.slabs[k]
+            rows = (ctypes.c_void_p * B)()
+            lens = (ctypes.c_long * B)()
+            dst = np.full((B, S), total, dtype=np.int64)                  # default: the sink
+            resets = []
+            for sl, rec, at, take, reset in entries:
+                rows[sl] = host_audio[rec].data_ptr() + at * esz
+                lens[sl] = take
+                nck = (take + n - 1) // n
+                dst[sl, :nck] = base[rec] + done[rec] + cols[0, :nck]
+                done[rec] += nck
+                if reset:
+                    resets.append(sl)
+            nbytes = B * width * esz
+            t0 = time.perf_counter()
+            if on_gpu:
+                i = pool.get(k, nbytes)
+                host = pool.host[i][:nbytes].view(dtype).view(B, width)
+            else:
+                i, host = 0, torch.empty((B, width), dtype=dtype)
+            rc = lib().vad_stage_rows(rows, lens, B, width, esz, host.data_ptr(), 0)
+            if rc:
+                raise _lib.VadError(rc, "vad_stage_rows")
+            STATS["stage_s"] += time.perf_counter() - t0
+            STATS["buckets"] += 1
+            idx = torch.from_numpy(dst.reshape(-1))
+            rs = torch.tensor(resets, dtype=torch.int64)
+            if not on_gpu:
+                return host, None, i, idx, rs
+            STATS["h2d_bytes"] += nbytes
+            d = pool.dev[i][:nbytes].view(dtype).view(B, width)
+            if pool.consumed[i] is not None:
+                pool.stream.wait_event(pool.consumed[i])
+            with torch.cuda.stream(pool.stream):
+                d.copy_(host, non_blocking=True)
+                idx_d = idx.pin_memory().to(dev, non_blocking=True)
+                rs_d = rs.pin_memory().to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(pool.stream)
+            pool.done[i] = ev
+            return d, ev, i, idx_d, rs_d
+
+        staged = stage(0) if plan.slabs else None
+        for k in range(len(plan.slabs)):
+            x, ev, slot, idx, rs = staged
+            if on_gpu:
+                cur.wait_event(ev)
+                for t in (x, idx, rs):
+                    t.record_stream(cur)
+            if rs.numel():                                                # re-admitted slots start like reset_states()
+                ctx.index_fill_(0, rs, 0.0)
+                state.index_fill_(1, rs, 0.0)
+            probs = eng.forward_audio(x, sampling_rate, ctx, state)     # [B, S], carried ctx/state updated in place
+            out_flat.index_put_((idx,), probs.reshape(-1))
+            if on_gpu:
+                pool.consumed[slot] = torch.cuda.Event()
+                pool.consumed[slot].record(cur)
+            staged = stage(k + 1) if k + 1 < len(plan.slabs) else None   # CPU packs k+1 meanwhile
+    if _keep_on_device:
+        return out_flat, base, plan
+    flat = out_flat.cpu()
+    return [flat[base[i]:base[i + 1]].clone() for i in range(len(audios))]
+
+
+def refill_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, slots: int = 1024,
+                           slab_chunks: int = 32, **scan_kw) -> List[list]:
+    """`ragged_speech_segments` over the continuous-refill scheduler: probabilities never leave the GPU; when the last
+    slab is done one device scan (vad_segment_probs_device with per-recording row offsets) turns them into segment
+    lists, which is all that crosses PCIe on the way back."""
+    n = chunk_size(sampling_rate)
+    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
+    flat, base, plan = refill_probs(audios, model, sampling_rate, slots, slab_chunks, _keep_on_device=True)
+    if flat.device.type != "cuda":                                        # CPU stand-in engines (tests)
+        probs = [flat[base[i]:base[i + 1]] for i in range(len(audios))]
+        from .timestamps import segment_probs
+        return [segment_probs(p, m, sampling_rate, **scan_kw) if m > 0 else [] for p, m in zip(probs, lengths)]
+    params = _segment_params(sampling_rate, **scan_kw)
+    nck = torch.from_numpy(np.diff(base))
+    meta = torch.stack([nck, torch.tensor(lengths, dtype=torch.int64), torch.from_numpy(base[:-1].copy())]).to(flat.device)
+    t0 = time.perf_counter()
+    cap = 32
+    while True:
+        counts, segs = _device_scan(model.engine, flat[None], meta[0], meta[1], params, cap, row_offsets=meta[2])
+        cnt = counts.cpu().numpy()
+        if len(cnt) == 0 or int(cnt.max()) <= cap:
+            break
+        cap = int(cnt.max())
+    m = int(cnt.max()) if len(cnt) else 0
+    sg = segs[:, :max(m, 1)].cpu().numpy()
+    STATS["scan_s"] += time.perf_counter() - t0
+    STATS["d2h_bytes"] += sg.nbytes + cnt.nbytes
+    return [[{"start": int(a), "end": int(b)} for a, b in sg[i, : cnt[i]]] for i in range(len(audios))]
 
 
 # ---- live streams --------------------------------------------------------------------------------------

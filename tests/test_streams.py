@@ -111,3 +111,63 @@ def test_batch_vad_iterator_equals_reference_iterator_per_stream(built, sr):
     bit.reset()
     bit.feed(probs[:, 0], active=[True, False] * 3)
     assert list(bit.current_sample) == [win, 0] * 3
+
+
+# ---- continuous refill ---------------------------------------------------------------------------------------------
+def test_refill_plan_covers_every_sample_once():
+    from silero_vad_amd import RefillPlan
+    rng = np.random.default_rng(4)
+    lengths = [int(v) for v in rng.integers(1, 40000, size=57)] + [0, 512, 511, 513]
+    for slots, slab in ((1, 3), (5, 4), (8, 32), (100, 2)):
+        plan = RefillPlan(lengths, slots, slab, 512)
+        width = slab * 512
+        seen = {i: 0 for i, m in enumerate(lengths) if m > 0}
+        busy_prev = {}
+        for entries in plan.slabs:
+            assert len({e[0] for e in entries}) == len(entries) <= slots           # one recording per slot and slab
+            for sl, rec, at, take, reset in entries:
+                assert at == seen[rec] and 0 < take <= width                          # in order, no gaps
+                assert reset == (at == 0)
+                if not reset:
+                    assert busy_prev.get(sl) == rec and at % width == 0              # stays in its slot
+                seen[rec] += take
+            busy_prev = {e[0]: e[1] for e in entries}
+        assert all(seen[i] == lengths[i] for i in seen)
+        assert plan.empty == [i for i, m in enumerate(lengths) if m == 0]
+        # a slot idles for less than one slab per recording it serves (+ the drain at the very end)
+        assert plan.padded_chunks() >= plan.real_chunks()
+
+
+@pytest.mark.parametrize("sr", [16000, 8000])
+def test_refill_equals_one_recording_at_a_time(oracle, sr):
+    """The scheduler's carried state / per-slot reset protocol, driven with the oracle behind the engine's Python
+    surface (tests/replay_engine.py): every recording must get exactly the probabilities of its own audio_forward."""
+    from replay_engine import ReplayEngine
+    from silero_vad_amd import refill_probs, refill_speech_segments
+    from silero_vad_amd.engine import HipSileroVAD
+    from silero_vad_amd.timestamps import segment_probs
+    n = 512 if sr == 16000 else 256
+    rng = np.random.default_rng(12)
+    lens = [int(v) for v in rng.integers(1, 30 * n, size=21)] + [n, 2 * n, n - 1, 0]
+    t = np.arange(30 * n + 5) / sr
+    base = (0.3 * np.sin(2 * np.pi * 200 * t) * (np.sin(2 * np.pi * 1.5 * t) > 0) + 0.02 * rng.standard_normal(len(t))).astype(np.float32)
+    audios = [torch.from_numpy(np.roll(base, -37 * i)[:m].copy()) for i, m in enumerate(lens)]
+    model = HipSileroVAD(engine=ReplayEngine(oracle))
+    for slots, slab in ((4, 3), (7, 8)):
+        got = refill_probs(audios, model, sr, slots=slots, slab_chunks=slab)
+        for a, p in zip(audios, got):
+            if len(a) == 0:
+                assert p.numel() == 0
+                continue
+            want = oracle.audio_forward(np.pad(a.numpy(), (0, max(0, n - len(a))))[None], sr)[0]
+            assert p.shape == want.shape and np.abs(p.numpy() - want).max() < 1e-6
+    segs = refill_speech_segments(audios, model, sr, slots=5, slab_chunks=4, threshold=0.4, min_speech_duration_ms=64)
+    for a, sg, p in zip(audios, segs, got):
+        assert sg == (segment_probs(p, len(a), sr, threshold=0.4, min_speech_duration_ms=64) if len(a) else [])
+    # int16 ingest takes the same route
+    a16 = [(a * 32767).to(torch.int16) for a in audios]
+    g16 = refill_probs(a16, model, sr, slots=6, slab_chunks=5)
+    for a, p in zip(a16, g16):
+        if len(a):
+            want = oracle.audio_forward(np.pad(a.numpy().astype(np.float32) / 32768.0, (0, max(0, n - len(a))))[None], sr)[0]
+            assert np.abs(p.numpy() - want).max() < 1e-6
