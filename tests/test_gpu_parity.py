@@ -787,27 +787,62 @@ def test_bit_stable_under_foreign_load(model, golden, kind):
         p = eng.forward_audio(x, sr, ctx, st)
         return p, st
 
+    def foreign():
+        with torch.cuda.stream(side):
+            if kind == "torch_elementwise":
+                for _ in range(40):
+                    c.copy_(torch.addcmul(c, a, b))
+            else:                                                     # 2 waves per SIMD, ~10 ms of FMAs each
+                _lib.check(eng._h, _lib.lib().vad_debug_foreign_load(
+                    eng._h, 0 if kind == "pk_fma_spinner" else 1, 2048, 600000, side.cuda_stream))
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    import time
     p0, s0 = run()
     torch.cuda.synchronize()
-    bad, launches = 0, 100
-    for i in range(launches):
-        with torch.cuda.stream(side):                                 # keep ~2 launches worth of foreign work queued
-            if kind == "torch_elementwise":
-                for _ in range(6):
-                    c = torch.addcmul(c, a, b)
-            else:
-                _lib.check(eng._h, _lib.lib().vad_debug_foreign_load(
-                    eng._h, 0 if kind == "pk_fma_spinner" else 1, 8192, 20000, side.cuda_stream))
-        p, s = run()
-        bad += int(not (torch.equal(p, p0) and torch.equal(s, s0)))
-    torch.cuda.synchronize()
+    per_group = 5
+    t_alone = timed(lambda: [run() for _ in range(per_group)])
+    t_foreign = timed(foreign)
+    bad, launches, t_both, together = 0, 0, 0.0, 0.0
+    main = torch.cuda.current_stream(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for i in range(20):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev[0].record(side)
+        foreign()                                                     # the tenant is resident first ...
+        ev[1].record(side)
+        ev[2].record(main)
+        res = [run() for _ in range(per_group)]                       # ... and the engine runs beside it
+        ev[3].record(main)
+        torch.cuda.synchronize()
+        t_both += time.perf_counter() - t0
+        # time both were in flight: min(end) - max(start), on the device's own clock
+        s_m, e_s, e_m = ev[0].elapsed_time(ev[2]), ev[0].elapsed_time(ev[1]), ev[0].elapsed_time(ev[3])
+        together += max(0.0, min(e_s, e_m) - max(0.0, s_m))
+        for p, s in res:
+            launches += 1
+            bad += int(not (torch.equal(p, p0) and torch.equal(s, s0)))
+    t_both /= 20
+    together /= 20
+    # share of the engine's launches (or of the tenant, whichever is shorter) during which both were in flight
+    overlap = together / (min(t_alone, t_foreign) * 1e3)
     out = {"precision": eng.precision, "foreign": kind, "launches": launches, "launches_differing": bad,
-           "tiles_per_launch": B // 16 * T}
+           "tiles_per_launch": B // 16 * T, "engine_ms_per_group_alone": round(t_alone * 1e3, 3),
+           "foreign_ms_alone": round(t_foreign * 1e3, 3), "both_ms": round(t_both * 1e3, 3),
+           "both_in_flight_ms": round(together, 3), "overlap": round(overlap, 3)}
     os.makedirs("gpurun_out", exist_ok=True)
     path = f"gpurun_out/foreign_load_{eng.precision}.json"
     prev = json.load(open(path)) if os.path.exists(path) else {}
     prev[kind] = out
     json.dump(prev, open(path, "w"), indent=1)
+    assert overlap > 0.2, f"the foreign kernel did not run beside the engine: {out}"
     if eng.precision == "fp32":
         assert bad == 0, out
     elif bad:
