@@ -916,3 +916,30 @@ def test_ragged_segments_device_scan_equals_host_scan(model, golden, tag):
         one = get_speech_timestamps(audios[3].float() / 32768.0, model, sampling_rate=sr, **kw)
         assert a[3] == one
     assert sum(len(s) for s in a) > 10
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_refill_scheduler_on_gpu(model, oracle, golden, tag):
+    """Continuous refill (RefillPlan: persistent slots, slabs, re-admission with reset) on the real engine: every
+    recording gets bit-identical probabilities to its own audio_forward, for float and int16 ingest, and the segments
+    of the device scan over the packed rows equal the bucket path's."""
+    from silero_vad_amd import ragged_speech_segments, refill_probs, refill_speech_segments
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    rng = np.random.default_rng(33)
+    lens = [int(v) for v in rng.integers(n // 2, 120 * n, size=70)] + [n, n + 1, 3]
+    starts = rng.integers(0, len(g["wav"]) - 120 * n, size=len(lens))
+    for kind in ("f32", "i16"):
+        src = g["wav"] if kind == "f32" else g["pcm_i16"]
+        audios = [torch.from_numpy(src[s:s + m].copy()) for s, m in zip(starts, lens)]
+        got = refill_probs(audios, model, sr, slots=17, slab_chunks=8)
+        for i, (a, p) in enumerate(zip(audios, got)):
+            if len(a) < n:
+                a = torch.nn.functional.pad(a, (0, n - len(a)))
+            assert torch.equal(p, model.audio_forward(a[None], sr)[0]), (kind, i)
+        i = 5
+        a = audios[i].numpy().astype(np.float32) / (32768.0 if kind == "i16" else 1.0)
+        assert np.abs(got[i].numpy() - oracle.audio_forward(a[None], sr)[0]).max() < TIGHT
+        a1 = refill_speech_segments(audios, model, sr, slots=17, slab_chunks=8, threshold=0.45)
+        a2 = ragged_speech_segments(audios, model, sr, threshold=0.45)
+        assert a1 == a2 and sum(len(x) for x in a1) > 10
