@@ -33,7 +33,8 @@ namespace {
 
 // ---- build-time knobs (tools/variants.py builds A/B variants; the defaults are the product) -------
 #ifndef VAD_SLOT_BLOCKS
-#define VAD_SLOT_BLOCKS 24       // 1-KiB blocks per ring slot (one unit = up to this many blocks)
+#define VAD_SLOT_BLOCKS 16       // 1-KiB blocks per ring slot (one unit = up to this many blocks); 8 / 16 / 24 measured:
+                                 // 5.46 / 5.36 / 5.49 ms per C2 launch (profiles/r02a_fp32_ablations.md)
 #endif
 #ifndef VAD_STAGGER
 #define VAD_STAGGER 0            // x 8128 cycles of start delay for odd wave slots (first workgroups)
