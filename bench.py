@@ -420,7 +420,7 @@ def run_corpus(args, rank, world, local, dist, steps):
         legs[name] = {"scheduler": sched, "value": round(chunks * world * steps / elapsed, 1), "unit": "chunks/s", "steps": steps,
                       "s_per_step": round(elapsed / steps, 4), "segments_found_rank0": nseg[0],
                       "ingest_GBps_per_gpu": round(bytes_in / elapsed / 1e9, 2),
-                      "h2d_GBps_while_copying": round(st.get("h2d_bytes", 0) / max(st.get("h2d_s", 0), 1e-9) / 1e9, 2),
+                      "h2d_GBps_while_copying": (round(st["h2d_bytes"] / st["h2d_s"] / 1e9, 2) if st.get("h2d_s") else None),
                       "host_stage_ms_per_step": round(st.get("stage_s", 0) / steps * 1e3, 2),
                       "host_segmenter_ms_per_step": round(st.get("scan_s", 0) / steps * 1e3, 2),
                       "d2h_MB_per_step": round(st.get("d2h_bytes", 0) / steps / 1e6, 3),

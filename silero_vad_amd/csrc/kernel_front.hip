@@ -36,18 +36,59 @@ namespace {
 #define VAD_SLOT_BLOCKS 16       // 1-KiB blocks per ring slot (one unit = up to this many blocks); 8 / 16 / 24 measured:
                                  // 5.46 / 5.36 / 5.49 ms per C2 launch (profiles/r02a_fp32_ablations.md)
 #endif
+#ifndef VAD_NYQ_VALU
+#define VAD_NYQ_VALU 1           // 1: the Nyquist bin (enc0's 129th / 65th input channel, alone in a 9th / 5th k-group of the
+#endif                           // image) is applied as an exact fp32 rank-1 VALU update from Tab::w_nyq instead of an MFMA
+                                 // step whose other 3 lane groups multiply zeros: -80 MFMAs, -10 ring units per tile
 #ifndef VAD_STAGGER
 #define VAD_STAGGER 0            // x 8128 cycles of start delay for odd wave slots (first workgroups)
 #endif
 
+#ifndef VAD_RING_SLOTS
+#define VAD_RING_SLOTS 2         // 2: a unit is requested when the previous one starts being consumed and awaited with vmcnt(0);
+#endif                           // 3: requested two units ahead by a static schedule of the whole weight stream (make_sched) and
+                                 //    awaited with a COUNTED vmcnt that leaves the younger unit in flight (needs uniform 16-block
+                                 //    units: VAD_SLOT_BLOCKS 16 and VAD_NYQ_VALU 1)
 constexpr int kSlotBlocks = VAD_SLOT_BLOCKS;
 constexpr int kRingSlotFloats = kSlotBlocks * 256;   // one unit: whole k-groups of one segment
+constexpr int kRingSlots = VAD_RING_SLOTS;
+static_assert(kRingSlots == 2 || (kRingSlots == 3 && kSlotBlocks == 16 && VAD_NYQ_VALU),
+              "the 3-slot ring assumes that every unit is exactly 16 blocks");
+
+// Program order of the weight stream as ring units (float offsets into the packed image): the kernel walks its
+// segments in exactly this order; gemm_seg() cross-checks every unit it consumes against it (3-slot ring only).
+struct Sched {
+    int n;
+    int off[128];
+};
+constexpr Sched make_sched(int Q) {
+    using namespace vadl;
+    constexpr int order[] = {E0T1, E0T2, E1T1,                    // enc0 frame 0            -> enc1 out 0 tap 1
+                             E0T0, E0T1, E0T2, E1T2, E1T0,        // enc0 frame 1            -> out 0 tap 2, out 1 tap 0
+                             E0T0, E0T1, E0T2, E1T1,              // enc0 frame 2            -> out 1 tap 1
+                             E0T0, E0T1, E1T2,                    // enc0 frame 3            -> out 1 tap 2
+                             E2T1, E2T2, E3T1, IH0, IH1, IH2, IH3};
+    Sched sc{};
+    int n = 0;
+    for (int seg : order) {
+        const int M = seg_mblocks(seg);
+        const int KS = seg <= E0T2 ? Q : seg_ksteps(seg, Q);      // enc0: the Nyquist k-group is not streamed
+        const int KG = (KS + 3) / 4, UG = kSlotBlocks / M;
+        for (int u = 0; u * UG < KG; ++u) sc.off[n++] = (int)(seg_offset(seg, Q) + (long)u * UG * M * 256);
+    }
+    sc.n = n;
+    return sc;
+}
+__device__ const Sched kSched32 = make_sched(32);
+__device__ const Sched kSched16 = make_sched(16);
 
 // ---- weight ring ----------------------------------------------------------------------------------
 struct Ring {
-    float *slots;            // LDS, 2 x kRingSlotFloats
+    float *slots;            // LDS, kRingSlots x kRingSlotFloats
     const float *wfront;     // global
     int unit;                // units consumed so far (wave-uniform)
+    const Sched *sched;      // 3-slot ring: the static unit schedule
+    int bad;                 // 3-slot ring: a consumed unit was not the scheduled one (programming error)
 #if VAD_TRACE
     long long wait = 0, span = 0, last = 0;   // cycles at unit barriers / between them (bring-up trace)
 #endif
@@ -125,13 +166,26 @@ __device__ __forceinline__ void gemm_seg(f32x4 (&acc)[M], BF bfun, Ring &ring, l
         const long long ta = __builtin_readcyclecounter();
         if (ring.last) ring.span += ta - ring.last;
 #endif
+        int slot;
+        if (kRingSlots == 3) {
+            // Every wave issued exactly 4 LDS-DMA instructions per unit and (unless this is the last unit) exactly one
+            // younger unit is in flight: loads complete in order, so "at most 4 outstanding" means this unit has
+            // landed.  Stores (gx, ctx) only ever add to the counter: they can delay this wait, never release it early.
+            if (ring.unit + 1 < ring.sched->n) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(VAD_ABLATE & 1)) __syncthreads();   // landed for every wave; the slot of unit - 1 is free
+            if (ring.sched->off[ring.unit] != (int)(seg_off + (long)u * UG * M * 256)) ring.bad = 1;
+            if (ring.unit + 2 < ring.sched->n)
+                ring_issue<kSlotBlocks>(ring, ring.sched->off[ring.unit + 2], (ring.unit + 2) % 3, ln);
+            slot = ring.unit % 3;
+        } else {
         ring_wait();
         if (!(VAD_ABLATE & 1)) __syncthreads();   // unit `ring.unit` landed for every wave; other slot free
 #if VAD_TRACE
         ring.last = __builtin_readcyclecounter();
         ring.wait += ring.last - ta;
 #endif
-        const int slot = ring.unit & 1;
+        slot = ring.unit & 1;
         constexpr int TAIL = (KG % UG == 0) ? UG : KG % UG;     // k-groups in the segment's last unit
         if (u + 1 < NU) {
             const long off = seg_off + (long)(u + 1) * UG * M * 256;
@@ -139,6 +193,7 @@ __device__ __forceinline__ void gemm_seg(f32x4 (&acc)[M], BF bfun, Ring &ring, l
             else ring_issue<M * TAIL>(ring, off, slot ^ 1, ln);
         } else if (NEXT_BLOCKS > 0) {
             ring_issue<(NEXT_BLOCKS > 0 ? NEXT_BLOCKS : 4)>(ring, next_off, slot ^ 1, ln);
+        }
         }
         // The unit is consumed as "steps" of two row blocks x 4 k-steps (8 MFMAs).  The A fragments of
         // step i+1 are read from LDS BEFORE the MFMAs of step i are issued (explicit double buffer;
@@ -190,6 +245,17 @@ __device__ __forceinline__ void relu(f32x4 (&acc)[M]) {
 }
 
 
+// Nyquist bin of one frame applied to enc0's 8 output blocks: Y[row] += w_nyq[tap][row] * |Y_nyq| (exact fp32 fma; the
+// MFMA it replaces is the same fma chain, so only the position of this term in the sum changes)
+__device__ __forceinline__ void nyq_update(f32x4 (&Y)[8], float xn, const float *wn_lds, const Lane &ln) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(wn_lds + 16 * m + 4 * ln.g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[m][r] = fmaf(w[r], xn, Y[m][r]);
+    }
+}
+
 // ---- the kernel ------------------------------------------------------------------------------------
 #if VAD_TRACE
 #define TRACE(i)                                                                          \
@@ -204,7 +270,7 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
     using namespace vadl;
     constexpr Tab tb = make_tab(8 * Q, Q);
     constexpr int TABF = (tb.total + 3) / 4 * 4;
-    __shared__ __attribute__((aligned(16))) float lds[TABF + 2 * kRingSlotFloats];
+    __shared__ __attribute__((aligned(16))) float lds[TABF + kRingSlots * kRingSlotFloats];
     float *tab = lds;
 
     Lane ln;
@@ -241,15 +307,20 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
         if (slot)
             for (int i = 0; i < VAD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    Ring ring{lds + TABF, a.wfront, 0};
+    Ring ring{lds + TABF, a.wfront, 0, Q == 32 ? &kSched32 : &kSched16, 0};
     constexpr long o_e0t0 = seg_offset(E0T0, Q), o_e0t1 = seg_offset(E0T1, Q), o_e0t2 = seg_offset(E0T2, Q);
     constexpr long o_e1t0 = seg_offset(E1T0, Q), o_e1t1 = seg_offset(E1T1, Q), o_e1t2 = seg_offset(E1T2, Q);
     constexpr long o_e2t1 = seg_offset(E2T1, Q), o_e2t2 = seg_offset(E2T2, Q), o_e3t1 = seg_offset(E3T1, Q);
 
-    constexpr int FB_E0 = first_unit_blocks(8, Q + 1), FB_E1 = first_unit_blocks(4, 32),
+    constexpr int FB_E0 = first_unit_blocks(8, VAD_NYQ_VALU ? Q : Q + 1), FB_E1 = first_unit_blocks(4, 32),
                   FB_E2 = first_unit_blocks(4, 16), FB_E3 = first_unit_blocks(8, 16),
                   FB_IH = first_unit_blocks(8, 32);
-    ring_issue<FB_E0>(ring, o_e0t1, 0, ln);      // first unit of the program: head of E0T1
+    if (kRingSlots == 3) {                       // prime: units 0 and 1
+        ring_issue<kSlotBlocks>(ring, ring.sched->off[0], 0, ln);
+        ring_issue<kSlotBlocks>(ring, ring.sched->off[1], 1, ln);
+    } else {
+        ring_issue<FB_E0>(ring, o_e0t1, 0, ln);  // first unit of the program: head of E0T1
+    }
     {   // tables -> LDS: all loads of a thread are issued before the first is stored
         static_assert(tb.total % 4 == 0, "tables are copied as 16-byte vectors");
         constexpr int NV = tb.total / 4, PER = (NV + 255) / 256;
@@ -284,12 +355,19 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
 
     f32x4 Y[8], Z0[4], Z1[4];
     auto bY = [&](int s) { return Y[s >> 2][s & 3]; };
-    constexpr int KS0 = Q + 1;
+    constexpr int KS0 = VAD_NYQ_VALU ? Q : Q + 1;
+    const float *wn = tab + tb.w_nyq;                  // [tap][row]
+    // |Y_nyq| of chunk j lives in lane group 0 (X[Q]); every lane of the chunk needs it
+    auto nyq = [&](const float (&X)[Q + 1]) { return __shfl(X[Q], ln.j); };
 
     // enc0 frame 0 (taps 1,2; tap 0 is the left zero pad)  -> enc1 out 0 tap 1
     init_bias<8>(Y, tab + tb.b_e0, ln);
     gemm_seg<8, KS0, FB_E0>(Y, bX0, ring, o_e0t1, o_e0t2, ln);
     gemm_seg<8, KS0, FB_E1>(Y, bX1, ring, o_e0t2, o_e1t1, ln);
+    if (VAD_NYQ_VALU) {
+        nyq_update(Y, nyq(X0), wn + 128, ln);
+        nyq_update(Y, nyq(X1), wn + 256, ln);
+    }
     relu<8>(Y);
     init_bias<4>(Z0, tab + tb.b_e1, ln);
     gemm_seg<4, 32, FB_E0>(Z0, bY, ring, o_e1t1, o_e0t0, ln);
@@ -298,6 +376,11 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
     gemm_seg<8, KS0, FB_E0>(Y, bX0, ring, o_e0t0, o_e0t1, ln);
     gemm_seg<8, KS0, FB_E0>(Y, bX1, ring, o_e0t1, o_e0t2, ln);
     gemm_seg<8, KS0, FB_E1>(Y, bX2, ring, o_e0t2, o_e1t2, ln);
+    if (VAD_NYQ_VALU) {
+        nyq_update(Y, nyq(X0), wn, ln);
+        nyq_update(Y, nyq(X1), wn + 128, ln);
+        nyq_update(Y, nyq(X2), wn + 256, ln);
+    }
     relu<8>(Y);
     gemm_seg<4, 32, FB_E1>(Z0, bY, ring, o_e1t2, o_e1t0, ln);
     init_bias<4>(Z1, tab + tb.b_e1, ln);
@@ -316,12 +399,21 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
     gemm_seg<8, KS0, FB_E0>(Y, bX1, ring, o_e0t0, o_e0t1, ln);
     gemm_seg<8, KS0, FB_E0>(Y, bX2, ring, o_e0t1, o_e0t2, ln);
     gemm_seg<8, KS0, FB_E1>(Y, bX3, ring, o_e0t2, o_e1t1, ln);
+    if (VAD_NYQ_VALU) {
+        nyq_update(Y, nyq(X1), wn, ln);
+        nyq_update(Y, nyq(X2), wn + 128, ln);
+        nyq_update(Y, nyq(X3), wn + 256, ln);
+    }
     relu<8>(Y);
     gemm_seg<4, 32, FB_E0>(Z1, bY, ring, o_e1t1, o_e0t0, ln);
     // enc0 frame 3 (taps 0,1; tap 2 is the right zero pad) -> enc1 out 1 tap 2
     init_bias<8>(Y, tab + tb.b_e0, ln);
     gemm_seg<8, KS0, FB_E0>(Y, bX2, ring, o_e0t0, o_e0t1, ln);
     gemm_seg<8, KS0, FB_E1>(Y, bX3, ring, o_e0t1, o_e1t2, ln);
+    if (VAD_NYQ_VALU) {
+        nyq_update(Y, nyq(X2), wn, ln);
+        nyq_update(Y, nyq(X3), wn + 128, ln);
+    }
     relu<8>(Y);
     gemm_seg<4, 32, FB_E2>(Z1, bY, ring, o_e1t2, o_e2t1, ln);
     relu<4>(Z0);
@@ -353,9 +445,11 @@ __global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
         if (q < 3) gemm_seg<8, 32, FB_IH>(G, bF, ring, seg_offset(IH0 + q, Q), seg_offset(IH0 + q + 1, Q), ln);
         else gemm_seg<8, 32, 0>(G, bF, ring, seg_offset(IH3, Q), 0, ln);
         if (ln.tile_valid) {
+            const float nanv = __builtin_nanf("");
 #pragma unroll
             for (int m = 0; m < 8; ++m)
-                *reinterpret_cast<f32x4 *>(gxt + (size_t)(8 * q + m) * 256) = G[m];
+                *reinterpret_cast<f32x4 *>(gxt + (size_t)(8 * q + m) * 256) =
+                    (kRingSlots == 3 && ring.bad) ? f32x4{nanv, nanv, nanv, nanv} : G[m];
         }
     }
     TRACE(9);

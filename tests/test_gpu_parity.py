@@ -790,8 +790,8 @@ def test_bit_stable_under_foreign_load(model, golden, kind):
     def foreign():
         with torch.cuda.stream(side):
             if kind == "torch_elementwise":
-                for _ in range(40):
-                    c.copy_(torch.addcmul(c, a, b))
+                for _ in range(300):                                  # ~25 ms of a*b+c over 64 MiB operands
+                    torch.addcmul(c, a, b, out=c)
             else:                                                     # 2 waves per SIMD, ~10 ms of FMAs each
                 _lib.check(eng._h, _lib.lib().vad_debug_foreign_load(
                     eng._h, 0 if kind == "pk_fma_spinner" else 1, 2048, 600000, side.cuda_stream))

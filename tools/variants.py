@@ -24,6 +24,10 @@ CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
 VARIANTS = {
     "base": [],
+    "nyq0": ["-DVAD_NYQ_VALU=0"],                       # Nyquist bin as a 9th MFMA k-group (round-1 form)
+    "nyq0_slot24": ["-DVAD_NYQ_VALU=0", "-DVAD_SLOT_BLOCKS=24"],
+    "ring3": ["-DVAD_RING_SLOTS=3"],                   # 3-slot weight ring, two units ahead, counted vmcnt
+    "ring3_nobar": ["-DVAD_RING_SLOTS=3", "-DVAD_ABLATE=1"],
     "slot8": ["-DVAD_SLOT_BLOCKS=8"],
     "slot16": ["-DVAD_SLOT_BLOCKS=16"],
     "stag6": ["-DVAD_STAGGER=6"],
