@@ -51,18 +51,19 @@ PEAK_HBM_GBPS = 8000.0
 
 # Work per chunk.  "flop"/"bytes": the reference's DENSE arithmetic and its I/O --
 # "useful reference work".  "front_mfma" / "rec_mfma": matrix flops our kernels EXECUTE (rFFT frontend on the VALU
-# instead of the DFT-basis conv, zero-padding taps skipped, K padded to the MFMA step) = MFMA instructions per
-# 16-chunk tile x 2048 flop / 16 -- the numerator of roofline.frac.  f16x3: three f16 products per product.
+# instead of the DFT-basis conv, zero-padding taps skipped, the Nyquist bin applied on the VALU) = MFMA instructions per
+# 16-chunk tile (tools/isa_mix.py; SQ_INSTS_MFMA / tiles in profiles/) x 2048 flop / 16 -- the numerator of
+# roofline.frac.  f16x3: three f16 products per product.
 WORK = {
     16000: {"chunk": 512, "flop": 1_359_104, "bytes": 2_052,
             "front_dense": 2 * (264_192 + 198_144 + 49_152 + 12_288 + 24_576 + 65_536),
-            "front_mfma": 2 * (10 * 128 * 132 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
+            "front_mfma": 2 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),   # 4480 MFMAs / tile
             "front_split_mfma": 2 * 3 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
             "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<32, float>",
             "front_split_kernel": "front_split_kernel<32, float>"},
     8000: {"chunk": 256, "flop": 767_232, "bytes": 1_028,
            "front_dense": 2 * (66_560 + 99_840 + 49_152 + 12_288 + 24_576 + 65_536),
-           "front_mfma": 2 * (10 * 128 * 68 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
+           "front_mfma": 2 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),    # 3200 MFMAs / tile
            "front_split_mfma": 2 * 3 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_kernel<16, float>",
            "front_split_kernel": "front_split_kernel<16, float>"},
@@ -407,7 +408,7 @@ def run_corpus(args, rank, world, local, dist, steps):
 
         def step():
             if sched == "buckets":      # length-sorted buckets, one lock-step call each, device scan per bucket
-                segs = ragged_speech_segments(audios, model, sr, max_waste=0.1, max_bytes=256 << 20)
+                segs = ragged_speech_segments(audios, model, sr, max_waste=0.1, max_bytes=64 << 20)
             else:                       # persistent slots refilled at slab boundaries, one device scan at the end
                 segs = refill_speech_segments(audios, model, sr, slots=max(64, R // 4), slab_chunks=32)
             nseg[0] = sum(len(s) for s in segs)

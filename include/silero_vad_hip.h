@@ -207,6 +207,10 @@ int  vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, 
  * arithmetic relies on.  Synchronous.                                                           */
 int  vad_debug_mfma_f16(vad_engine *e, const uint16_t *a, const uint16_t *b, float *d);
 
+/* Device: y[i] = sigmoid(x[i]) (kind 0) or tanh(x[i]) (kind 1) exactly as the recurrent kernels evaluate them
+ * (v_exp_f32 / v_rcp_f32 based, csrc/activations.hpp); x, y device pointers.  For the accuracy test.        */
+int  vad_debug_activation(vad_engine *e, int kind, const float *x, float *y, long n, void *stream);
+
 /* Device: launch a "foreign tenant" on `stream`: `blocks` one-wave workgroups that execute nothing but fp32
  * VALU FMAs for `iters` rounds (kind 0: packed v_pk_fma_f32, kind 1: scalar v_fma_f32).  The GPU tests run
  * it beside the engine's kernels to check their results under a co-resident foreign kernel.  Asynchronous. */

@@ -61,6 +61,7 @@ SYMBOLS = {
     "vad_debug_packed_copy": (c_int, [c_void_p, c_int, c_int, f32p, c_long]),
     "vad_create_host_only": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "vad_debug_mfma_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vad_debug_activation": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p]),
     "vad_debug_foreign_load": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p]),
     "vad_debug_frontend": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
 }

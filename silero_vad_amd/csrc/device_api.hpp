@@ -77,6 +77,9 @@ hipError_t launch_scan(const float *probs, long ldp, const long *row_off, long n
                        const long *audio_len, const vad_segment_params &p, vad_segment *out, long cap, long *counts,
                        hipStream_t s);
 
+// test hook: y[i] = sigmoid (kind 0) / tanh (kind 1) of x[i] exactly as the recurrent kernels evaluate them (activations.hpp)
+hipError_t launch_activation_probe(int kind, const float *x, float *y, long n, hipStream_t s);
+
 // test hook: VALU-only spinner (kind 0 packed fp32, 1 scalar fp32), `blocks` one-wave workgroups
 hipError_t launch_foreign_spin(float *sink, int blocks, long iters, int kind, hipStream_t s);
 

@@ -533,6 +533,14 @@ int vad_debug_mfma_f16(vad_engine *e, const uint16_t *a, const uint16_t *b, floa
     return VAD_OK;
 }
 
+int vad_debug_activation(vad_engine *e, int kind, const float *x, float *y, long n, void *stream) {
+    if (!e || kind < 0 || kind > 1 || n < 0 || (n > 0 && (!x || !y))) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, vad::launch_activation_probe(kind, x, y, n, (hipStream_t)stream));
+    return VAD_OK;
+}
+
 int vad_debug_foreign_load(vad_engine *e, int kind, int blocks, long iters, void *stream) {
     if (!e || kind < 0 || kind > 1 || blocks < 0 || iters < 0) return VAD_ERR_ARG;
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");

@@ -15,6 +15,7 @@
 //   * the head's 128-term dot product is reduced lane -> wave (2 shuffles) -> workgroup (LDS).
 #include <hip/hip_runtime.h>
 
+#include "activations.hpp"
 #include "device_api.hpp"
 #include "layout.hpp"
 
@@ -22,15 +23,6 @@ namespace vad {
 namespace {
 
 using f32x4 = float __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float sigmoid_f(float x) {
-    // 1 / (1 + e^-x), e^-x = 2^(-x log2 e); v_exp_f32 / v_rcp_f32 are 1-ulp ops
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float tanh_f(float x) {
-    // tanh x = 2 sigmoid(2x) - 1 loses relative accuracy near 0 only at the 1e-7 absolute level
-    return fmaf(2.0f, sigmoid_f(2.0f * x), -1.0f);
-}
 
 template <int NTAB_WOUT, int NTAB_BOUT>
 __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
@@ -119,6 +111,18 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
 }
 
 }  // namespace
+
+namespace {
+__global__ void activation_probe_kernel(int kind, const float *x, float *y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = kind == 0 ? sigmoid_f(x[i]) : tanh_f(x[i]);
+}
+}  // namespace
+hipError_t launch_activation_probe(int kind, const float *x, float *y, long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(activation_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kind, x, y, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_rec(int sr, const RecArgs &a, hipStream_t s) {
     if (a.B <= 0 || a.nt <= 0) return hipSuccess;

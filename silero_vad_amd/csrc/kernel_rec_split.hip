@@ -13,6 +13,7 @@
 // Built without packed-fp32 VALU instructions, like kernel_front_split.hip (see the note there).
 #include <hip/hip_runtime.h>
 
+#include "activations.hpp"
 #include "device_api.hpp"
 #include "layout.hpp"
 
@@ -26,10 +27,6 @@ using u32x2 = unsigned __attribute__((ext_vector_type(2)));
 using h8 = _Float16 __attribute__((ext_vector_type(8)));
 using h2 = _Float16 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float sigmoid_f(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float tanh_f(float x) { return fmaf(2.0f, sigmoid_f(2.0f * x), -1.0f); }
 __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }

@@ -151,13 +151,15 @@ def _repair_out_of_range(audios, idxs, probs, model, sampling_rate, n):
 
 
 def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
-                   max_bytes: int = 256 << 20, plan: RaggedPlan = None, post=None):
+                   max_bytes: int = 256 << 20, plan: RaggedPlan = None, post=None, meta=None):
     """Generator over the plan's buckets: yields (indices, probs[len(indices), T_bucket] on the CPU).
     Recording i of a bucket owns the first ceil(len_i / N) entries of its row.
 
-    `post` (GPU models only): a function (probs_dev, indices) -> list of device tensors that is enqueued right after
-    the bucket's kernels; the generator then yields (indices, [those tensors on the CPU], probs_dev) and the
-    probabilities themselves never leave the GPU (ragged_speech_segments scans them there)."""
+    `post` (GPU models only): a function (probs_dev, indices, meta_dev) -> list of device tensors that is enqueued
+    right after the bucket's kernels; the generator then yields (indices, [those tensors on the CPU], probs_dev) and
+    the probabilities themselves never leave the GPU (ragged_speech_segments scans them there).  `meta` (indices ->
+    small CPU int64 tensor) rides to the GPU with the bucket's PCM on the copy stream (pinned, asynchronous), so that
+    nothing in the loop blocks the host on the compute stream."""
     n = chunk_size(sampling_rate)
     as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
     dtype = torch.int16 if as_i16 else torch.float32
@@ -197,15 +199,17 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         d = pool.dev[i][:nbytes].view(dtype).view(len(idxs), width)
         if pool.consumed[i] is not None:                  # the device buffer's previous reader is done
             pool.stream.wait_event(pool.consumed[i])
+        m_host = meta(idxs).pin_memory() if meta is not None else None
         with torch.cuda.stream(pool.stream):
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record(pool.stream)
             d.copy_(host, non_blocking=True)
+            m_dev = m_host.to(dev, non_blocking=True) if m_host is not None else None
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(pool.stream)
         copies.append((ev0, ev))
         pool.done[i] = ev
-        return d, ev, i
+        return d, ev, i, m_dev, m_host
 
     def finish(done_bucket):
         idxs, outs, _, probs_dev = done_bucket
@@ -216,13 +220,15 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     staged = stage(0) if plan.buckets else None
     prev = None
     for k, idxs in enumerate(plan.buckets):
-        x, ev, slot = staged
+        x, ev, slot, m_dev, _keep = staged
         cur.wait_event(ev)
         x.record_stream(cur)                              # allocated on pool.stream, read on `cur`
+        if m_dev is not None:
+            m_dev.record_stream(cur)
         probs = fast(x, sampling_rate, guarded=False)     # async: kernels of bucket k (flagged rows: _repair_...)
         pool.consumed[slot] = torch.cuda.Event()
         pool.consumed[slot].record(cur)
-        back = [probs] if post is None else post(probs, idxs)
+        back = [probs] if post is None else post(probs, idxs, m_dev)
         outs = []
         for o in back:                                    # pinned blocks come from torch's caching host allocator
             h = torch.empty(o.shape, dtype=o.dtype, pin_memory=True)
@@ -282,14 +288,16 @@ def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
         params = _segment_params(sampling_rate, **scan_kw)
         cap0 = 24                                              # segments per recording copied back optimistically
 
-        def post(probs_dev, idxs):
+        def meta(idxs):                                        # [2, n]: chunks and samples of each recording of the bucket
             lens = torch.tensor([lengths[i] for i in idxs], dtype=torch.int64)
-            nck = (lens + n - 1) // n
-            both = torch.stack([nck, lens]).to(probs_dev.device, non_blocking=True)
+            return torch.stack([(lens + n - 1) // n, lens])
+
+        def post(probs_dev, idxs, both):
             counts, segs = _device_scan(model.engine, probs_dev, both[0], both[1], params, cap0)
             return [counts, segs]
 
-        for idxs, (counts, segs), probs_dev in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes, post=post):
+        for idxs, (counts, segs), probs_dev in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes,
+                                                              post=post, meta=meta):
             t0 = time.perf_counter()
             cnt = counts.numpy()
             if len(cnt) and int(cnt.max()) > cap0:             # rare: rescan this bucket with room for all
