@@ -166,14 +166,13 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
     // vector loads (which cover whole groups of dec raw samples) would run past the end of the row.
     const void *tail = nullptr;
     if (Ld % N || Ld * dec > L) {
-        const long rem = Ld - (T - 1) * N;               // samples of the last chunk at the net's rate
-        HIP_TRY(e, hipMemsetAsync(e->d_tail, 0, (size_t)B * N * esz, stream));
-        if (dec == 1)
-            HIP_TRY(e, hipMemcpy2DAsync(e->d_tail, N * esz, pcm + (T - 1) * N, ld * esz, rem * esz, B,
-                                        hipMemcpyDeviceToDevice, stream));
-        else
-            HIP_TRY(e, vad::launch_decimate<PcmT>(pcm + (T - 1) * N * dec, ld, reinterpret_cast<PcmT *>(e->d_tail), N,
-                                                  B, rem, dec, stream));
+        // [B][N * dec], zero padded, RAW sample spacing (the kernel reads it with the same stride as the signal)
+        const long rem = L - (T - 1) * N * dec;          // raw samples of the last chunk
+        rc = grow(e, &e->d_tail, &e->tail_bytes, (size_t)B * N * dec * esz, stream, "tail");
+        if (rc) return rc;
+        HIP_TRY(e, hipMemsetAsync(e->d_tail, 0, (size_t)B * N * dec * esz, stream));
+        HIP_TRY(e, hipMemcpy2DAsync(e->d_tail, (size_t)N * dec * esz, pcm + (T - 1) * N * dec, ld * esz, rem * esz, B,
+                                    hipMemcpyDeviceToDevice, stream));
         tail = e->d_tail;
     }
     const long slab = e->slab_steps;
@@ -232,13 +231,13 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
     hipStream_t stream = (hipStream_t)stream_v;
     if (sr > 16000 && sr % 16000 == 0) {
         // sample-rate front door: a multiple of 16 kHz is decimated to 16 kHz, x[:, ::sr/16000], exactly as the
-        // reference does (vad_annotator.py:104-112), and takes the 16 kHz path.  For 32 and 48 kHz the fp32 frontend
-        // does it while loading (no extra pass over HBM); other multiples, the f16x3 frontend and impl=reference
+        // reference does (vad_annotator.py:104-112), and takes the 16 kHz path.  For 32 kHz the fp32 frontend does it
+        // while loading (no extra pass over HBM); 48 kHz and higher multiples, the f16x3 frontend and impl=reference
         // go through a decimated copy in engine scratch.
         if (B == 0 || L == 0) return VAD_OK;
         const int k = sr / 16000;
         HIP_TRY(e, hipSetDevice(e->device));
-        if (k <= 3 && !e->split && !e->impl_reference && e->fused_decimation)
+        if (k == 2 && !e->split && !e->impl_reference && e->fused_decimation)
             return forward_core<PcmT>(e, 16000, k, B, L, pcm, ld, ctx, state, probs, ldp, stream);
         const long Ld = (L + k - 1) / k, ldd = (Ld + 15) / 16 * 16;
         int rc = grow(e, &e->d_decim, &e->decim_bytes, (size_t)B * ldd * sizeof(PcmT), stream, "decimation");

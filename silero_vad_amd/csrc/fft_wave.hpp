@@ -67,17 +67,23 @@ __device__ __forceinline__ void cvt8(const u32x4 v, float *o) {       // 8 x int
 }
 // s[i] = p[i * DEC], i < SL.  DEC > 1 is the sample-rate front door folded into the load: the reference decimates
 // 32 / 48 kHz input with x[:, ::DEC] (JIT!/vad/model/vad_annotator.py:104-112, src/silero_vad/utils_vad.py:39-42);
-// here the lane reads the DEC-times longer raw span with the same 16-byte vector loads and keeps every DEC-th
-// element (selection by compile-time index: no extra instructions beyond the loads).
+// here the lane reads exactly the samples it keeps, so the raw signal is touched once and never copied.
 template <int SL, int DEC>
 __device__ __forceinline__ void load_vec(const float *p, float (&s)[SL]) {
+    if (DEC == 1) {
 #pragma unroll
-    for (int k = 0; k < SL * DEC / 4; ++k) {
-        const f32x4 v = VAD_NT_PCM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p) + k)
-                                   : reinterpret_cast<const f32x4 *>(p)[k];
+        for (int k = 0; k < SL / 4; ++k) {
+            const f32x4 v = VAD_NT_PCM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p) + k)
+                                       : reinterpret_cast<const f32x4 *>(p)[k];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if ((4 * k + e) % DEC == 0) s[(4 * k + e) / DEC] = v[e];
+            for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
+        }
+    } else {
+        // one 4-byte load per sample that is kept (immediate offsets): loading the whole DEC-times longer span with vector
+        // loads and discarding would need DEC x the registers while the loads are in flight -- this kernel has none to spare
+#pragma unroll
+        for (int i = 0; i < SL; ++i) s[i] = p[i * DEC];
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 template <int SL, int DEC>
@@ -89,16 +95,7 @@ __device__ __forceinline__ void load_vec(const int16_t *p, float (&s)[SL]) {
                             : reinterpret_cast<const u32x4 *>(p)[k], &s[8 * k]);
     } else {
 #pragma unroll
-        for (int k = 0; k < SL * DEC / 8; ++k) {
-            const u32x4 v = reinterpret_cast<const u32x4 *>(p)[k];
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if ((8 * k + e) % DEC == 0) {
-                    const unsigned w = v[e >> 1];
-                    const int x = (e & 1) ? (int)w >> 16 : (int)(w << 16) >> 16;
-                    s[(8 * k + e) / DEC] = (float)x * (1.0f / 32768.0f);
-                }
-        }
+        for (int i = 0; i < SL; ++i) s[i] = (float)p[i * DEC] * (1.0f / 32768.0f);
     }
 }
 
@@ -114,10 +111,10 @@ __device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a
     const long p0 = (long)SL * (8 * ln.t - 1 + sg);          // stream-absolute index of s[0] (in 16 / 8 kHz samples)
     const PcmT *src = row + p0 * DEC;
     const PcmT *esrc = row + ((long)N * ln.t + N - SL - 1) * DEC;   // x[16Q-1], for the reflect pad
-    if (ln.from_tail) {                                       // wave-uniform; the tail copy is already decimated
-        const PcmT *trow = reinterpret_cast<const PcmT *>(a.tail) + (size_t)ln.b * N;
-        if (sg > 0) src = trow + SL * (sg - 1);
-        esrc = trow + (N - SL - 1);
+    if (ln.from_tail) {                                       // wave-uniform; the tail copy keeps the raw sample spacing
+        const PcmT *trow = reinterpret_cast<const PcmT *>(a.tail) + (size_t)ln.b * N * DEC;
+        if (sg > 0) src = trow + SL * (sg - 1) * DEC;
+        esrc = trow + (N - SL - 1) * DEC;
     }
     if (VAD_ABLATE & 16) {
         // timing experiment: same instruction count and bytes, but every instruction reads 1 KiB of
@@ -138,9 +135,25 @@ __device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[4 * k + e] = v[e];
         }
-    } else if (V == 0 && ln.t == 0 && ln.g == 0) load_vec<SL, 1>(a.ctx_in + (size_t)ln.b * SL, s);
-    else if (DEC == 1 || (ln.from_tail && sg > 0)) load_vec<SL, 1>(src, s);
-    else load_vec<SL, DEC>(src, s);
+    } else if (DEC == 1) {
+        if (V == 0 && ln.t == 0 && ln.g == 0) load_vec<SL, 1>(a.ctx_in + (size_t)ln.b * SL, s);
+        else load_vec<SL, 1>(src, s);
+    } else if (V == 0) {
+        // the carried context (lane group 0 of the first chunk) is stored at unit stride, the signal at stride DEC.  Two
+        // divergent load sequences would hold both results in registers; instead EVERY lane runs the strided sequence
+        // (lane group 0 of chunk 0 from a harmless in-bounds address) and the context is patched in by select.
+        const bool from_ctx = ln.t == 0 && ln.g == 0;
+        load_vec<SL, DEC>(from_ctx ? row : src, s);
+        const f32x4 *c4 = reinterpret_cast<const f32x4 *>(a.ctx_in + (size_t)ln.b * SL);
+#pragma unroll
+        for (int k = 0; k < SL / 4; ++k) {
+            const f32x4 v = c4[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[4 * k + e] = from_ctx ? v[e] : s[4 * k + e];
+        }
+    } else {
+        load_vec<SL, DEC>(src, s);
+    }
     if (V == 3) {
         // context for the next call = last C = 2Q samples of the (zero padded) last chunk = slice 8
         if (a.ctx_out && ln.t == a.T - 1 && ln.g == 2 && ln.tile_valid &&

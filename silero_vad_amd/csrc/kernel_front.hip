@@ -249,10 +249,15 @@ __device__ __forceinline__ void relu(f32x4 (&acc)[M]) {
 // MFMA it replaces is the same fma chain, so only the position of this term in the sum changes)
 __device__ __forceinline__ void nyq_update(f32x4 (&Y)[8], float xn, const float *wn_lds, const Lane &ln) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const f32x4 w = *reinterpret_cast<const f32x4 *>(wn_lds + 16 * m + 4 * ln.g);
+    for (int m = 0; m < 8; m += 2) {                 // two blocks at a time: the kernel has no registers to spare for
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wn_lds + 16 * m + 4 * ln.g);         // all 8 reads up front
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wn_lds + 16 * (m + 1) + 4 * ln.g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Y[m][r] = fmaf(w[r], xn, Y[m][r]);
+        for (int r = 0; r < 4; ++r) {
+            Y[m][r] = fmaf(w0[r], xn, Y[m][r]);
+            Y[m + 1][r] = fmaf(w1[r], xn, Y[m + 1][r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -483,9 +488,10 @@ hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s) {
     if (a.B <= 0 || a.nt <= 0) return hipSuccess;
     const long nst = (a.B + 15) / 16, total = nst * a.nt;
     const unsigned grid = (unsigned)((total + 3) / 4);
-    // a.dec > 1: 32 / 48 kHz input, decimation folded into the loads (16 kHz net only)
+    // a.dec == 2: 32 kHz input, decimation folded into the loads (16 kHz net only).  (A stride-3 instantiation for
+    // 48 kHz does not fit the 256-VGPR budget of two workgroups per CU -- it spills ~230 registers -- so 48 kHz and the
+    // other multiples go through the engine's decimation pass.)
     if (sr == 16000 && a.dec == 2) hipLaunchKernelGGL((front_kernel<32, PcmT, 2>), dim3(grid), dim3(256), 0, s, a);
-    else if (sr == 16000 && a.dec == 3) hipLaunchKernelGGL((front_kernel<32, PcmT, 3>), dim3(grid), dim3(256), 0, s, a);
     else if (a.dec > 1) return hipErrorInvalidValue;
     else if (sr == 16000) hipLaunchKernelGGL((front_kernel<32, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((front_kernel<16, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
