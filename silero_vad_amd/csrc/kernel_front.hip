@@ -270,8 +270,11 @@ __device__ __forceinline__ void nyq_update(f32x4 (&Y)[8], float xn, const float 
 #else
 #define TRACE(i) do {} while (0)
 #endif
+#ifndef VAD_WG_PER_CU_8K
+#define VAD_WG_PER_CU_8K 3       // the 8 kHz instantiation needs ~160 VGPRs: three workgroups (3 waves per SIMD) fit a CU
+#endif
 template <int Q, typename PcmT, int DEC>
-__global__ void __launch_bounds__(256, 2) front_kernel(const FrontArgs a) {
+__global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_kernel(const FrontArgs a) {
     using namespace vadl;
     constexpr Tab tb = make_tab(8 * Q, Q);
     constexpr int TABF = (tb.total + 3) / 4 * 4;

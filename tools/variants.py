@@ -26,6 +26,7 @@ VARIANTS = {
     "base": [],
     "nyq0": ["-DVAD_NYQ_VALU=0"],                       # Nyquist bin as a 9th MFMA k-group (round-1 form)
     "nyq0_slot24": ["-DVAD_NYQ_VALU=0", "-DVAD_SLOT_BLOCKS=24"],
+    "wg8k2": ["-DVAD_WG_PER_CU_8K=2"],                  # 8 kHz frontend at two workgroups per CU (round-1 form)
     "ring3": ["-DVAD_RING_SLOTS=3"],                   # 3-slot weight ring, two units ahead, counted vmcnt
     "ring3_nobar": ["-DVAD_RING_SLOTS=3", "-DVAD_ABLATE=1"],
     "slot8": ["-DVAD_SLOT_BLOCKS=8"],
