@@ -451,6 +451,8 @@ class RefillPlan:
             if not entries:
                 break
             self.slabs.append(entries)
+        # the same schedule as arrays (slot, recording, first sample, samples, reset flag), for the vectorised stager
+        self.slab_arrays = [np.asarray(e, dtype=np.int64).reshape(-1, 5) for e in self.slabs]
 
     def n_chunks(self, i: int) -> int:
         return (self.lengths[i] + self.chunk - 1) // self.chunk
@@ -509,20 +511,22 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
         STATS["padded"] += plan.padded_chunks() * n
         STATS["real"] += sum(m for m in lengths if m > 0)
 
+        ptr0 = np.array([a.data_ptr() if a.numel() else 0 for a in host_audio], dtype=np.uint64)
+
         def stage(k):
-            entries = plan.slabs[k]
-            rows = (ctypes.c_void_p * B)()
-            lens = (ctypes.c_long * B)()
+            e = plan.slab_arrays[k]                                        # [entries, 5], vectorised bookkeeping
+            sl, rec, at, take = e[:, 0], e[:, 1], e[:, 2], e[:, 3]
+            rows = np.zeros(B, dtype=np.uint64)
+            lens = np.zeros(B, dtype=np.int64)
+            rows[sl] = ptr0[rec] + (at * esz).astype(np.uint64)
+            lens[sl] = take
+            nck = (take + n - 1) // n
             dst = np.full((B, S), total, dtype=np.int64)                  # default: the sink
-            resets = []
-            for sl, rec, at, take, reset in entries:
-                rows[sl] = host_audio[rec].data_ptr() + at * esz
-                lens[sl] = take
-                nck = (take + n - 1) // n
-                dst[sl, :nck] = base[rec] + done[rec] + cols[0, :nck]
-                done[rec] += nck
-                if reset:
-                    resets.append(sl)
+            dst[sl] = np.where(cols < nck[:, None], (base[rec] + done[rec])[:, None] + cols, total)
+            done[rec] += nck
+            resets = sl[e[:, 4] != 0]
+            rows_p = rows.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))
+            lens_p = lens.ctypes.data_as(ctypes.POINTER(ctypes.c_long))
             nbytes = B * width * esz
             t0 = time.perf_counter()
             if on_gpu:
@@ -530,13 +534,13 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
                 host = pool.host[i][:nbytes].view(dtype).view(B, width)
             else:
                 i, host = 0, torch.empty((B, width), dtype=dtype)
-            rc = lib().vad_stage_rows(rows, lens, B, width, esz, host.data_ptr(), 0)
+            rc = lib().vad_stage_rows(rows_p, lens_p, B, width, esz, host.data_ptr(), 0)
             if rc:
                 raise _lib.VadError(rc, "vad_stage_rows")
             STATS["stage_s"] += time.perf_counter() - t0
             STATS["buckets"] += 1
             idx = torch.from_numpy(dst.reshape(-1))
-            rs = torch.tensor(resets, dtype=torch.int64)
+            rs = torch.from_numpy(np.ascontiguousarray(resets))
             if not on_gpu:
                 return host, None, i, idx, rs
             STATS["h2d_bytes"] += nbytes
