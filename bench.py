@@ -410,7 +410,7 @@ def run_corpus(args, rank, world, local, dist, steps):
             if sched == "buckets":      # length-sorted buckets, one lock-step call each, device scan per bucket
                 segs = ragged_speech_segments(audios, model, sr, max_waste=0.1, max_bytes=1 << 30)
             else:                       # persistent slots refilled at slab boundaries, one device scan at the end
-                segs = refill_speech_segments(audios, model, sr, slots=max(64, R // 2), slab_chunks=32)
+                segs = refill_speech_segments(audios, model, sr, slots=max(64, R // 2), slab_chunks=64)
             nseg[0] = sum(len(s) for s in segs)
 
         step()                                                  # warm-up: pinned buffers, scratch
