@@ -21,8 +21,10 @@
 //     the k-order permutation being folded into the packed weights on the host.  Activations
 //     never touch LDS or HBM between the FFT and the gx store.
 //   * weights (0.65 MB packed, L2 resident) stream global -> LDS with global_load_lds_dwordx4
-//     (no VGPR round trip) through a 2-slot ring shared by the 4 waves, one k-group (4 k-steps x
-//     all row blocks, <= 8 KiB) per slot, and reach the MFMA A operand by ds_read_b128.
+//     (no VGPR round trip) through a 3-slot ring of 16 KiB units shared by the 4 waves, walked by a
+//     static schedule, and reach the MFMA A operand by ds_read_b128 one step ahead of their use --
+//     across unit and segment boundaries, so that neither the LDS latency nor the DMA wait nor the
+//     workgroup barrier (placed in the middle of the previous unit) is exposed at a boundary.
 //   * zero-padding taps of the convs are skipped (enc0 10/12, enc1 5/6, enc2 2/3, enc3 1/3 taps).
 #include <hip/hip_runtime.h>
 
@@ -45,10 +47,11 @@ namespace {
 #endif
 
 #ifndef VAD_RING_SLOTS
-#define VAD_RING_SLOTS 2         // 2: a unit is requested when the previous one starts being consumed and awaited with vmcnt(0);
-#endif                           // 3: requested two units ahead by a static schedule of the whole weight stream (make_sched) and
-                                 //    awaited with a COUNTED vmcnt that leaves the younger unit in flight (needs uniform 16-block
-                                 //    units: VAD_SLOT_BLOCKS 16 and VAD_NYQ_VALU 1)
+#define VAD_RING_SLOTS 3         // 3 (product): "seamless" pipeline -- a static schedule of the whole weight stream (make_sched), the
+#endif                           //    workgroup barrier for unit u+1 in the MIDDLE of unit u, fragment reads carried across unit and
+                                 //    segment boundaries (gemm_seg).  Needs uniform 16-block units (VAD_SLOT_BLOCKS 16, VAD_NYQ_VALU 1).
+                                 // 2: round-1 form: a unit is requested when the previous one starts being consumed, awaited with
+                                 //    vmcnt(0) + barrier at the unit boundary (5.27 vs 5.17 ms per C2 launch)
 constexpr int kSlotBlocks = VAD_SLOT_BLOCKS;
 constexpr int kRingSlotFloats = kSlotBlocks * 256;   // one unit: whole k-groups of one segment
 constexpr int kRingSlots = VAD_RING_SLOTS;
@@ -89,6 +92,7 @@ struct Ring {
     int unit;                // units consumed so far (wave-uniform)
     const Sched *sched;      // 3-slot ring: the static unit schedule
     int bad;                 // 3-slot ring: a consumed unit was not the scheduled one (programming error)
+    f32x4 c0, c1;            // 3-slot ring: A fragments of the next step, carried across unit and segment boundaries
 #if VAD_TRACE
     long long wait = 0, span = 0, last = 0;   // cycles at unit barriers / between them (bring-up trace)
 #endif
@@ -155,11 +159,64 @@ __device__ __forceinline__ void ring_wait() { asm volatile("s_waitcnt vmcnt(0)" 
 // acc[m] += A_seg[m][:, k] * B[k][:]  for all k-steps.  bfun(s) must return the B-operand register of
 // k-step s (compile-time s).  NEXT_BLOCKS / next_off describe the first unit of the segment that
 // follows in program order (prefetch; 0 = none).
-template <int M, int KS, int NEXT_BLOCKS, class BF>
+//
+// 3-slot ring ("seamless" pipeline, VAD_RING_SLOTS == 3): every unit is 16 blocks = 8 steps.  The workgroup barrier that
+// makes unit u+1 visible sits in the MIDDLE of unit u (its DMA was requested in the middle of unit u-1, a full unit
+// earlier), and the double-buffered fragment reads run across unit and segment boundaries: the last step of a unit
+// prefetches the first fragments of the next one (CARRY_OUT / CARRY_IN; dropped only around the FFT of frame 3 and at
+// the end).  No LDS latency and no DMA wait is exposed at a unit boundary any more; the slot that the barrier frees is
+// the one of unit u-1, which every wave has left.
+template <int M, int KS, int NEXT_BLOCKS, bool CARRY_IN, bool CARRY_OUT, class BF>
 __device__ __forceinline__ void gemm_seg(f32x4 (&acc)[M], BF bfun, Ring &ring, long seg_off,
                                          long next_off, const Lane &ln) {
     constexpr int KG = (KS + 3) / 4, UG = unit_kgroups(M), NU = (KG + UG - 1) / UG;
     static_assert(UG >= 1, "slot smaller than one k-group");
+    if constexpr (kRingSlots == 3) {
+        static_assert(UG * (M / 2) == 8 && KG % UG == 0, "uniform units of 8 steps");
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int unit = ring.unit, n_units = ring.sched->n;
+            if (ring.sched->off[unit] != (int)(seg_off + (long)u * UG * M * 256)) ring.bad = 1;
+            const f32x4 *A = reinterpret_cast<const f32x4 *>(ring.slots + (unit % 3) * kRingSlotFloats) + ln.lane;
+            const f32x4 *An = reinterpret_cast<const f32x4 *>(ring.slots + ((unit + 1) % 3) * kRingSlotFloats) + ln.lane;
+            if (!CARRY_IN && u == 0) {
+                ring.c0 = A[0];
+                ring.c1 = A[64];
+            }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (st == 4 && unit + 1 < n_units) {
+                    // this wave's share of unit + 1 has landed; then everyone's, and everyone has left unit - 1.  A bare
+                    // s_barrier (no lgkmcnt(0) fence): the fragment reads in flight belong to the current slot
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!(VAD_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (unit + 2 < n_units) ring_issue<kSlotBlocks>(ring, ring.sched->off[unit + 2], (unit + 2) % 3, ln);
+                }
+                f32x4 n0 = ring.c0, n1 = ring.c1;
+                if (st + 1 < 8) {
+                    n0 = A[(2 * (st + 1)) * 64];
+                    n1 = A[(2 * (st + 1) + 1) * 64];
+                } else if (u + 1 < NU || CARRY_OUT) {
+                    n0 = An[0];
+                    n1 = An[64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int kg = u * UG + st / (M / 2), mp = 2 * (st % (M / 2));
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const float bv = bfun(kg * 4 + ks);
+                    acc[mp + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.c0[ks], bv, acc[mp + 0], 0, 0, 0);
+                    acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.c1[ks], bv, acc[mp + 1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ring.c0 = n0;
+                ring.c1 = n1;
+            }
+            ring.unit++;
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
 #if VAD_TRACE
@@ -167,18 +224,7 @@ __device__ __forceinline__ void gemm_seg(f32x4 (&acc)[M], BF bfun, Ring &ring, l
         if (ring.last) ring.span += ta - ring.last;
 #endif
         int slot;
-        if (kRingSlots == 3) {
-            // Every wave issued exactly 4 LDS-DMA instructions per unit and (unless this is the last unit) exactly one
-            // younger unit is in flight: loads complete in order, so "at most 4 outstanding" means this unit has
-            // landed.  Stores (gx, ctx) only ever add to the counter: they can delay this wait, never release it early.
-            if (ring.unit + 1 < ring.sched->n) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(VAD_ABLATE & 1)) __syncthreads();   // landed for every wave; the slot of unit - 1 is free
-            if (ring.sched->off[ring.unit] != (int)(seg_off + (long)u * UG * M * 256)) ring.bad = 1;
-            if (ring.unit + 2 < ring.sched->n)
-                ring_issue<kSlotBlocks>(ring, ring.sched->off[ring.unit + 2], (ring.unit + 2) % 3, ln);
-            slot = ring.unit % 3;
-        } else {
+        {
         ring_wait();
         if (!(VAD_ABLATE & 1)) __syncthreads();   // unit `ring.unit` landed for every wave; other slot free
 #if VAD_TRACE
@@ -315,7 +361,7 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
         if (slot)
             for (int i = 0; i < VAD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    Ring ring{lds + TABF, a.wfront, 0, Q == 32 ? &kSched32 : &kSched16, 0};
+    Ring ring{lds + TABF, a.wfront, 0, Q == 32 ? &kSched32 : &kSched16, 0, f32x4{}, f32x4{}};
     constexpr long o_e0t0 = seg_offset(E0T0, Q), o_e0t1 = seg_offset(E0T1, Q), o_e0t2 = seg_offset(E0T2, Q);
     constexpr long o_e1t0 = seg_offset(E1T0, Q), o_e1t1 = seg_offset(E1T1, Q), o_e1t2 = seg_offset(E1T2, Q);
     constexpr long o_e2t1 = seg_offset(E2T1, Q), o_e2t2 = seg_offset(E2T2, Q), o_e3t1 = seg_offset(E3T1, Q);
@@ -345,6 +391,7 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
             if (i < NV) reinterpret_cast<f32x4 *>(tab)[i] = v[k];
         }
     }
+    if (kRingSlots == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // units 0 and 1 (and the tables) have landed
     __syncthreads();
 
     float X0[Q + 1], X1[Q + 1], X2[Q + 1], X3[Q + 1];
@@ -370,29 +417,29 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
 
     // enc0 frame 0 (taps 1,2; tap 0 is the left zero pad)  -> enc1 out 0 tap 1
     init_bias<8>(Y, tab + tb.b_e0, ln);
-    gemm_seg<8, KS0, FB_E0>(Y, bX0, ring, o_e0t1, o_e0t2, ln);
-    gemm_seg<8, KS0, FB_E1>(Y, bX1, ring, o_e0t2, o_e1t1, ln);
+    gemm_seg<8, KS0, FB_E0, false, true>(Y, bX0, ring, o_e0t1, o_e0t2, ln);
+    gemm_seg<8, KS0, FB_E1, true, true>(Y, bX1, ring, o_e0t2, o_e1t1, ln);
     if (VAD_NYQ_VALU) {
         nyq_update(Y, nyq(X0), wn + 128, ln);
         nyq_update(Y, nyq(X1), wn + 256, ln);
     }
     relu<8>(Y);
     init_bias<4>(Z0, tab + tb.b_e1, ln);
-    gemm_seg<4, 32, FB_E0>(Z0, bY, ring, o_e1t1, o_e0t0, ln);
+    gemm_seg<4, 32, FB_E0, true, true>(Z0, bY, ring, o_e1t1, o_e0t0, ln);
     // enc0 frame 1 -> enc1 out 0 tap 2, out 1 tap 0
     init_bias<8>(Y, tab + tb.b_e0, ln);
-    gemm_seg<8, KS0, FB_E0>(Y, bX0, ring, o_e0t0, o_e0t1, ln);
-    gemm_seg<8, KS0, FB_E0>(Y, bX1, ring, o_e0t1, o_e0t2, ln);
-    gemm_seg<8, KS0, FB_E1>(Y, bX2, ring, o_e0t2, o_e1t2, ln);
+    gemm_seg<8, KS0, FB_E0, true, true>(Y, bX0, ring, o_e0t0, o_e0t1, ln);
+    gemm_seg<8, KS0, FB_E0, true, true>(Y, bX1, ring, o_e0t1, o_e0t2, ln);
+    gemm_seg<8, KS0, FB_E1, true, true>(Y, bX2, ring, o_e0t2, o_e1t2, ln);
     if (VAD_NYQ_VALU) {
         nyq_update(Y, nyq(X0), wn, ln);
         nyq_update(Y, nyq(X1), wn + 128, ln);
         nyq_update(Y, nyq(X2), wn + 256, ln);
     }
     relu<8>(Y);
-    gemm_seg<4, 32, FB_E1>(Z0, bY, ring, o_e1t2, o_e1t0, ln);
+    gemm_seg<4, 32, FB_E1, true, true>(Z0, bY, ring, o_e1t2, o_e1t0, ln);
     init_bias<4>(Z1, tab + tb.b_e1, ln);
-    gemm_seg<4, 32, FB_E0>(Z1, bY, ring, o_e1t0, o_e0t0, ln);
+    gemm_seg<4, 32, FB_E0, true, false>(Z1, bY, ring, o_e1t0, o_e0t0, ln);
 
     TRACE(5);
 #if VAD_TRACE
@@ -404,26 +451,26 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
 
     // enc0 frame 2 -> enc1 out 1 tap 1
     init_bias<8>(Y, tab + tb.b_e0, ln);
-    gemm_seg<8, KS0, FB_E0>(Y, bX1, ring, o_e0t0, o_e0t1, ln);
-    gemm_seg<8, KS0, FB_E0>(Y, bX2, ring, o_e0t1, o_e0t2, ln);
-    gemm_seg<8, KS0, FB_E1>(Y, bX3, ring, o_e0t2, o_e1t1, ln);
+    gemm_seg<8, KS0, FB_E0, false, true>(Y, bX1, ring, o_e0t0, o_e0t1, ln);
+    gemm_seg<8, KS0, FB_E0, true, true>(Y, bX2, ring, o_e0t1, o_e0t2, ln);
+    gemm_seg<8, KS0, FB_E1, true, true>(Y, bX3, ring, o_e0t2, o_e1t1, ln);
     if (VAD_NYQ_VALU) {
         nyq_update(Y, nyq(X1), wn, ln);
         nyq_update(Y, nyq(X2), wn + 128, ln);
         nyq_update(Y, nyq(X3), wn + 256, ln);
     }
     relu<8>(Y);
-    gemm_seg<4, 32, FB_E0>(Z1, bY, ring, o_e1t1, o_e0t0, ln);
+    gemm_seg<4, 32, FB_E0, true, true>(Z1, bY, ring, o_e1t1, o_e0t0, ln);
     // enc0 frame 3 (taps 0,1; tap 2 is the right zero pad) -> enc1 out 1 tap 2
     init_bias<8>(Y, tab + tb.b_e0, ln);
-    gemm_seg<8, KS0, FB_E0>(Y, bX2, ring, o_e0t0, o_e0t1, ln);
-    gemm_seg<8, KS0, FB_E1>(Y, bX3, ring, o_e0t1, o_e1t2, ln);
+    gemm_seg<8, KS0, FB_E0, true, true>(Y, bX2, ring, o_e0t0, o_e0t1, ln);
+    gemm_seg<8, KS0, FB_E1, true, true>(Y, bX3, ring, o_e0t1, o_e1t2, ln);
     if (VAD_NYQ_VALU) {
         nyq_update(Y, nyq(X2), wn, ln);
         nyq_update(Y, nyq(X3), wn + 128, ln);
     }
     relu<8>(Y);
-    gemm_seg<4, 32, FB_E2>(Z1, bY, ring, o_e1t2, o_e2t1, ln);
+    gemm_seg<4, 32, FB_E2, true, true>(Z1, bY, ring, o_e1t2, o_e2t1, ln);
     relu<4>(Z0);
     relu<4>(Z1);
 
@@ -434,13 +481,13 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
     auto bV = [&](int s) { return Vv[s >> 2][s & 3]; };
     TRACE(7);
     init_bias<4>(Vv, tab + tb.b_e2, ln);
-    gemm_seg<4, 16, FB_E2>(Vv, bZ0, ring, o_e2t1, o_e2t2, ln);
-    gemm_seg<4, 16, FB_E3>(Vv, bZ1, ring, o_e2t2, o_e3t1, ln);
+    gemm_seg<4, 16, FB_E2, true, true>(Vv, bZ0, ring, o_e2t1, o_e2t2, ln);
+    gemm_seg<4, 16, FB_E3, true, true>(Vv, bZ1, ring, o_e2t2, o_e3t1, ln);
     relu<4>(Vv);
     f32x4 Fe[8];
     auto bF = [&](int s) { return Fe[s >> 2][s & 3]; };
     init_bias<8>(Fe, tab + tb.b_e3, ln);
-    gemm_seg<8, 16, FB_IH>(Fe, bV, ring, o_e3t1, seg_offset(IH0, Q), ln);
+    gemm_seg<8, 16, FB_IH, true, true>(Fe, bV, ring, o_e3t1, seg_offset(IH0, Q), ln);
     relu<8>(Fe);
     TRACE(8);
 
@@ -450,8 +497,8 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
     for (int q = 0; q < 4; ++q) {
         f32x4 G[8];
         init_bias<8>(G, tab + tb.b_g + 128 * q, ln);
-        if (q < 3) gemm_seg<8, 32, FB_IH>(G, bF, ring, seg_offset(IH0 + q, Q), seg_offset(IH0 + q + 1, Q), ln);
-        else gemm_seg<8, 32, 0>(G, bF, ring, seg_offset(IH3, Q), 0, ln);
+        if (q < 3) gemm_seg<8, 32, FB_IH, true, true>(G, bF, ring, seg_offset(IH0 + q, Q), seg_offset(IH0 + q + 1, Q), ln);
+        else gemm_seg<8, 32, 0, true, false>(G, bF, ring, seg_offset(IH3, Q), 0, ln);
         if (ln.tile_valid) {
             const float nanv = __builtin_nanf("");
 #pragma unroll

@@ -6,7 +6,7 @@
 //   0 all waves: F fp32 MFMAs                     1 all waves: B bf16 MFMAs                2 all waves: V VALU fmas
 //   3 even slots fp32 MFMA, odd slots bf16 MFMA   4 even slots VALU, odd slots bf16 MFMA   5 even fp32 MFMA, odd VALU
 //   6 one wave: fp32 MFMAs then bf16 MFMAs        7 one wave: interleaved 8 fp32 + 16 bf16 (independent accumulators)
-//   8 one wave: interleaved 16 bf16 MFMA + 32 VALU
+//   8 one wave: interleaved 16 bf16 MFMA + 32 VALU     9 all waves: 32 v_pk_fma_f32 (packed fp32) per trip
 // If two pipes are independent, mode 3 (4, 7, 8) takes max(...) of the single-pipe times instead of their sum.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -28,6 +28,15 @@ __device__ __forceinline__ void bf_mfma(f32x4 (&acc)[4], bf8 a, bf8 b, int n) {
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[m], 0, 0, 0);
+    }
+}
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void valu_pk(f2 (&v)[16], f2 c, int n) {          // 32 v_pk_fma_f32 per trip
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = __builtin_elementwise_fma(v[k], c, f2{0.25f, 0.5f});
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = __builtin_elementwise_fma(v[k], c, f2{-0.25f, -0.5f});
     }
 }
 __device__ __forceinline__ void valu(float (&v)[16], float c, int n) {
@@ -70,6 +79,13 @@ __global__ void __launch_bounds__(256, 2) k(int mode, int n, float *out) {
                 }
             }
             break;
+        case 9: {
+            f2 w[16];
+            for (int i = 0; i < 16; ++i) w[i] = f2{v[i], v[i] + 1.0f};
+            valu_pk(w, f2{0.999f, 1.001f}, n);
+            for (int i = 0; i < 16; ++i) v[i] = w[i].x + w[i].y;
+            break;
+        }
         default:
             for (int i = 0; i < n; ++i) {
 #pragma unroll
@@ -96,7 +112,7 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int n = 20000;
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 9; ++mode) {
+        for (int mode = 0; mode < 10; ++mode) {
             hipEventRecord(e0);
             hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, 0, mode, n, out);
             hipEventRecord(e1); hipEventSynchronize(e1);

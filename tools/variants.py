@@ -26,8 +26,13 @@ VARIANTS = {
     "base": [],
     "nyq0": ["-DVAD_NYQ_VALU=0"],                       # Nyquist bin as a 9th MFMA k-group (round-1 form)
     "nyq0_slot24": ["-DVAD_NYQ_VALU=0", "-DVAD_SLOT_BLOCKS=24"],
+    "slot32": ["-DVAD_SLOT_BLOCKS=32"],
+    "slot32_nobar": ["-DVAD_SLOT_BLOCKS=32", "-DVAD_ABLATE=1"],
     "wg8k2": ["-DVAD_WG_PER_CU_8K=2"],                  # 8 kHz frontend at two workgroups per CU (round-1 form)
     "ring3": ["-DVAD_RING_SLOTS=3"],                   # 3-slot weight ring, two units ahead, counted vmcnt
+    "ring2": ["-DVAD_RING_SLOTS=2"],                   # round-1 two-slot ring (barrier + vmcnt(0) at every unit boundary)
+    "ring3_nofft": ["-DVAD_RING_SLOTS=3", "-DVAD_ABLATE=2"],
+    "ring3_noring": ["-DVAD_RING_SLOTS=3", "-DVAD_ABLATE=8"],
     "ring3_nobar": ["-DVAD_RING_SLOTS=3", "-DVAD_ABLATE=1"],
     "slot8": ["-DVAD_SLOT_BLOCKS=8"],
     "slot16": ["-DVAD_SLOT_BLOCKS=16"],
