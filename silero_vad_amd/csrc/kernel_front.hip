@@ -317,8 +317,8 @@ __device__ __forceinline__ void nyq_update(f32x4 (&Y)[8], float xn, const float 
 #define TRACE(i) do {} while (0)
 #endif
 #ifndef VAD_WG_PER_CU_8K
-#define VAD_WG_PER_CU_8K 3       // the 8 kHz instantiation needs ~160 VGPRs: three workgroups (3 waves per SIMD) fit a CU
-#endif
+#define VAD_WG_PER_CU_8K 2       // (the 2-slot 8 kHz instantiation fits three workgroups per CU at 159 VGPRs; measured 224.3 vs
+#endif                           //  224.2 M chunks/s -- occupancy is not what limits the kernel)
 template <int Q, typename PcmT, int DEC>
 __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_kernel(const FrontArgs a) {
     using namespace vadl;
