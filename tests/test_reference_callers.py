@@ -103,3 +103,54 @@ def test_model_protocol_details_the_reference_relies_on(model):
     assert model._state.shape == (2, 3, 128) and model._context.shape == (3, 32)
     p = model.audio_forward(torch.zeros(2, 1000), 16000)
     assert p.shape == (2, 2) and p.device.type == "cpu"
+
+
+class _Replay:
+    """Model object that replays given probabilities (protocol: utils_vad.py:57-92)."""
+
+    def __init__(self, probs):
+        self.probs, self.i = [float(p) for p in probs], 0
+
+    def reset_states(self):
+        self.i = 0
+
+    def __call__(self, x, sr):
+        p = self.probs[self.i]
+        self.i += 1
+        return torch.tensor([[p]], dtype=torch.float32)
+
+
+def test_native_scanner_equals_reference_scan_fuzz(ref, built):
+    """The native segmenter (csrc/scanner.hpp: O(1) state instead of the reference's `possible_ends` list) against the
+    reference's own Python scan (utils_vad.py:338-450) on random-walk probabilities and random argument sets, with the
+    emphasis on the max_speech_duration_s branches that the speech fixtures barely reach."""
+    from silero_vad_amd.timestamps import segment_probs
+    rng = np.random.default_rng(2024)
+    checked = with_cut = 0
+    for case in range(160):
+        sr = 16000 if case % 2 == 0 else 8000
+        n = 512 if sr == 16000 else 256
+        T = int(rng.integers(1, 400))
+        walk = np.cumsum(rng.standard_normal(T) * rng.uniform(0.1, 0.8))
+        probs = (1.0 / (1.0 + np.exp(-walk + rng.standard_normal()))).astype(np.float32)
+        if case % 7 == 0:
+            probs[rng.integers(0, T, size=T // 3)] = 0.0                      # many short drop-outs
+        audio_len = T * n - int(rng.integers(0, n))
+        kw = dict(threshold=float(rng.choice([0.3, 0.5, 0.7, 0.9])),
+                  min_speech_duration_ms=int(rng.choice([0, 100, 250, 1000])),
+                  min_silence_duration_ms=int(rng.choice([0, 32, 100, 300, 700])),
+                  speech_pad_ms=int(rng.choice([0, 30, 100, 400])),
+                  max_speech_duration_s=float(rng.choice([0.3, 0.6, 1.0, 2.5, float("inf")])),
+                  min_silence_at_max_speech=int(rng.choice([0, 40, 98, 200])),
+                  use_max_poss_sil_at_max_speech=bool(rng.integers(0, 2)))
+        if rng.random() < 0.3:
+            kw["neg_threshold"] = float(rng.choice([0.05, 0.2, 0.45, 0.8]))
+        audio = torch.zeros(audio_len)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = ref.get_speech_timestamps(audio, _Replay(probs), sampling_rate=sr, **kw)
+        got = segment_probs(probs, audio_len, sr, **kw)
+        assert got == want, (case, sr, kw, want[:3], got[:3])
+        checked += 1
+        with_cut += int(np.isfinite(kw["max_speech_duration_s"]) and len(want) > 1)
+    assert checked == 160 and with_cut > 30
