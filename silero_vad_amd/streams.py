@@ -429,36 +429,44 @@ class RefillPlan:
         if self.slots < 1 or self.slab_chunks < 1:
             raise ValueError("slots and slab_chunks must be positive")
         width = self.slab_chunks * self.chunk
-        queue = sorted((i for i, n in enumerate(self.lengths) if n > 0), key=lambda i: -self.lengths[i])
+        lens = np.asarray(self.lengths, dtype=np.int64)
+        queue = np.asarray(sorted((i for i, n in enumerate(self.lengths) if n > 0), key=lambda i: -self.lengths[i]),
+                           dtype=np.int64)
         self.empty = [i for i, n in enumerate(self.lengths) if n <= 0]
-        cur = [None] * self.slots                      # (recording, next sample) per slot
-        self.slabs: List[list] = []
-        qi = 0
-        while True:
-            entries = []
-            for sl in range(self.slots):
-                reset = False
-                if cur[sl] is None and qi < len(queue):
-                    cur[sl] = (queue[qi], 0)
-                    qi += 1
-                    reset = True
-                if cur[sl] is None:
-                    continue
-                rec, at = cur[sl]
-                take = min(width, self.lengths[rec] - at)
-                entries.append((sl, rec, at, take, reset))
-                cur[sl] = (rec, at + take) if at + take < self.lengths[rec] else None
-            if not entries:
-                break
-            self.slabs.append(entries)
-        # the same schedule as arrays (slot, recording, first sample, samples, reset flag), for the vectorised stager
-        self.slab_arrays = [np.asarray(e, dtype=np.int64).reshape(-1, 5) for e in self.slabs]
+        need = (lens[queue] + width - 1) // width            # slabs each recording occupies its slot for
+        # event-driven form of "at every slab boundary, every free slot (in slot order) takes the next recording":
+        # a heap of (slab at which the slot becomes free, slot)
+        import heapq
+        free = [(0, sl) for sl in range(self.slots)]
+        start = np.zeros(len(queue), dtype=np.int64)
+        slot = np.zeros(len(queue), dtype=np.int64)
+        for q in range(len(queue)):
+            t, sl = heapq.heappop(free)
+            start[q], slot[q] = t, sl
+            heapq.heappush(free, (t + int(need[q]), sl))
+        # one row per (recording, slab it is active in): [slot, recording, first sample, samples, reset]
+        reps = np.repeat(np.arange(len(queue)), need)
+        j = np.arange(len(reps)) - np.repeat(np.cumsum(need) - need, need)          # 0 .. need-1 within a recording
+        at = j * width
+        rows = np.stack([slot[reps], queue[reps], at, np.minimum(width, lens[queue[reps]] - at), (j == 0).astype(np.int64)], 1)
+        slab_of = start[reps] + j
+        order = np.lexsort((rows[:, 0], slab_of))                                    # by slab, then by slot
+        rows, slab_of = rows[order], slab_of[order]
+        n_slabs = int(slab_of[-1]) + 1 if len(slab_of) else 0
+        cuts = np.searchsorted(slab_of, np.arange(n_slabs + 1))
+        # the schedule as arrays (slot, recording, first sample, samples, reset flag) per slab, for the vectorised stager
+        self.slab_arrays = [rows[cuts[k]:cuts[k + 1]] for k in range(n_slabs)]
+
+    @property
+    def slabs(self) -> List[list]:
+        """The schedule as lists of (slot, recording, first sample, samples, reset) tuples per slab."""
+        return [[(int(a), int(b), int(c), int(d), bool(e)) for a, b, c, d, e in arr] for arr in self.slab_arrays]
 
     def n_chunks(self, i: int) -> int:
         return (self.lengths[i] + self.chunk - 1) // self.chunk
 
     def padded_chunks(self) -> int:
-        return len(self.slabs) * self.slots * self.slab_chunks
+        return len(self.slab_arrays) * self.slots * self.slab_chunks
 
     def real_chunks(self) -> int:
         return sum(self.n_chunks(i) for i in range(len(self.lengths)) if self.lengths[i] > 0)
@@ -556,8 +564,9 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
             pool.done[i] = ev
             return d, ev, i, idx_d, rs_d
 
-        staged = stage(0) if plan.slabs else None
-        for k in range(len(plan.slabs)):
+        n_slabs = len(plan.slab_arrays)
+        staged = stage(0) if n_slabs else None
+        for k in range(n_slabs):
             x, ev, slot, idx, rs = staged
             if on_gpu:
                 cur.wait_event(ev)
@@ -571,7 +580,7 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
             if on_gpu:
                 pool.consumed[slot] = torch.cuda.Event()
                 pool.consumed[slot].record(cur)
-            staged = stage(k + 1) if k + 1 < len(plan.slabs) else None   # CPU packs k+1 meanwhile
+            staged = stage(k + 1) if k + 1 < n_slabs else None          # CPU packs k+1 meanwhile
     if _keep_on_device:
         return out_flat, base, plan
     flat = out_flat.cpu()
