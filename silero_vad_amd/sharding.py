@@ -25,6 +25,24 @@ def shard_range(n_items: int, world_size: int, rank: int) -> range:
     return range(lo, lo + q + (1 if rank < r else 0))
 
 
+def shard_by_duration(lengths: Sequence[int], world_size: int, rank: int) -> List[int]:
+    """Indices owned by `rank` when items are dealt out by total duration instead of by count (SURVEY.md 8e:
+    "contiguous blocks balanced by total duration"): longest first, each to the rank with the least work so far
+    (ties: lowest rank).  Deterministic, so every rank computes the same partition without communicating; the
+    returned indices are in input order."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    import heapq
+    load = [(0, r) for r in range(world_size)]
+    mine = []
+    for i in sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i)):
+        total, r = heapq.heappop(load)
+        if r == rank:
+            mine.append(i)
+        heapq.heappush(load, (total + int(lengths[i]), r))
+    return sorted(mine)
+
+
 def gather_to_rank0(obj, group=None):
     """Host-side gather of a picklable per-rank result; returns the list on rank 0, None elsewhere.
     Works without an initialised process group (single process)."""
@@ -38,18 +56,26 @@ def gather_to_rank0(obj, group=None):
 
 
 def batch_speech_timestamps(audios: Sequence[torch.Tensor], model, sampling_rate: int = 16000,
-                            rank: int = 0, world_size: int = 1, **kwargs) -> List[list]:
+                            rank: int = 0, world_size: int = 1, balance: str = "duration",
+                            scheduler: str = "buckets", **kwargs) -> List[list]:
     """`get_speech_timestamps` over many recordings (the reference's pattern is one worker process
-    per file, examples/parallel_example.ipynb cells 5, 7): this rank processes its contiguous
-    shard -- recordings of any lengths are bucketed into lock-step GPU batches by
-    `streams.ragged_probs` and segmented by the native batch scanner -- and rank 0 receives every
-    result in input order (other ranks get None).  kwargs are those of get_speech_timestamps."""
+    per file, examples/parallel_example.ipynb cells 5, 7): this rank processes its shard --
+    `balance="duration"` (default) deals recordings out by total audio length, `"count"` by contiguous
+    index blocks; recordings of any lengths go through `scheduler="buckets"` (length-sorted lock-step
+    batches, `streams.ragged_speech_segments`) or `"refill"` (persistent slots, continuous refill,
+    `streams.refill_speech_segments`), both scanned on the GPU -- and rank 0 receives every result in
+    input order (other ranks get None).  kwargs are those of get_speech_timestamps."""
     import warnings
 
-    from .streams import ragged_speech_segments
+    from .streams import ragged_speech_segments, refill_speech_segments
     from .timestamps import get_speech_timestamps
 
-    mine = list(shard_range(len(audios), world_size, rank))
+    if balance not in ("duration", "count") or scheduler not in ("buckets", "refill"):
+        raise ValueError("balance must be duration|count and scheduler buckets|refill")
+    if balance == "duration":
+        mine = shard_by_duration([int(a.shape[-1]) if hasattr(a, "shape") else len(a) for a in audios], world_size, rank)
+    else:
+        mine = list(shard_range(len(audios), world_size, rank))
     results = {}
     scan_kw = {k: kwargs[k] for k in kwargs if k not in ("return_seconds", "time_resolution",
                                                          "visualize_probs", "progress_tracking_callback",
@@ -70,7 +96,7 @@ def batch_speech_timestamps(audios: Sequence[torch.Tensor], model, sampling_rate
                 a = a.squeeze(0)
             local.append(a[::step] if step > 1 else a)
         lens = [int(a.shape[0]) for a in local]
-        segs = ragged_speech_segments(local, model, sr, **scan_kw)
+        segs = (ragged_speech_segments if scheduler == "buckets" else refill_speech_segments)(local, model, sr, **scan_kw)
         seconds, res = kwargs.get("return_seconds", False), kwargs.get("time_resolution", 1)
         for r, i in enumerate(mine):
             out = segs[r]

@@ -24,6 +24,28 @@ def test_shard_range_partitions():
         shard_range(4, 2, 2)
 
 
+def test_shard_by_duration_partitions_and_balances():
+    from silero_vad_amd import shard_by_duration
+    rng = np.random.default_rng(6)
+    for n, w in ((0, 3), (1, 2), (7, 2), (100, 8), (1000, 8)):
+        lens = [int(v) for v in rng.integers(1, 100000, size=n)]
+        parts = [shard_by_duration(lens, w, r) for r in range(w)]
+        assert sorted(i for p in parts for i in p) == list(range(n))        # a partition, every rank computes it alike
+        assert all(p == sorted(p) for p in parts)
+        if n >= 100:
+            loads = [sum(lens[i] for i in p) for p in parts]
+            assert max(loads) - min(loads) <= max(lens)                      # LPT: within one item of each other
+            counts = [sum(lens[i] for i in shard_range_list(n, w, r)) for r in range(w)]
+            assert max(loads) <= max(counts)                                  # never worse than dealing by count
+    with pytest.raises(ValueError):
+        shard_by_duration([1, 2], 2, 2)
+
+
+def shard_range_list(n, w, r):
+    from silero_vad_amd import shard_range
+    return list(shard_range(n, w, r))
+
+
 class OracleModel:
     """Stand-in engine for CPU tests: model protocol + audio_forward_device over the oracle."""
 
@@ -53,10 +75,12 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from silero_vad_amd import batch_speech_timestamps
     res = batch_speech_timestamps(_audios(), OracleModel(), rank=rank, world_size=world, threshold=0.4)
+    res2 = batch_speech_timestamps(_audios(), OracleModel(), rank=rank, world_size=world, threshold=0.4, balance="count")
     if rank == 0:
+        assert res == res2                                      # the partition does not change anybody's result
         q.put(res)
     else:
-        assert res is None
+        assert res is None and res2 is None
     dist.barrier()
     dist.destroy_process_group()
 
