@@ -143,7 +143,10 @@ __device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a
         // divergent load sequences would hold both results in registers; instead EVERY lane runs the strided sequence
         // (lane group 0 of chunk 0 from a harmless in-bounds address) and the context is patched in by select.
         const bool from_ctx = ln.t == 0 && ln.g == 0;
-        load_vec<SL, DEC>(from_ctx ? row : src, s);
+        // (the harmless address: the start of the row -- or of the zero-padded tail copy when the first chunk is also the
+        //  last, partial one and the row itself may be shorter than a slice)
+        const PcmT *safe = ln.from_tail ? reinterpret_cast<const PcmT *>(a.tail) + (size_t)ln.b * N * DEC : row;
+        load_vec<SL, DEC>(from_ctx ? safe : src, s);
         const f32x4 *c4 = reinterpret_cast<const f32x4 *>(a.ctx_in + (size_t)ln.b * SL);
 #pragma unroll
         for (int k = 0; k < SL / 4; ++k) {
