@@ -274,7 +274,7 @@ def test_sample_rate_front_door(model, oracle, golden, k):
         assert np.abs(outs[0][0].cpu().numpy() - want).max() < TIGHT
         assert state_err(outs[0][1].cpu().numpy(), wst) < TOL and np.array_equal(outs[0][2].cpu().numpy(), wctx)
     # lengths around the edge cases of the folded decimation: L % k != 0 with a full last chunk, one raw sample short
-    for L2 in (k * 3 * 512, k * 3 * 512 - 1, k * 3 * 512 - k, k * 2 * 512 + 1, k * 512):
+    for L2 in (k * 3 * 512, k * 3 * 512 - 1, k * 3 * 512 - k, k * 2 * 512 + 1, k * 512, k * 100 + 1, k * 33):
         x2 = torch.from_numpy(np.stack([np.roll(golden["16k"]["wav"], -b * 911)[:L2] for b in range(3)])).to(dev).contiguous()
         T2 = ((L2 + k - 1) // k + 511) // 512
         res = []
