@@ -93,6 +93,10 @@ def setup_dist(args):
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):   # single node: rendezvous over loopback
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if args.dry:
             dist.init_process_group("gloo")
         else:
