@@ -1,5 +1,5 @@
 #!/bin/bash
-# final evidence run: tests, the default bench line, ramped rocprofv3 trace + PMC passes (fp32 default and f16x3), summaries
+# evidence run (gpurun --timeout 1800 -- "bash tools/gpu_evidence.sh <tag>"): tests, the default bench line, ramped rocprofv3 trace + PMC passes (fp32 default and f16x3), summaries
 set -u
 tag=${1:-x}
 out=gpurun_out/$tag
