@@ -48,6 +48,10 @@ struct FrontArgs {
 };
 template <typename PcmT>
 hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s);
+// Same function, encoder 0 as two Winograd F(2,3) transforms over the frame pairs (kernel_front_wino.hip); `wfront` points
+// to the Winograd image (layout.hpp w_* units).  The product's fp32 frontend.
+template <typename PcmT>
+hipError_t launch_front_wino(int sr, const FrontArgs &a, hipStream_t s);
 
 // Recurrence: persistent over the slab's time steps; W_hh pinned in VGPRs, h exchanged through
 // LDS, LSTM pointwise + head fused.  One workgroup (8 waves) per 16 streams.

@@ -22,6 +22,7 @@ struct vad_engine {
     bool impl_reference = false;
     bool split = false;                             // precision: exact fp32 MFMA (default) | fp16x3 split MFMA (opt-in)
     bool split_rec = false;                         // (bring-up: the two kernels can be chosen separately)
+    bool wino = true;                               // fp32 frontend: encoder 0 in Winograd F(2,3) form (option "enc0")
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the fp32 frontend's loads (option "fused_decimation")
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
@@ -29,7 +30,7 @@ struct vad_engine {
     // device images
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
-    float *d_front[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
+    float *d_front[2] = {}, *d_front_wino[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
     uint16_t *d_front_split[2] = {}, *d_whh_split[2] = {};
 
     // scratch
@@ -181,7 +182,8 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
     for (long t0 = 0; t0 < T; t0 += slab) {
         const long nt = std::min(slab, T - t0);
         vad::FrontArgs fa{};
-        fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni]) : e->d_front[ni];
+        fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni])
+                             : e->wino ? e->d_front_wino[ni] : e->d_front[ni];
         fa.tables = e->d_tables[ni];
         fa.pcm = pcm;
         fa.tail = tail;
@@ -211,6 +213,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             HIP_TRY(e, hipEventRecord(ev[0], stream));
         }
         if (e->split) HIP_TRY(e, vad::launch_front_split<PcmT>(sr, fa, stream));
+        else if (e->wino) HIP_TRY(e, vad::launch_front_wino<PcmT>(sr, fa, stream));
         else HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
         if (e->split_rec) HIP_TRY(e, vad::launch_rec_split(sr, ra, stream));
@@ -331,6 +334,7 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
     if (hipSetDevice(device) != hipSuccess) return bail(VAD_ERR_HIP);
     for (int ni = 0; ni < 2; ++ni) {
         if (upload(e, &e->d_front[ni], e->weights.packed[ni].front)) return bail(VAD_ERR_HIP);
+        if (upload(e, &e->d_front_wino[ni], e->weights.packed[ni].front_wino)) return bail(VAD_ERR_HIP);
         if (upload(e, &e->d_whh[ni], e->weights.packed[ni].whh)) return bail(VAD_ERR_HIP);
         if (upload(e, &e->d_tables[ni], e->weights.packed[ni].tables)) return bail(VAD_ERR_HIP);
         if (upload(e, &e->d_front_split[ni], e->weights.packed[ni].front_split)) return bail(VAD_ERR_HIP);
@@ -363,6 +367,7 @@ void vad_destroy(vad_engine *e) {
         (void)hipDeviceSynchronize();
         for (int ni = 0; ni < 2; ++ni) {
             if (e->d_front[ni]) (void)hipFree(e->d_front[ni]);
+            if (e->d_front_wino[ni]) (void)hipFree(e->d_front_wino[ni]);
             if (e->d_whh[ni]) (void)hipFree(e->d_whh[ni]);
             if (e->d_tables[ni]) (void)hipFree(e->d_tables[ni]);
             if (e->d_front_split[ni]) (void)hipFree(e->d_front_split[ni]);
@@ -397,6 +402,12 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
     if (n == "precision_front" || n == "precision_rec") {   // bring-up: mix the two kernels
         if (v != "f16x3" && v != "fp32") return fail(e, VAD_ERR_OPTION, "precision must be f16x3|fp32");
         (n == "precision_front" ? e->split : e->split_rec) = (v == "f16x3");
+        return VAD_OK;
+    }
+    if (n == "enc0") {                               // fp32 frontend: how encoder 0 is evaluated
+        if (v == "winograd") e->wino = true;
+        else if (v == "direct") e->wino = false;
+        else return fail(e, VAD_ERR_OPTION, "enc0 must be winograd|direct");
         return VAD_OK;
     }
     if (n == "fused_decimation") {                   // "0": always decimate into scratch first (A/B for tests)
@@ -498,7 +509,7 @@ long vad_debug_packed_floats(const vad_engine *e, int sr, int which) {
     const vad::PackedNet &p = e->weights.packed[ni];
     return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size()
          : which == 2 ? (long)p.tables.size() : which == 3 ? (long)p.front_split.size() / 2
-         : which == 4 ? (long)p.whh_split.size() / 2 : -1;
+         : which == 4 ? (long)p.whh_split.size() / 2 : which == 5 ? (long)p.front_wino.size() : -1;
 }
 
 int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n) {
@@ -511,7 +522,8 @@ int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, lo
         std::memcpy(dst, h.data(), h.size() * sizeof(uint16_t));
         return VAD_OK;
     }
-    const std::vector<float> *v = which == 0 ? &p.front : which == 1 ? &p.whh : which == 2 ? &p.tables : nullptr;
+    const std::vector<float> *v = which == 0 ? &p.front : which == 1 ? &p.whh : which == 2 ? &p.tables
+                                  : which == 5 ? &p.front_wino : nullptr;
     if (!v || n != (long)v->size()) return VAD_ERR_ARG;
     std::memcpy(dst, v->data(), v->size() * sizeof(float));
     return VAD_OK;
@@ -565,7 +577,8 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     if (L % N || ((size_t)pcm & 15) || (ld * sizeof(float)) % 16 || ((size_t)ctx & 15))
         return fail(e, VAD_ERR_ARG, "debug frontend: whole chunks and 16-byte aligned rows only");
     vad::FrontArgs fa{};
-    fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni]) : e->d_front[ni];
+    fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni])
+                         : e->wino ? e->d_front_wino[ni] : e->d_front[ni];
     fa.tables = e->d_tables[ni];
     fa.pcm = pcm;
     fa.ld = ld; fa.L = L; fa.T = T; fa.t0 = 0; fa.nt = T;
@@ -575,6 +588,7 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.B = B;
     fa.trace = e->trace;
     if (e->split) HIP_TRY(e, vad::launch_front_split<float>(sr, fa, stream));
+    else if (e->wino) HIP_TRY(e, vad::launch_front_wino<float>(sr, fa, stream));
     else HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
     HIP_TRY(e, vad::launch_unpack_gx(e->d_gx, gx, B, T, stream));
     return VAD_OK;

@@ -48,6 +48,54 @@ constexpr long seg_offset(int s, int Q) {
 }
 constexpr long front_floats(int Q) { return seg_offset(NSEG, Q); }
 
+// ---- Winograd frontend image (kernel_front_wino.hip): whole 16-block (16 KiB) units ------------------------------
+// enc0 is a k = 3, stride-1 conv over the 4 STFT frames; as two F(2,3) Winograd transforms over the frame pairs
+// (0,1) and (2,3) it needs 4 instead of 5 GEMMs of [128 x 4Q] per pair:
+//     d = (0, x0, x1, x2) | (x1, x2, x3, 0)      (inputs of the pair, zero = the conv's own zero padding)
+//     m1 = (d0 - d2) G0,  m2 = (d1 + d2) GA,  m3 = (d2 - d1) GB,  m4 = (d1 - d3) G2
+//     y_first = m1 + m2 + m3,   y_second = m2 - m3 - m4
+// with G0 = g0, GA = (g0 + g1 + g2) / 2, GB = (g0 - g1 + g2) / 2, G2 = g2 (g_tau = tap tau of the conv weight; GA, GB
+// are formed in double and rounded once).  Every product and sum is fp32; on the reference's fixtures the result is
+// as close to the reference as the direct form (4e-7 / 1.7e-6 on the probabilities, measured with the ATen port).
+// Each matrix is cut into P row parts of RB = 64 / Q row blocks, so that one (part, matrix) pair is exactly one unit
+// [k-group Q/4][RB][lane 64][4]; encoder 1 is cut by K half (64 input channels = one unit per (tap, half)).
+constexpr int w_rb(int Q) { return 64 / Q; }                  // row blocks per enc0 part: 2 (16 kHz) | 4 (8 kHz)
+constexpr int w_parts(int Q) { return 8 / w_rb(Q); }          // 4 | 2
+enum WMat { WG0 = 0, WGA, WGB, WG2 };
+constexpr int w_e0(int p, int j, int Q) { return p * 4 + j; }                          // part p, matrix j
+constexpr int w_e1(int h, int i, int Q) { return 4 * w_parts(Q) + 3 * h + i; }         // K half h; i: 0 tap 1, 1 tap 2, 2 tap 0
+constexpr int w_e2(int i, int Q) { return 4 * w_parts(Q) + 6 + i; }                    // i: 0 tap 1, 1 tap 2
+constexpr int w_e3(int u, int Q) { return 4 * w_parts(Q) + 8 + u; }                    // 2 units
+constexpr int w_ih(int q, int u, int Q) { return 4 * w_parts(Q) + 10 + 4 * q + u; }    // gate q, 4 units each
+constexpr int w_image_units(int Q) { return 4 * w_parts(Q) + 26; }
+constexpr long kWUnitFloats = 16 * 256;
+constexpr long front_wino_floats(int Q) { return (long)w_image_units(Q) * kWUnitFloats; }
+// Program order of the units (what the kernel consumes, in order; enc0 units are walked twice, once per frame pair)
+constexpr int w_program_units(int Q) { return 2 * 4 * w_parts(Q) + 6 + 4 + 2 + 2 + 16; }
+struct WSched {
+    int n;
+    int unit[80];
+};
+constexpr WSched make_wsched(int Q) {
+    WSched sc{};
+    int n = 0;
+    const int P = w_parts(Q), PH = P / 2;
+    for (int pair = 0; pair < 2; ++pair)
+        for (int h = 0; h < 2; ++h) {
+            for (int pp = 0; pp < PH; ++pp)
+                for (int j = 0; j < 4; ++j) sc.unit[n++] = w_e0(h * PH + pp, j, Q);
+            for (int i = 0; i < (pair == 0 ? 3 : 2); ++i) sc.unit[n++] = w_e1(h, i, Q);
+        }
+    sc.unit[n++] = w_e2(0, Q);
+    sc.unit[n++] = w_e2(1, Q);
+    sc.unit[n++] = w_e3(0, Q);
+    sc.unit[n++] = w_e3(1, Q);
+    for (int q = 0; q < 4; ++q)
+        for (int u = 0; u < 4; ++u) sc.unit[n++] = w_ih(q, u, Q);
+    sc.n = n;
+    return sc;
+}
+
 // ---- recurrent image: [wave 8][gate 4][kgroup 8][lane 64][4] ------------------------------------
 constexpr long whh_floats() { return 8L * 4 * 8 * 256; }
 

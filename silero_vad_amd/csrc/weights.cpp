@@ -133,6 +133,40 @@ void pack_net_split(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
                     }
 }
 
+// Winograd image (layout.hpp "Winograd frontend image"): whole units, enc0 as the 4 transformed matrices
+void pack_net_wino(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
+    using namespace vadl;
+    const int Q = g.Q, K = g.K, RB = w_rb(Q), P = w_parts(Q);
+    p.front_wino.assign((size_t)front_wino_floats(Q), 0.f);
+    auto unit = [&](int u) { return p.front_wino.data() + (size_t)u * kWUnitFloats; };
+    auto g_tap = [&](int row, int bin, int tau) { return (double)t.ew[0][((size_t)row * K + bin) * 3 + tau]; };
+    for (int part = 0; part < P; ++part)
+        for (int j = 0; j < 4; ++j)
+            pack_segment(unit(w_e0(part, j, Q)), RB, Q, [&](int row, int s, int gg) {
+                const int r = 16 * RB * part + row, bin = 4 * s + kResidue[gg];
+                const double g0 = g_tap(r, bin, 0), g1 = g_tap(r, bin, 1), g2 = g_tap(r, bin, 2);
+                const double v = j == WG0 ? g0 : j == WGA ? 0.5 * (g0 + g1 + g2) : j == WGB ? 0.5 * (g0 - g1 + g2) : g2;
+                return (float)v;
+            });
+    const int e1_tap[3] = {1, 2, 0};
+    for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 3; ++i)
+            pack_segment(unit(w_e1(h, i, Q)), 4, 16, [&](int row, int s, int gg) {
+                return t.ew[1][((size_t)row * 128 + 64 * h + chain_chan(s, gg)) * 3 + e1_tap[i]];
+            });
+    for (int i = 0; i < 2; ++i)
+        pack_segment(unit(w_e2(i, Q)), 4, 16, [&](int row, int s, int gg) {
+            return t.ew[2][((size_t)row * 64 + chain_chan(s, gg)) * 3 + 1 + i];
+        });
+    pack_segment(unit(w_e3(0, Q)), 8, 16, [&](int row, int s, int gg) {       // 2 consecutive units
+        return t.ew[3][((size_t)row * 64 + chain_chan(s, gg)) * 3 + 1];
+    });
+    for (int q = 0; q < 4; ++q)
+        pack_segment(unit(w_ih(q, 0, Q)), 8, 32, [&](int row, int s, int gg) {  // 4 consecutive units
+            return t.w_ih[((size_t)(128 * q + row)) * 128 + chain_chan(s, gg)];
+        });
+}
+
 void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
     using namespace vadl;
     const int Q = g.Q, K = g.K;
@@ -205,6 +239,7 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
         for (int row = 0; row < 128; ++row)
             T[tb.w_nyq + tau * 128 + row] = t.ew[0][((size_t)row * K + 4 * Q) * 3 + tau];
     pack_net_split(t, g, p);
+    pack_net_wino(t, g, p);
 }
 
 }  // namespace

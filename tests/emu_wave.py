@@ -480,3 +480,151 @@ def rec_split_step(whh_img, tables, tb, gx, h, c):
         part_all[w] = part[:16]
     p = tables[tb.b_out] + part_all.sum(0)
     return sigmoid_f(p.astype(f32)), hn, cn
+
+
+# ---- kernel_front_wino.hip: encoder 0 as two Winograd F(2,3) transforms, weight stream in whole units ------------
+def w_rb(Q):
+    return 64 // Q
+
+
+def w_parts(Q):
+    return 8 // w_rb(Q)
+
+
+def w_e0(p, j, Q):
+    return p * 4 + j
+
+
+def w_e1(h, i, Q):
+    return 4 * w_parts(Q) + 3 * h + i
+
+
+def w_e2(i, Q):
+    return 4 * w_parts(Q) + 6 + i
+
+
+def w_e3(u, Q):
+    return 4 * w_parts(Q) + 8 + u
+
+
+def w_ih(q, u, Q):
+    return 4 * w_parts(Q) + 10 + 4 * q + u
+
+
+def w_image_units(Q):
+    return 4 * w_parts(Q) + 26
+
+
+def make_wsched(Q):
+    """layout.hpp make_wsched: image unit consumed by each program unit."""
+    P = w_parts(Q)
+    PH = P // 2
+    sc = []
+    for pair in range(2):
+        for h in range(2):
+            for pp in range(PH):
+                sc += [w_e0(h * PH + pp, j, Q) for j in range(4)]
+            sc += [w_e1(h, i, Q) for i in range(3 if pair == 0 else 2)]
+    sc += [w_e2(0, Q), w_e2(1, Q), w_e3(0, Q), w_e3(1, Q)]
+    sc += [w_ih(q, u, Q) for q in range(4) for u in range(4)]
+    return sc
+
+
+class FrontWinoEmu(FrontEmu):
+    """The program of front_wino_kernel, executed unit by unit in PROGRAM order (every unit the kernel requests is
+    taken from the schedule, so a packing / schedule / program mismatch shows up as wrong numbers)."""
+    UNIT = 16 * 256
+
+    def __init__(self, sr, image, tables):
+        self.Q = 32 if sr == 16000 else 16
+        self.image = image
+        self.tab = tables
+        self.tb = Tab(8 * self.Q, self.Q)
+        assert len(tables) == self.tb.total
+        assert len(image) == w_image_units(self.Q) * self.UNIT
+        self.sched = make_wsched(self.Q)
+        self.pu = 0                                   # program unit consumed next
+
+    def gemm_w(self, acc, bfun, M, KG):
+        """[k-group][row block] blocks in whole units, starting at the next program unit."""
+        steps = KG * (M // 2)
+        assert steps % 8 == 0
+        for i in range(steps):
+            unit = self.sched[self.pu + i // 8]
+            base = unit * self.UNIT + (i % 8) * 2 * 256
+            kg, mp = i // (M // 2), 2 * (i % (M // 2))
+            for d in range(2):
+                blk = self.image[base + d * 256: base + (d + 1) * 256].reshape(64, 4)
+                for ks in range(4):
+                    acc[mp + d] = mfma_16x16x4(blk[:, ks], bfun(kg * 4 + ks), acc[mp + d])
+        self.pu += steps // 8
+
+    def nyq(self, acc, xn, tau, row0):
+        tb = self.tb
+        for m in range(acc.shape[0]):
+            for r in range(4):
+                w = self.tab[tb.w_nyq + tau * 128 + row0 + 16 * m + 4 * G + r]
+                acc[m, r] = acc[m, r] + w * xn
+
+    def run(self, x):
+        tb, Q = self.tb, self.Q
+        RB, P = w_rb(Q), w_parts(Q)
+        PH, KG0 = P // 2, Q // 4
+        X = [self.fft_pass(x, v) for v in range(4)]
+        xn = [X[v][Q][J] for v in range(4)]           # __shfl(X[Q], lane & 15): Nyquist magnitude of chunk j
+        chain = lambda A: (lambda s: A[s >> 2, s & 3])
+        relu = lambda A: np.maximum(A, 0)
+        self.pu = 0
+        Z0 = self.init_bias(4, tb.b_e1)
+        Z1 = self.init_bias(4, tb.b_e1)
+        for pair in range(2):
+            if pair == 0:      # d = (0, x0, x1, x2)
+                b = [lambda s: -X[1][s], lambda s: X[0][s] + X[1][s], lambda s: X[1][s] - X[0][s], lambda s: X[2][s] - X[0][s]]
+                nyq_first, nyq_second = [(0, 1), (1, 2)], [(0, 0), (1, 1), (2, 2)]          # (frame, tap)
+            else:              # d = (x1, x2, x3, 0)
+                b = [lambda s: X[1][s] - X[3][s], lambda s: X[2][s] + X[3][s], lambda s: X[3][s] - X[2][s], lambda s: -X[2][s]]
+                nyq_first, nyq_second = [(1, 0), (2, 1), (3, 2)], [(2, 0), (3, 1)]
+            for h in range(2):
+                Ya = np.zeros((4, 4, 64), f32)
+                Yb = np.zeros((4, 4, 64), f32)
+                for pp in range(PH):
+                    row0 = 16 * RB * (h * PH + pp)
+                    a0 = self.init_bias_at(RB, tb.b_e0 + row0)
+                    a1 = self.init_bias_at(RB, tb.b_e0 + row0)
+                    Pm = np.zeros((RB, 4, 64), f32)
+                    Qm = np.zeros((RB, 4, 64), f32)
+                    self.gemm_w(a0, b[0], RB, KG0)
+                    self.gemm_w(Pm, b[1], RB, KG0)
+                    self.gemm_w(Qm, b[2], RB, KG0)
+                    self.gemm_w(a1, b[3], RB, KG0)
+                    for fr, tau in nyq_first:
+                        self.nyq(a0, xn[fr], tau, row0)
+                    for fr, tau in nyq_second:
+                        self.nyq(a1, xn[fr], tau, row0)
+                    Ya[pp * RB:(pp + 1) * RB] = relu(a0 + (Pm + Qm))
+                    Yb[pp * RB:(pp + 1) * RB] = relu(a1 + (Pm - Qm))
+                if pair == 0:
+                    self.gemm_w(Z0, chain(Ya), 4, 4)          # out 0, tap 1 <- y0
+                    self.gemm_w(Z0, chain(Yb), 4, 4)          # out 0, tap 2 <- y1
+                    self.gemm_w(Z1, chain(Yb), 4, 4)          # out 1, tap 0 <- y1
+                else:
+                    self.gemm_w(Z1, chain(Ya), 4, 4)          # out 1, tap 1 <- y2
+                    self.gemm_w(Z1, chain(Yb), 4, 4)          # out 1, tap 2 <- y3
+        Z0, Z1 = relu(Z0), relu(Z1)
+        V = self.init_bias(4, tb.b_e2)
+        self.gemm_w(V, chain(Z0), 4, 4)
+        self.gemm_w(V, chain(Z1), 4, 4)
+        V = relu(V)
+        Fe = self.init_bias(8, tb.b_e3)
+        self.gemm_w(Fe, chain(V), 8, 4)
+        Fe = relu(Fe)
+        gx = np.zeros((32, 4, 64), f32)
+        for q in range(4):
+            Gq = self.init_bias(8, tb.b_g + 128 * q)
+            self.gemm_w(Gq, chain(Fe), 8, 8)
+            gx[8 * q: 8 * q + 8] = Gq
+        assert self.pu == len(self.sched)
+        return {"X": X, "feat": Fe, "gx": gx}
+
+    def init_bias_at(self, M, off):
+        return self.init_bias(M, off)

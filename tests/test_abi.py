@@ -79,6 +79,8 @@ def test_packed_image_sizes(built):
     # 16 kHz frontend stream: E0 3x(9 kg x 8 mb) + E1 3x(8x4) + E2 2x(4x4) + E3 (4x8) + IH 4x(8x8) KiB
     assert L.vad_debug_packed_floats(h, 16000, 0) == (3 * 72 + 3 * 32 + 2 * 16 + 32 + 4 * 64) * 256
     assert L.vad_debug_packed_floats(h, 8000, 0) == (3 * 40 + 3 * 32 + 2 * 16 + 32 + 4 * 64) * 256
+    assert L.vad_debug_packed_floats(h, 16000, 5) == (4 * 4 + 26) * 16 * 256        # Winograd image: whole 16 KiB units
+    assert L.vad_debug_packed_floats(h, 8000, 5) == (4 * 2 + 26) * 16 * 256
     assert L.vad_debug_packed_floats(h, 16000, 1) == 128 * 512
     n = L.vad_debug_packed_floats(h, 16000, 1)
     whh = np.empty(n, np.float32)

@@ -978,3 +978,34 @@ def test_activation_accuracy(model):
     # (the ulp error of e^-x grows with |x|: the rounding of the exponent's argument alone is ~|x| / 2 ulp of the result)
     assert out["sigmoid"]["max_abs_err"] < 2.5e-7 and out["sigmoid"]["max_ulp_err_|x|<=8"] <= 16
     assert out["tanh"]["max_abs_err"] < 5e-7
+
+
+# ---- (10) the two evaluations of encoder 0 ------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_enc0_winograd_and_direct_agree(model, oracle, golden, tag):
+    """The fp32 frontend evaluates encoder 0 as two Winograd F(2,3) transforms over the STFT frame pairs (the default)
+    or tap by tap (option enc0=direct): both are fp32 throughout, both must meet the oracle to the TIGHT bound on real
+    speech and on the adversarial inputs, and they must agree with each other to fp32 round-off -- gate pre-activations
+    included."""
+    if model.engine.precision != "fp32":
+        pytest.skip("enc0 selects between the two fp32 frontends")
+    sr = SRS[tag]
+    n = chunk_of(sr)
+    eng = model.engine
+    rows = np.concatenate([rolled_rows(golden[tag]["wav"], 40, 50 * n, 7919), _adversarial(sr, 50)[1]])
+    want, wctx, wst = oracle.forward_audio(rows, sr)
+    res = {}
+    for algo in ("winograd", "direct"):
+        eng.set_option("enc0", algo)
+        try:
+            probs, ctx, st = run_engine(model, rows, sr)
+            gx = eng.debug_frontend(torch.from_numpy(rows[:19, :5 * n].copy()).to(model.device), sr,
+                                    torch.zeros((19, n // 8), device=model.device)).cpu().numpy()
+        finally:
+            eng.set_option("enc0", "winograd")
+        assert np.abs(probs - want).max() < TIGHT, algo
+        assert state_err(st, wst) < TOL and np.array_equal(ctx, wctx), algo
+        res[algo] = (probs, gx)
+    assert np.abs(res["winograd"][0] - res["direct"][0]).max() < 1e-5
+    g1, g2 = res["winograd"][1], res["direct"][1]
+    assert np.abs(g1 - g2).max() < 2e-5 * max(1.0, np.abs(g2).max())
