@@ -46,22 +46,18 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 // The input combinations of the Winograd transform are needed once per row part.  Left to the optimiser they are
-// computed once and kept (4 x 33 registers per frame pair, which this kernel does not have); the volatile asm makes
-// every use recompute them: one VALU instruction per k-step and GEMM.
-__device__ __forceinline__ float add_now(float x, float y) {
-    float r;
-    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-__device__ __forceinline__ float sub_now(float x, float y) {
-    float r;
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-__device__ __forceinline__ float neg_now(float x) {
-    float r;
-    asm volatile("v_xor_b32 %0, 0x80000000, %1" : "=v"(r) : "v"(x));
-    return r;
+// computed once and kept (4 x 33 registers per frame pair, which this kernel does not have).  They are therefore
+// written as fma's with an OPAQUE +-1 (an SGPR the compiler cannot see through, fresh per row part): x + 1*y and
+// y - 1*x are exact, cost the one VALU instruction an add would, and cannot be merged across parts.  (Not inline-asm
+// adds: the compiler's hazard recogniser does not see inside asm, and a VALU result consumed by the very next MFMA
+// needs its wait states.)
+struct Unit {
+    float one, mone;
+};
+__device__ __forceinline__ Unit opaque_unit() {
+    Unit u;
+    asm volatile("s_mov_b32 %0, 1.0\n\ts_mov_b32 %1, -1.0" : "=s"(u.one), "=s"(u.mone));
+    return u;
 }
 
 struct WRing {
@@ -262,10 +258,11 @@ __global__ void __launch_bounds__(256, 2) front_wino_kernel(const FrontArgs a) {
             init_bias<RB>(a1, tab + tb.b_e0 + row0, ln);
             zero<RB>(Pm);
             zero<RB>(Qm);
-            gemm_w<Q, PG::e0(0, h, pp, WG0), RB, KG0, !first, true>(a0, [&](int s) VAD_INLINE { return neg_now(X1[s]); }, ring, ln);
-            gemm_w<Q, PG::e0(0, h, pp, WGA), RB, KG0, true, true>(Pm, [&](int s) VAD_INLINE { return add_now(X0[s], X1[s]); }, ring, ln);
-            gemm_w<Q, PG::e0(0, h, pp, WGB), RB, KG0, true, true>(Qm, [&](int s) VAD_INLINE { return sub_now(X1[s], X0[s]); }, ring, ln);
-            gemm_w<Q, PG::e0(0, h, pp, WG2), RB, KG0, true, true>(a1, [&](int s) VAD_INLINE { return sub_now(X2[s], X0[s]); }, ring, ln);
+            const Unit k = opaque_unit();
+            gemm_w<Q, PG::e0(0, h, pp, WG0), RB, KG0, !first, true>(a0, [&](int s) VAD_INLINE { return X1[s] * k.mone; }, ring, ln);
+            gemm_w<Q, PG::e0(0, h, pp, WGA), RB, KG0, true, true>(Pm, [&](int s) VAD_INLINE { return fmaf(X1[s], k.one, X0[s]); }, ring, ln);
+            gemm_w<Q, PG::e0(0, h, pp, WGB), RB, KG0, true, true>(Qm, [&](int s) VAD_INLINE { return fmaf(X0[s], k.mone, X1[s]); }, ring, ln);
+            gemm_w<Q, PG::e0(0, h, pp, WG2), RB, KG0, true, true>(a1, [&](int s) VAD_INLINE { return fmaf(X0[s], k.mone, X2[s]); }, ring, ln);
             nyq_update<RB>(a0, nyq(X0), wn + 128 + row0, ln);
             nyq_update<RB>(a0, nyq(X1), wn + 256 + row0, ln);
             nyq_update<RB>(a1, nyq(X0), wn + row0, ln);
@@ -301,10 +298,11 @@ __global__ void __launch_bounds__(256, 2) front_wino_kernel(const FrontArgs a) {
             init_bias<RB>(a1, tab + tb.b_e0 + row0, ln);
             zero<RB>(Pm);
             zero<RB>(Qm);
-            gemm_w<Q, PG::e0(1, h, pp, WG0), RB, KG0, !first, true>(a0, [&](int s) VAD_INLINE { return sub_now(X1[s], X3[s]); }, ring, ln);
-            gemm_w<Q, PG::e0(1, h, pp, WGA), RB, KG0, true, true>(Pm, [&](int s) VAD_INLINE { return add_now(X2[s], X3[s]); }, ring, ln);
-            gemm_w<Q, PG::e0(1, h, pp, WGB), RB, KG0, true, true>(Qm, [&](int s) VAD_INLINE { return sub_now(X3[s], X2[s]); }, ring, ln);
-            gemm_w<Q, PG::e0(1, h, pp, WG2), RB, KG0, true, true>(a1, [&](int s) VAD_INLINE { return neg_now(X2[s]); }, ring, ln);
+            const Unit k = opaque_unit();
+            gemm_w<Q, PG::e0(1, h, pp, WG0), RB, KG0, !first, true>(a0, [&](int s) VAD_INLINE { return fmaf(X3[s], k.mone, X1[s]); }, ring, ln);
+            gemm_w<Q, PG::e0(1, h, pp, WGA), RB, KG0, true, true>(Pm, [&](int s) VAD_INLINE { return fmaf(X3[s], k.one, X2[s]); }, ring, ln);
+            gemm_w<Q, PG::e0(1, h, pp, WGB), RB, KG0, true, true>(Qm, [&](int s) VAD_INLINE { return fmaf(X2[s], k.mone, X3[s]); }, ring, ln);
+            gemm_w<Q, PG::e0(1, h, pp, WG2), RB, KG0, true, true>(a1, [&](int s) VAD_INLINE { return X2[s] * k.mone; }, ring, ln);
             nyq_update<RB>(a0, nyq(X1), wn + row0, ln);
             nyq_update<RB>(a0, nyq(X2), wn + 128 + row0, ln);
             nyq_update<RB>(a0, nyq(X3), wn + 256 + row0, ln);
