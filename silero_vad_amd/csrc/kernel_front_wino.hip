@@ -123,11 +123,13 @@ __device__ __forceinline__ void gemm_w(f32x4 (&acc)[M], BF bfun, WRing &ring, co
             }
             __builtin_amdgcn_sched_barrier(0);
             constexpr int i = u * 8 + st, kg = i / (M / 2), mp = 2 * (i % (M / 2));
+            float bv[4];                      // all four B values first: a VALU result feeding the very next MFMA costs
+#pragma unroll                               // wait states (s_nop), four instructions of distance do not
+            for (int ks = 0; ks < 4; ++ks) bv[ks] = bfun(kg * 4 + ks);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const float bv = bfun(kg * 4 + ks);
-                acc[mp + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.c0[ks], bv, acc[mp + 0], 0, 0, 0);
-                acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.c1[ks], bv, acc[mp + 1], 0, 0, 0);
+                acc[mp + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.c0[ks], bv[ks], acc[mp + 0], 0, 0, 0);
+                acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.c1[ks], bv[ks], acc[mp + 1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             ring.c0 = n0;
