@@ -126,6 +126,7 @@ __device__ __forceinline__ void gemm_w(f32x4 (&acc)[M], BF bfun, WRing &ring, co
             float bv[4];                      // all four B values first: a VALU result feeding the very next MFMA costs
 #pragma unroll                               // wait states (s_nop), four instructions of distance do not
             for (int ks = 0; ks < 4; ++ks) bv[ks] = bfun(kg * 4 + ks);
+            __builtin_amdgcn_sched_barrier(0);       // (or the scheduler sinks each one back in front of its MFMA)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 acc[mp + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.c0[ks], bv[ks], acc[mp + 0], 0, 0, 0);
