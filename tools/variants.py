@@ -28,6 +28,7 @@ VARIANTS = {
     "nyq0_slot24": ["-DVAD_NYQ_VALU=0", "-DVAD_SLOT_BLOCKS=24"],
     "slot32": ["-DVAD_SLOT_BLOCKS=32"],
     "slot32_nobar": ["-DVAD_SLOT_BLOCKS=32", "-DVAD_ABLATE=1"],
+    "nopk_front": [],                                  # fp32 frontends without packed-fp32 VALU (scalar FFT)
     "wg8k2": ["-DVAD_WG_PER_CU_8K=2"],                  # 8 kHz frontend at two workgroups per CU (round-1 form)
     "ring3": ["-DVAD_RING_SLOTS=3"],                   # 3-slot weight ring, two units ahead, counted vmcnt
     "ring2": ["-DVAD_RING_SLOTS=2"],                   # round-1 two-slot ring (barrier + vmcnt(0) at every unit boundary)
@@ -94,7 +95,7 @@ def build(names):
         d = OUT / ("obj_" + name)
         d.mkdir(exist_ok=True)
         for src in knob_units:
-            extra = nopk if ("split" in src and not name.startswith("pk")) else []   # product flags (see __graft_entry__)
+            extra = nopk if (("split" in src and not name.startswith("pk")) or name.startswith("nopk")) else []   # product flags (see __graft_entry__)
             procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950"] + common + extra + VARIANTS[name]
                                           + ["-c", str(CSRC / src), "-o", str(d / (src + ".o"))]))
     for p in procs:
