@@ -5,6 +5,7 @@ export TMPDIR=/tmp
 out=gpurun_out/hunt_$(date +%s); mkdir -p $out
 line=$(python bench.py --no-cpu-baseline --no-extras --steps 150 2>/dev/null | tail -1)
 front=$(echo "$line" | python -c "import sys,json; print(json.loads(sys.stdin.read())['kernel_ms']['front'])")
+./build/ubench/icache 2>/dev/null | tee -a $out/summary.txt
 echo "front_ms $front id $(rocm-smi --showuniqueid 2>/dev/null | grep -o '0x[0-9a-f]*' | head -1)" | tee $out/summary.txt
 slow=$(python -c "print(1 if float('$front') > 5.5 else 0)")
 if [ "$slow" = "1" ]; then
