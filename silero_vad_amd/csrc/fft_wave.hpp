@@ -194,6 +194,28 @@ __device__ __forceinline__ f32x2 cmul(f32x2 v, float c, float sn) {
     return __builtin_elementwise_fma(swap2(v), f32x2{-sn, sn}, v * f32x2{c, c});
 }
 
+#ifndef VAD_XLANE_SWAP
+#define VAD_XLANE_SWAP 1
+#endif
+// a of lanes 32..63 <-> b of lanes 0..31 (v_permlane32_swap_b32); a of odd 16-lane rows <-> b of even rows
+// (v_permlane16_swap_b32).  Both registers change in place.
+__device__ __forceinline__ void trade32(f32x2 &a, f32x2 &b) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[e]), __float_as_uint(b[e]), false, false);
+        a[e] = __uint_as_float(r[0]);
+        b[e] = __uint_as_float(r[1]);
+    }
+}
+__device__ __forceinline__ void trade16(f32x2 &a, f32x2 &b) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[e]), __float_as_uint(b[e]), false, false);
+        a[e] = __uint_as_float(r[0]);
+        b[e] = __uint_as_float(r[1]);
+    }
+}
+
 template <int Q>
 __device__ __forceinline__ void fft_inlane(f32x2 (&z)[Q]) {
 #pragma unroll
@@ -247,8 +269,46 @@ __device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, 
             z[2 * k + 1] = f32x2{s[4 * k + 2], s[4 * k + 3]} * f32x2{wv[2], wv[3]};
         }
     }
-    // radix-4 across the 4 lanes of a chunk.  Stage A pairs g <-> g^2, stage B pairs g <-> g^1.
+    // radix-4 across the 4 lanes of a chunk.  Stage A pairs g <-> g^2 (lanes 32 apart), stage B pairs g <-> g^1
+    // (lanes 16 apart).  Each pair splits the butterflies between its two lanes with gfx950's register-pair swaps
+    // (v_permlane32_swap / v_permlane16_swap: VALU, no LDS round trip, no lane selects): the lower lane trades its
+    // upper Q/2 values for the upper lane's lower Q/2, both lanes form sums and differences of what they now hold,
+    // and a second trade leaves all sums in the lower lane and all differences (lower minus upper) in the upper one.
     const f32x4 *tw1 = reinterpret_cast<const f32x4 *>(tab_lds + tb.tw1 + ln.g * Q * 4);
+#if VAD_XLANE_SWAP
+    constexpr int H = Q / 2;
+#pragma unroll
+    for (int q = 0; q < H; ++q) trade32(z[q], z[q + H]);
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+        const f32x2 u = z[q], v = z[q + H];
+        z[q] = u + v;
+        z[q + H] = u - v;
+    }
+#pragma unroll
+    for (int q = 0; q < H; ++q) trade32(z[q], z[q + H]);
+    // lane group 3 multiplies by -i between the two stages: x*rotA + swap(x)*rotB
+    const f32x2 rotA = ln.g == 3 ? f32x2{0.f, 0.f} : f32x2{1.f, 1.f};
+    const f32x2 rotB = ln.g == 3 ? f32x2{1.f, -1.f} : f32x2{0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) z[q] = __builtin_elementwise_fma(swap2(z[q]), rotB, z[q] * rotA);
+#pragma unroll
+    for (int q = 0; q < H; ++q) trade16(z[q], z[q + H]);
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+        const f32x2 u = z[q], v = z[q + H];
+        z[q] = u + v;
+        z[q + H] = u - v;
+    }
+#pragma unroll
+    for (int q = 0; q < H; ++q) trade16(z[q], z[q + H]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const f32x2 x = z[q];
+        const f32x4 t = tw1[q];                        // * W_4Q^(P[g] q): (-s, s, c, 0)
+        z[q] = __builtin_elementwise_fma(swap2(x), f32x2{t[0], t[1]}, x * f32x2{t[2], t[2]});
+    }
+#else
     const f32x2 sA{ln.sgnA, ln.sgnA}, sB{ln.sgnB, ln.sgnB};
     // lane group 3 multiplies by -i between the two stages: x*rotA + swap(x)*rotB
     const f32x2 rotA = ln.g == 3 ? f32x2{0.f, 0.f} : f32x2{1.f, 1.f};
@@ -264,6 +324,7 @@ __device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, 
         const f32x4 t = tw1[q];                        // * W_4Q^(P[g] q): (-s, s, c, 0)
         z[q] = __builtin_elementwise_fma(swap2(x), f32x2{t[0], t[1]}, x * f32x2{t[2], t[2]});
     }
+#endif
     fft_inlane<Q>(z);
     // real-FFT split: Y[k] = E + W_8Q^k O from Z[k] and conj Z[4Q - k]
     constexpr int LG = ilog2(Q);
