@@ -58,17 +58,17 @@ PEAK_HBM_GBPS = 8000.0
 WORK = {
     16000: {"chunk": 512, "flop": 1_359_104, "bytes": 2_052,
             "front_dense": 2 * (264_192 + 198_144 + 49_152 + 12_288 + 24_576 + 65_536),
-            "front_mfma": 62 * 64 * 2048 // 16,       # 3 968 MFMAs / tile: 62 weight units x 64 (enc0 in Winograd F(2,3) form)
+            "front_mfma": 54 * 64 * 2048 // 16,       # 3 456 MFMAs / tile: 54 weight units x 64 (enc0 as one Winograd F(4,3) tile)
             "front_mfma_direct": 2 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),   # 4 480 (enc0 tap by tap)
             "front_split_mfma": 2 * 3 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
-            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_wino_kernel<32, float>",
+            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_f43_kernel<32, float>",
             "front_split_kernel": "front_split_kernel<32, float>"},
     8000: {"chunk": 256, "flop": 767_232, "bytes": 1_028,
            "front_dense": 2 * (66_560 + 99_840 + 49_152 + 12_288 + 24_576 + 65_536),
-           "front_mfma": 46 * 64 * 2048 // 16,        # 2 944 MFMAs / tile (Winograd)
+           "front_mfma": 42 * 64 * 2048 // 16,        # 2 688 MFMAs / tile (Winograd F(4,3))
            "front_mfma_direct": 2 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),    # 3 200
            "front_split_mfma": 2 * 3 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
-           "rec_mfma": 2 * 512 * 128, "front_kernel": "front_wino_kernel<16, float>",
+           "rec_mfma": 2 * 512 * 128, "front_kernel": "front_f43_kernel<16, float>",
            "front_split_kernel": "front_split_kernel<16, float>"},
 }
 GX_BYTES = 2048          # engine-internal: fp32 LSTM input-gate pre-activations per chunk, written and read once

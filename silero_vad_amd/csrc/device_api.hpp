@@ -48,8 +48,12 @@ struct FrontArgs {
 };
 template <typename PcmT>
 hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s);
-// Same function, encoder 0 as two Winograd F(2,3) transforms over the frame pairs (kernel_front_wino.hip); `wfront` points
-// to the Winograd image (layout.hpp w_* units).  The product's fp32 frontend.
+// Same function, encoder 0 as one Winograd F(4,3) tile over the 4 frames, loop-structured code (kernel_front_f43.hip);
+// `wfront` points to the F(4,3) image (layout.hpp w4_* units).  The product's fp32 frontend.
+template <typename PcmT>
+hipError_t launch_front_f43(int sr, const FrontArgs &a, hipStream_t s);
+// Same function, encoder 0 as two Winograd F(2,3) tiles over the frame pairs, straight-line code (kernel_front_wino.hip);
+// `wfront` points to the F(2,3) image (layout.hpp w_* units).  Kept as an A/B form (option enc0=winograd2).
 template <typename PcmT>
 hipError_t launch_front_wino(int sr, const FrontArgs &a, hipStream_t s);
 

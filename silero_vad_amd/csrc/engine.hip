@@ -22,7 +22,7 @@ struct vad_engine {
     bool impl_reference = false;
     bool split = false;                             // precision: exact fp32 MFMA (default) | fp16x3 split MFMA (opt-in)
     bool split_rec = false;                         // (bring-up: the two kernels can be chosen separately)
-    bool wino = true;                               // fp32 frontend: encoder 0 in Winograd F(2,3) form (option "enc0")
+    int enc0 = 2;                                   // fp32 frontend, encoder 0: 0 direct, 1 Winograd F(2,3), 2 F(4,3) (option "enc0")
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the fp32 frontend's loads (option "fused_decimation")
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
@@ -30,7 +30,7 @@ struct vad_engine {
     // device images
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
-    float *d_front[2] = {}, *d_front_wino[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
+    float *d_front[2] = {}, *d_front_wino[2] = {}, *d_front_wino4[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
     uint16_t *d_front_split[2] = {}, *d_whh_split[2] = {};
 
     // scratch
@@ -183,7 +183,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         const long nt = std::min(slab, T - t0);
         vad::FrontArgs fa{};
         fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni])
-                             : e->wino ? e->d_front_wino[ni] : e->d_front[ni];
+                             : e->enc0 == 2 ? e->d_front_wino4[ni] : e->enc0 == 1 ? e->d_front_wino[ni] : e->d_front[ni];
         fa.tables = e->d_tables[ni];
         fa.pcm = pcm;
         fa.tail = tail;
@@ -213,7 +213,8 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             HIP_TRY(e, hipEventRecord(ev[0], stream));
         }
         if (e->split) HIP_TRY(e, vad::launch_front_split<PcmT>(sr, fa, stream));
-        else if (e->wino) HIP_TRY(e, vad::launch_front_wino<PcmT>(sr, fa, stream));
+        else if (e->enc0 == 2) HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
+        else if (e->enc0 == 1) HIP_TRY(e, vad::launch_front_wino<PcmT>(sr, fa, stream));
         else HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
         if (e->split_rec) HIP_TRY(e, vad::launch_rec_split(sr, ra, stream));
@@ -335,6 +336,7 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
     for (int ni = 0; ni < 2; ++ni) {
         if (upload(e, &e->d_front[ni], e->weights.packed[ni].front)) return bail(VAD_ERR_HIP);
         if (upload(e, &e->d_front_wino[ni], e->weights.packed[ni].front_wino)) return bail(VAD_ERR_HIP);
+        if (upload(e, &e->d_front_wino4[ni], e->weights.packed[ni].front_wino4)) return bail(VAD_ERR_HIP);
         if (upload(e, &e->d_whh[ni], e->weights.packed[ni].whh)) return bail(VAD_ERR_HIP);
         if (upload(e, &e->d_tables[ni], e->weights.packed[ni].tables)) return bail(VAD_ERR_HIP);
         if (upload(e, &e->d_front_split[ni], e->weights.packed[ni].front_split)) return bail(VAD_ERR_HIP);
@@ -368,6 +370,7 @@ void vad_destroy(vad_engine *e) {
         for (int ni = 0; ni < 2; ++ni) {
             if (e->d_front[ni]) (void)hipFree(e->d_front[ni]);
             if (e->d_front_wino[ni]) (void)hipFree(e->d_front_wino[ni]);
+            if (e->d_front_wino4[ni]) (void)hipFree(e->d_front_wino4[ni]);
             if (e->d_whh[ni]) (void)hipFree(e->d_whh[ni]);
             if (e->d_tables[ni]) (void)hipFree(e->d_tables[ni]);
             if (e->d_front_split[ni]) (void)hipFree(e->d_front_split[ni]);
@@ -405,9 +408,10 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         return VAD_OK;
     }
     if (n == "enc0") {                               // fp32 frontend: how encoder 0 is evaluated
-        if (v == "winograd") e->wino = true;
-        else if (v == "direct") e->wino = false;
-        else return fail(e, VAD_ERR_OPTION, "enc0 must be winograd|direct");
+        if (v == "winograd" || v == "winograd4") e->enc0 = 2;
+        else if (v == "winograd2") e->enc0 = 1;
+        else if (v == "direct") e->enc0 = 0;
+        else return fail(e, VAD_ERR_OPTION, "enc0 must be winograd|winograd4|winograd2|direct");
         return VAD_OK;
     }
     if (n == "fused_decimation") {                   // "0": always decimate into scratch first (A/B for tests)
@@ -509,7 +513,8 @@ long vad_debug_packed_floats(const vad_engine *e, int sr, int which) {
     const vad::PackedNet &p = e->weights.packed[ni];
     return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size()
          : which == 2 ? (long)p.tables.size() : which == 3 ? (long)p.front_split.size() / 2
-         : which == 4 ? (long)p.whh_split.size() / 2 : which == 5 ? (long)p.front_wino.size() : -1;
+         : which == 4 ? (long)p.whh_split.size() / 2 : which == 5 ? (long)p.front_wino.size()
+         : which == 6 ? (long)p.front_wino4.size() : -1;
 }
 
 int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n) {
@@ -523,7 +528,7 @@ int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, lo
         return VAD_OK;
     }
     const std::vector<float> *v = which == 0 ? &p.front : which == 1 ? &p.whh : which == 2 ? &p.tables
-                                  : which == 5 ? &p.front_wino : nullptr;
+                                  : which == 5 ? &p.front_wino : which == 6 ? &p.front_wino4 : nullptr;
     if (!v || n != (long)v->size()) return VAD_ERR_ARG;
     std::memcpy(dst, v->data(), v->size() * sizeof(float));
     return VAD_OK;
@@ -578,7 +583,7 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
         return fail(e, VAD_ERR_ARG, "debug frontend: whole chunks and 16-byte aligned rows only");
     vad::FrontArgs fa{};
     fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni])
-                         : e->wino ? e->d_front_wino[ni] : e->d_front[ni];
+                         : e->enc0 == 2 ? e->d_front_wino4[ni] : e->enc0 == 1 ? e->d_front_wino[ni] : e->d_front[ni];
     fa.tables = e->d_tables[ni];
     fa.pcm = pcm;
     fa.ld = ld; fa.L = L; fa.T = T; fa.t0 = 0; fa.nt = T;
@@ -588,7 +593,8 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.B = B;
     fa.trace = e->trace;
     if (e->split) HIP_TRY(e, vad::launch_front_split<float>(sr, fa, stream));
-    else if (e->wino) HIP_TRY(e, vad::launch_front_wino<float>(sr, fa, stream));
+    else if (e->enc0 == 2) HIP_TRY(e, vad::launch_front_f43<float>(sr, fa, stream));
+    else if (e->enc0 == 1) HIP_TRY(e, vad::launch_front_wino<float>(sr, fa, stream));
     else HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
     HIP_TRY(e, vad::launch_unpack_gx(e->d_gx, gx, B, T, stream));
     return VAD_OK;

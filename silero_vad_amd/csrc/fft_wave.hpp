@@ -95,15 +95,21 @@ __device__ __forceinline__ void load_vec(const int16_t *p, float (&s)[SL]) {
                             : reinterpret_cast<const u32x4 *>(p)[k], &s[8 * k]);
     } else {
 #pragma unroll
-        for (int i = 0; i < SL; ++i) s[i] = (float)p[i * DEC] * (1.0f / 32768.0f);
+        for (int h = 0; h < 2; ++h) {                          // two batches: half the raw values in flight at a time
+#pragma unroll
+            for (int i = h * SL / 2; i < (h + 1) * SL / 2; ++i) s[i] = (float)p[i * DEC] * (1.0f / 32768.0f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
 // slice V of the lane: s[i] = x[2Q*(2V+g) + i], x = ctx | chunk (| reflected tail for V==3,g==3).
 // Vector loads only: the engine guarantees 16-byte aligned rows, and hands the (zero padded) last
 // chunk of every stream in `tail` when L is not a multiple of the chunk size.
-template <int Q, int V, typename PcmT, int DEC>
-__device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a, const Lane &ln) {
+// V is an ordinary argument: a literal at the call site folds to the frame's own code, a loop variable gives one body
+// for all four frames (wave-uniform branches for the context of frame 0 and the reflect pad of frame 3).
+template <int Q, typename PcmT, int DEC>
+__device__ __forceinline__ void load_slice(float (&s)[2 * Q], const FrontArgs &a, const Lane &ln, const int V) {
     constexpr int SL = 2 * Q, N = 16 * Q;
     const PcmT *row = reinterpret_cast<const PcmT *>(a.pcm) + (size_t)ln.b * a.ld;
     const int sigma = 2 * V + ln.g;
@@ -239,9 +245,9 @@ __device__ __forceinline__ void fft_inlane(f32x2 (&z)[Q]) {
 }
 
 // One frame (V) of 16 chunks: X[s] (s < Q): |Y[4s + P[g]]|;  X[Q]: |Y[4Q]| in group 0, 0 elsewhere.
-template <int Q, int V, typename PcmT, int DEC = 1>
-__device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, const float *tab_lds,
-                                         const Lane &ln) {
+template <int Q, typename PcmT, int DEC = 1>
+__device__ __forceinline__ void fft_frame(float (&X)[Q + 1], const int V, const FrontArgs &a, const float *tab_lds,
+                                          const Lane &ln) {
     constexpr int SL = 2 * Q;
     constexpr vadl::Tab tb = vadl::make_tab(8 * Q, Q);
     __builtin_amdgcn_sched_barrier(0);     // keep each pass's loads inside the pass (register budget)
@@ -250,7 +256,7 @@ __device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, 
 #pragma unroll
         for (int i = 0; i < SL; ++i) s[i] = (float)(ln.lane + i) * 1e-3f;
     } else {
-        load_slice<Q, V, PcmT, DEC>(s, a, ln);
+        load_slice<Q, PcmT, DEC>(s, a, ln, V);
     }
     if (VAD_ABLATE & 2) {
 #pragma unroll
@@ -349,6 +355,11 @@ __device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, 
         X[k] = 0.5f * __builtin_amdgcn_sqrtf(yy.x + yy.y);
     }
     X[Q] = ln.g == 0 ? fabsf(z[0].x - z[0].y) : 0.f;           // Nyquist: Re Z0 - Im Z0
+}
+
+template <int Q, int V, typename PcmT, int DEC = 1>
+__device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, const float *tab_lds, const Lane &ln) {
+    fft_frame<Q, PcmT, DEC>(X, V, a, tab_lds, ln);
 }
 
 }  // namespace

@@ -96,6 +96,33 @@ constexpr WSched make_wsched(int Q) {
     return sc;
 }
 
+// ---- F(4,3) Winograd frontend image (kernel_front_wino.hip, front_wino4_kernel) -----------------------------------
+// All 4 STFT frames of a chunk are one F(4,3) tile of the k = 3, stride-1 conv: d = (0, x0, x1, x2, x3, 0), 6 GEMMs of
+// [128 x 4Q] instead of the 10 of the direct form (8 with two F(2,3) tiles).  With interpolation points 0, +-1, +-2, inf:
+//     t1 = (x2 + x3) - 4 (x0 + x1)    U1 = -(g0 + g1 + g2) / 6           y0 = m0 + m1 + m2 +   m3 +   m4
+//     t2 = (x3 - x2) + 4 (x0 - x1)    U2 = -(g0 - g1 + g2) / 6           y1 =      m1 - m2 + 2 m3 - 2 m4
+//     t3 = (x3 - x1) + 2 (x2 - x0)    U3 = g0 / 24 + g1 / 12 + g2 / 6    y2 =      m1 + m2 + 4 m3 + 4 m4
+//     t4 = (x3 - x1) - 2 (x2 - x0)    U4 = g0 / 24 - g1 / 12 + g2 / 6    y3 =      m1 - m2 + 8 m3 - 8 m4 + m5
+//     t0 = x3 - 5 x1                  U0 = g0 / 4                        (m_i = U_i t_i; U_i formed in double, rounded once)
+//     t5 = x0 - 1.25 x2               U5 = 4 g2
+// The image IS the program: units in the order the kernel consumes them, each used once per tile.  Per row part p
+// (16 RB rows, RB = w_rb(Q)): U1, U2, U3, U4, U0, U5, then encoder 1's share of the part's 16 RB input channels:
+//   Q = 32 (8 k-steps per tap and part, two taps per unit):  [tap1 <- y0 | tap2 <- y1] -> out 0,
+//        [tap0 <- y1 | tap1 <- y2] -> out 1, and after every odd part [tap2 <- y3 of part p-1 | tap2 <- y3 of part p] -> out 1
+//   Q = 16 (16 k-steps per tap and part): tap1 <- y0, tap2 <- y1 (out 0); tap0 <- y1, tap1 <- y2, tap2 <- y3 (out 1)
+enum W4Mat { W4U1 = 0, W4U2, W4U3, W4U4, W4U0, W4U5 };
+constexpr int w4_e1_units(int p, int Q) { return Q == 32 ? 2 + (p & 1) : 5; }
+constexpr int w4_part0(int p, int Q) {
+    int u = 0;
+    for (int i = 0; i < p; ++i) u += 6 + w4_e1_units(i, Q);
+    return u;
+}
+constexpr int w4_e0(int p, int j, int Q) { return w4_part0(p, Q) + j; }
+constexpr int w4_e1(int p, int i, int Q) { return w4_part0(p, Q) + 6 + i; }
+constexpr int w4_tail0(int Q) { return w4_part0(w_parts(Q), Q); }          // E2 tap 1, tap 2, E3 (2), W_ih (16)
+constexpr int w4_units(int Q) { return w4_tail0(Q) + 20; }                 // 54 | 42
+constexpr long front_wino4_floats(int Q) { return (long)w4_units(Q) * kWUnitFloats; }
+
 // ---- recurrent image: [wave 8][gate 4][kgroup 8][lane 64][4] ------------------------------------
 constexpr long whh_floats() { return 8L * 4 * 8 * 256; }
 

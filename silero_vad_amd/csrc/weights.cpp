@@ -167,6 +167,66 @@ void pack_net_wino(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
         });
 }
 
+// F(4,3) image (layout.hpp "F(4,3) Winograd frontend image"): the units in program order
+void pack_net_wino4(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
+    using namespace vadl;
+    const int Q = g.Q, K = g.K, RB = w_rb(Q), P = w_parts(Q);
+    p.front_wino4.assign((size_t)front_wino4_floats(Q), 0.f);
+    auto unit = [&](int u) { return p.front_wino4.data() + (size_t)u * kWUnitFloats; };
+    auto g_tap = [&](int row, int bin, int tau) { return (double)t.ew[0][((size_t)row * K + bin) * 3 + tau]; };
+    auto e1 = [&](int row, int chan, int tau) { return t.ew[1][((size_t)row * 128 + chan) * 3 + tau]; };
+    for (int part = 0; part < P; ++part) {
+        for (int j = 0; j < 6; ++j)
+            pack_segment(unit(w4_e0(part, j, Q)), RB, Q, [&](int row, int s, int gg) {
+                const int r = 16 * RB * part + row, bin = 4 * s + kResidue[gg];
+                const double g0 = g_tap(r, bin, 0), g1 = g_tap(r, bin, 1), g2 = g_tap(r, bin, 2);
+                double v = 0;
+                switch (j) {
+                    case W4U1: v = -(g0 + g1 + g2) / 6.0; break;
+                    case W4U2: v = -(g0 - g1 + g2) / 6.0; break;
+                    case W4U3: v = g0 / 24.0 + g1 / 12.0 + g2 / 6.0; break;
+                    case W4U4: v = g0 / 24.0 - g1 / 12.0 + g2 / 6.0; break;
+                    case W4U0: v = g0 / 4.0; break;
+                    default: v = 4.0 * g2; break;
+                }
+                return (float)v;
+            });
+        const int c0 = 16 * RB * part;                    // first input channel of the part
+        if (Q == 32) {
+            // 8 k-steps per tap: k-steps 0..7 the first tap, 8..15 the second
+            const int tapsA[2] = {1, 2}, tapsB[2] = {0, 1};
+            pack_segment(unit(w4_e1(part, 0, Q)), 4, 16, [&](int row, int s, int gg) {
+                return e1(row, c0 + chain_chan(s & 7, gg), tapsA[s >> 3]);
+            });
+            pack_segment(unit(w4_e1(part, 1, Q)), 4, 16, [&](int row, int s, int gg) {
+                return e1(row, c0 + chain_chan(s & 7, gg), tapsB[s >> 3]);
+            });
+            if (part & 1)
+                pack_segment(unit(w4_e1(part, 2, Q)), 4, 16, [&](int row, int s, int gg) {
+                    return e1(row, c0 - 32 * (1 - (s >> 3)) + chain_chan(s & 7, gg), 2);
+                });
+        } else {
+            const int taps[5] = {1, 2, 0, 1, 2};
+            for (int i = 0; i < 5; ++i)
+                pack_segment(unit(w4_e1(part, i, Q)), 4, 16, [&](int row, int s, int gg) {
+                    return e1(row, c0 + chain_chan(s, gg), taps[i]);
+                });
+        }
+    }
+    const int T0 = w4_tail0(Q);
+    for (int i = 0; i < 2; ++i)
+        pack_segment(unit(T0 + i), 4, 16, [&](int row, int s, int gg) {
+            return t.ew[2][((size_t)row * 64 + chain_chan(s, gg)) * 3 + 1 + i];
+        });
+    pack_segment(unit(T0 + 2), 8, 16, [&](int row, int s, int gg) {           // 2 consecutive units
+        return t.ew[3][((size_t)row * 64 + chain_chan(s, gg)) * 3 + 1];
+    });
+    for (int q = 0; q < 4; ++q)
+        pack_segment(unit(T0 + 4 + 4 * q), 8, 32, [&](int row, int s, int gg) {  // 4 consecutive units
+            return t.w_ih[((size_t)(128 * q + row)) * 128 + chain_chan(s, gg)];
+        });
+}
+
 void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
     using namespace vadl;
     const int Q = g.Q, K = g.K;
@@ -240,6 +300,7 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
             T[tb.w_nyq + tau * 128 + row] = t.ew[0][((size_t)row * K + 4 * Q) * 3 + tau];
     pack_net_split(t, g, p);
     pack_net_wino(t, g, p);
+    pack_net_wino4(t, g, p);
 }
 
 }  // namespace

@@ -24,6 +24,7 @@ struct PackedNet {
     vadl::Geo geo{};
     std::vector<float> front;    // frontend GEMM stream (layout.hpp Seg order)
     std::vector<float> front_wino;   // frontend stream with enc0 in Winograd F(2,3) form (layout.hpp w_* units)
+    std::vector<float> front_wino4;  // the same with enc0 as one F(4,3) tile, units in program order (layout.hpp w4_*)
     std::vector<float> whh;      // recurrent image
     std::vector<float> tables;   // biases, head, window, twiddles, Nyquist-bin weights
     std::vector<uint16_t> front_split;   // fp16 hi/lo frontend image (layout.hpp SSeg order)

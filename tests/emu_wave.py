@@ -628,3 +628,86 @@ class FrontWinoEmu(FrontEmu):
 
     def init_bias_at(self, M, off):
         return self.init_bias(M, off)
+
+
+# ---- kernel_front_f43.hip: encoder 0 as one Winograd F(4,3) tile, the image is the program --------------------------
+def w4_e1_units(p, Q):
+    return 2 + (p & 1) if Q == 32 else 5
+
+
+def w4_units(Q):
+    return sum(6 + w4_e1_units(p, Q) for p in range(w_parts(Q))) + 20
+
+
+class FrontF43Emu(FrontWinoEmu):
+    """The program of front_f43_kernel: units consumed strictly in image order (layout.hpp w4_*)."""
+
+    def __init__(self, sr, image, tables):
+        self.Q = 32 if sr == 16000 else 16
+        self.image = image
+        self.tab = tables
+        self.tb = Tab(8 * self.Q, self.Q)
+        assert len(tables) == self.tb.total
+        assert len(image) == w4_units(self.Q) * self.UNIT
+        self.sched = list(range(w4_units(self.Q)))
+        self.pu = 0
+
+    def run(self, x):
+        tb, Q = self.tb, self.Q
+        RB, P, KG0 = w_rb(Q), w_parts(Q), Q // 4
+        X = [self.fft_pass(x, v) for v in range(4)]
+        xn = [X[v][Q][J] for v in range(4)]
+        chain = lambda A: (lambda s: A[s >> 2, s & 3])
+        two = lambda A, B: (lambda s: A[s >> 2, s & 3] if s < 8 else B[(s - 8) >> 2, s & 3])
+        relu = lambda A: np.maximum(A, 0)
+        f = f32
+        self.pu = 0
+        Z0 = self.init_bias(4, tb.b_e1)
+        Z1 = self.init_bias(4, tb.b_e1)
+        keep = None
+        for p in range(P):
+            row0 = 16 * RB * p
+            m1 = self.init_bias(RB, tb.b_e0 + row0)
+            m2, m3, m4 = (np.zeros((RB, 4, 64), f32) for _ in range(3))
+            self.gemm_w(m1, lambda s: (X[2][s] + X[3][s]) - f(4) * (X[0][s] + X[1][s]), RB, KG0)
+            self.gemm_w(m2, lambda s: (X[3][s] - X[2][s]) + f(4) * (X[0][s] - X[1][s]), RB, KG0)
+            self.gemm_w(m3, lambda s: (X[3][s] - X[1][s]) + f(2) * (X[2][s] - X[0][s]), RB, KG0)
+            self.gemm_w(m4, lambda s: (X[3][s] - X[1][s]) - f(2) * (X[2][s] - X[0][s]), RB, KG0)
+            sm, df, s2, d2 = m1 + m2, m1 - m2, m3 + m4, m3 - m4
+            Y = [sm + s2, df + f(2) * d2, sm + f(4) * s2, df + f(8) * d2]
+            self.gemm_w(Y[0], lambda s: X[3][s] - f(5) * X[1][s], RB, KG0)
+            self.gemm_w(Y[3], lambda s: X[0][s] - f(1.25) * X[2][s], RB, KG0)
+            for fr in range(4):
+                for tau in range(3):
+                    src = fr + tau - 1
+                    if 0 <= src < 4:
+                        self.nyq(Y[fr], xn[src], tau, row0)
+            Y = [relu(y) for y in Y]
+            if Q == 32:
+                self.gemm_w(Z0, two(Y[0], Y[1]), 4, 4)
+                self.gemm_w(Z1, two(Y[1], Y[2]), 4, 4)
+                if p & 1:
+                    self.gemm_w(Z1, two(keep, Y[3]), 4, 4)
+                else:
+                    keep = Y[3]
+            else:
+                self.gemm_w(Z0, chain(Y[0]), 4, 4)
+                self.gemm_w(Z0, chain(Y[1]), 4, 4)
+                self.gemm_w(Z1, chain(Y[1]), 4, 4)
+                self.gemm_w(Z1, chain(Y[2]), 4, 4)
+                self.gemm_w(Z1, chain(Y[3]), 4, 4)
+        Z0, Z1 = relu(Z0), relu(Z1)
+        V = self.init_bias(4, tb.b_e2)
+        self.gemm_w(V, chain(Z0), 4, 4)
+        self.gemm_w(V, chain(Z1), 4, 4)
+        V = relu(V)
+        Fe = self.init_bias(8, tb.b_e3)
+        self.gemm_w(Fe, chain(V), 8, 4)
+        Fe = relu(Fe)
+        gx = np.zeros((32, 4, 64), f32)
+        for q in range(4):
+            Gq = self.init_bias(8, tb.b_g + 128 * q)
+            self.gemm_w(Gq, chain(Fe), 8, 8)
+            gx[8 * q: 8 * q + 8] = Gq
+        assert self.pu == len(self.sched)
+        return {"X": X, "feat": Fe, "gx": gx}

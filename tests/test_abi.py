@@ -81,6 +81,8 @@ def test_packed_image_sizes(built):
     assert L.vad_debug_packed_floats(h, 8000, 0) == (3 * 40 + 3 * 32 + 2 * 16 + 32 + 4 * 64) * 256
     assert L.vad_debug_packed_floats(h, 16000, 5) == (4 * 4 + 26) * 16 * 256        # Winograd image: whole 16 KiB units
     assert L.vad_debug_packed_floats(h, 8000, 5) == (4 * 2 + 26) * 16 * 256
+    assert L.vad_debug_packed_floats(h, 16000, 6) == 54 * 16 * 256                  # F(4,3) image = the program, 54 | 42 units
+    assert L.vad_debug_packed_floats(h, 8000, 6) == 42 * 16 * 256
     assert L.vad_debug_packed_floats(h, 16000, 1) == 128 * 512
     n = L.vad_debug_packed_floats(h, 16000, 1)
     whh = np.empty(n, np.float32)

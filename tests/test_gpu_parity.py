@@ -980,22 +980,23 @@ def test_activation_accuracy(model):
     assert out["tanh"]["max_abs_err"] < 5e-7
 
 
-# ---- (10) the two evaluations of encoder 0 ------------------------------------------------------------------------
+# ---- (10) the three evaluations of encoder 0 ------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["16k", "8k"])
 def test_enc0_winograd_and_direct_agree(model, oracle, golden, tag):
-    """The fp32 frontend evaluates encoder 0 as two Winograd F(2,3) transforms over the STFT frame pairs (the default)
-    or tap by tap (option enc0=direct): both are fp32 throughout, both must meet the oracle to the TIGHT bound on real
-    speech and on the adversarial inputs, and they must agree with each other to fp32 round-off -- gate pre-activations
+    """The fp32 frontend evaluates encoder 0 as one Winograd F(4,3) tile over the chunk's 4 STFT frames (the default,
+    kernel_front_f43.hip), as two F(2,3) tiles over the frame pairs (enc0=winograd2, kernel_front_wino.hip) or tap by tap
+    (enc0=direct, kernel_front.hip): all are fp32 throughout, all must meet the oracle to the TIGHT bound on real speech
+    and on the adversarial inputs, and they must agree with each other to fp32 round-off -- gate pre-activations
     included."""
     if model.engine.precision != "fp32":
-        pytest.skip("enc0 selects between the two fp32 frontends")
+        pytest.skip("enc0 selects between the fp32 frontends")
     sr = SRS[tag]
     n = chunk_of(sr)
     eng = model.engine
     rows = np.concatenate([rolled_rows(golden[tag]["wav"], 40, 50 * n, 7919), _adversarial(sr, 50)[1]])
     want, wctx, wst = oracle.forward_audio(rows, sr)
     res = {}
-    for algo in ("winograd", "direct"):
+    for algo in ("winograd", "winograd2", "direct"):
         eng.set_option("enc0", algo)
         try:
             probs, ctx, st = run_engine(model, rows, sr)
@@ -1009,6 +1010,7 @@ def test_enc0_winograd_and_direct_agree(model, oracle, golden, tag):
         #  fp32 evaluations in different summation orders differ by up to 1.1e-4 relative there; probabilities by 4e-6)
         assert state_err(st, wst) < 3e-4, algo
         res[algo] = (probs, gx)
-    assert np.abs(res["winograd"][0] - res["direct"][0]).max() < 1e-5
-    g1, g2 = res["winograd"][1], res["direct"][1]
-    assert np.abs(g1 - g2).max() < 2e-5 * max(1.0, np.abs(g2).max())
+    for algo in ("winograd", "winograd2"):
+        assert np.abs(res[algo][0] - res["direct"][0]).max() < 1e-5, algo
+        g1, g2 = res[algo][1], res["direct"][1]
+        assert np.abs(g1 - g2).max() < 2e-5 * max(1.0, np.abs(g2).max()), algo

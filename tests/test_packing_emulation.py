@@ -20,7 +20,7 @@ def packed(built):
     assert L.vad_create_host_only(blob, len(blob), ctypes.byref(h)) == 0
     out = {}
     for sr in (16000, 8000):
-        for which in range(6):
+        for which in range(7):
             n = L.vad_debug_packed_floats(h, sr, which)
             a = np.empty(n, np.float32)
             assert L.vad_debug_packed_copy(h, sr, which, a.ctypes.data_as(_lib.f32p), n) == 0
@@ -74,6 +74,26 @@ def test_winograd_wave_program_matches_reference_activations(packed, golden, tag
     encoder output and gate pre-activations as the reference, to fp32 round-off -- and as the tap-by-tap program."""
     sr, g = SRS[tag], golden[tag]
     emu = E.FrontWinoEmu(sr, packed[sr, 5], packed[sr, 2])
+    out = emu.run(g["stage_x"])
+    feat = E.chain_to_dense(out["feat"])
+    ref = g["stage_enc3"][:, :, 0]
+    assert np.abs(feat - ref).max() < 3e-5
+    direct = E.FrontEmu(sr, packed[sr, 0], packed[sr, 2]).run(g["stage_x"])
+    assert np.abs(out["gx"] - direct["gx"]).max() < 1e-4 * max(1.0, np.abs(direct["gx"]).max())
+    prob, hn, cn = E.rec_step(packed[sr, 1], packed[sr, 2], emu.tb, out["gx"],
+                              g["stage_state_in"][0], g["stage_state_in"][1])
+    assert np.abs(prob - g["stage_prob"][:, 0]).max() < 1e-5
+    assert state_err(np.stack([hn, cn]), g["stage_state_out"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_f43_wave_program_matches_reference_activations(packed, golden, tag):
+    """front_f43_kernel's program (encoder 0 as ONE Winograd F(4,3) tile over the 4 frames, row parts, encoder 1 fed part
+    by part -- two taps per unit at 16 kHz, the tap-2 units spanning two parts --, units consumed in image order) on the
+    F(4,3) image the C++ packer produces: same encoder output and gate pre-activations as the reference, to fp32
+    round-off -- and as the tap-by-tap program."""
+    sr, g = SRS[tag], golden[tag]
+    emu = E.FrontF43Emu(sr, packed[sr, 6], packed[sr, 2])
     out = emu.run(g["stage_x"])
     feat = E.chain_to_dense(out["feat"])
     ref = g["stage_enc3"][:, :, 0]

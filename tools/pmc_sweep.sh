@@ -23,7 +23,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = "front" if ("front_kernel" in k or "front_wino_kernel" in k) else "rec" if "rec_kernel" in k else None
+        k = "front" if ("front_kernel" in k or "front_wino_kernel" in k or "front_f43_kernel" in k) else "rec" if "rec_kernel" in k else None
         if k: agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(agg.items()):
     print(f"{k:6s} {c:32s} {sum(v)/len(v):.6g}")

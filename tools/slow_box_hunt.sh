@@ -8,6 +8,9 @@ front=$(echo "$line" | python -c "import sys,json; print(json.loads(sys.stdin.re
 ./build/ubench/icache 2>/dev/null | tee -a $out/summary.txt
 echo "front_ms $front id $(rocm-smi --showuniqueid 2>/dev/null | grep -o '0x[0-9a-f]*' | head -1)" | tee $out/summary.txt
 slow=$(python -c "print(1 if float('$front') > 5.5 else 0)")
+if [ "$slow" = "1" ] || [ -n "${HUNT_FORCE_PMC:-}" ]; then
+  bash tools/pmc_front.sh $out/pmc | tee -a $out/summary.txt
+fi
 if [ "$slow" = "1" ]; then
   echo SLOW BOX | tee -a $out/summary.txt
   bash tools/box_check.sh > $out/box_check.log 2>&1

@@ -18,7 +18,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
-HIP = ["engine.hip", "kernel_front.hip", "kernel_front_wino.hip", "kernel_rec.hip", "kernel_front_split.hip", "kernel_rec_split.hip",
+HIP = ["engine.hip", "kernel_front.hip", "kernel_front_wino.hip", "kernel_front_f43.hip", "kernel_rec.hip", "kernel_front_split.hip", "kernel_rec_split.hip",
        "kernels_ref.hip", "kernel_scan.hip"]
 CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
@@ -83,7 +83,7 @@ def build(names):
     shared.mkdir(exist_ok=True)
     procs = []
     # translation units without knobs are compiled once
-    knob_units = {"kernel_front.hip", "kernel_front_wino.hip", "kernel_rec.hip", "kernel_front_split.hip", "kernel_rec_split.hip"}
+    knob_units = {"kernel_front.hip", "kernel_front_wino.hip", "kernel_front_f43.hip", "kernel_rec.hip", "kernel_front_split.hip", "kernel_rec_split.hip"}
     for src in HIP + CPP:
         if src in knob_units:
             continue
