@@ -256,6 +256,8 @@ def time_batch(eng, precision, step, probs, world, dist, dev, steps, warmup):
     """One arithmetic on one workload: clock ramp, warm-up, `steps` timed calls with the engine's hipEvents on."""
     import torch
     eng.set_precision(precision)
+    if os.environ.get("VAD_BENCH_ENC0"):           # tools/slow_box_hunt.sh: time an A/B form of the fp32 frontend (the
+        eng.set_option("enc0", os.environ["VAD_BENCH_ENC0"])   # roofline block of the line then does not apply)
     # the GPU takes some tens of milliseconds of load to reach its sustained clocks (measured: +4 % between the
     # 4th and the 40th step): a fixed untimed ramp precedes the W warm-up steps so that K steps time steady state
     for _ in range(max(0, CLOCK_RAMP_STEPS - warmup)):
