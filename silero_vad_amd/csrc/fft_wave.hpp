@@ -283,21 +283,21 @@ __device__ __forceinline__ void fft_frame(float (&X)[Q + 1], const int V, const 
     const f32x4 *tw1 = reinterpret_cast<const f32x4 *>(tab_lds + tb.tw1 + ln.g * Q * 4);
 #if VAD_XLANE_SWAP
     constexpr int H = Q / 2;
+    // lane group 3 multiplies by -i between the two stages.  Its values are the stage-A differences formed in the odd lane
+    // groups (1 keeps the lower half for 3, 3 its own upper half), so only those H differences are rotated, before they are
+    // traded: x*rotA + swap(x)*rotB
+    const f32x2 rotA = (ln.g & 1) ? f32x2{0.f, 0.f} : f32x2{1.f, 1.f};
+    const f32x2 rotB = (ln.g & 1) ? f32x2{1.f, -1.f} : f32x2{0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < H; ++q) trade32(z[q], z[q + H]);
 #pragma unroll
     for (int q = 0; q < H; ++q) {
-        const f32x2 u = z[q], v = z[q + H];
+        const f32x2 u = z[q], v = z[q + H], d = u - v;
         z[q] = u + v;
-        z[q + H] = u - v;
+        z[q + H] = __builtin_elementwise_fma(swap2(d), rotB, d * rotA);
     }
 #pragma unroll
     for (int q = 0; q < H; ++q) trade32(z[q], z[q + H]);
-    // lane group 3 multiplies by -i between the two stages: x*rotA + swap(x)*rotB
-    const f32x2 rotA = ln.g == 3 ? f32x2{0.f, 0.f} : f32x2{1.f, 1.f};
-    const f32x2 rotB = ln.g == 3 ? f32x2{1.f, -1.f} : f32x2{0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < Q; ++q) z[q] = __builtin_elementwise_fma(swap2(z[q]), rotB, z[q] * rotA);
 #pragma unroll
     for (int q = 0; q < H; ++q) trade16(z[q], z[q + H]);
 #pragma unroll
