@@ -71,8 +71,8 @@ __device__ __forceinline__ Coef opaque_coef() {
                  : "=s"(k.p1), "=s"(k.m1), "=s"(k.a), "=s"(k.b) : "n"(A_BITS), "n"(B_BITS));
     return k;
 }
-constexpr unsigned kF2 = 0x40000000u, kFm2 = 0xC0000000u, kF4 = 0x40800000u, kFm4 = 0xC0800000u, kFm5 = 0xC0A00000u,
-                   kFm125 = 0xBFA00000u;
+[[maybe_unused]] constexpr unsigned kF2 = 0x40000000u, kFm2 = 0xC0000000u, kF4 = 0x40800000u, kFm4 = 0xC0800000u, kFm5 = 0xC0A00000u,
+                   kFm125 = 0xBFA00000u, kF3 = 0x40400000u, kFm3 = 0xC0400000u, kFm025 = 0xBE800000u;
 
 // ---- the weight ring -------------------------------------------------------------------------------------------------
 struct Ring {
@@ -268,6 +268,15 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     // |Y_nyq| of chunk j lives in lane group 0 (X[Q]); every lane of the chunk needs it
     const float xn0 = __shfl(X0[Q], ln.j), xn1 = __shfl(X1[Q], ln.j), xn2 = __shfl(X2[Q], ln.j), xn3 = __shfl(X3[Q], ln.j);
 
+#if VAD_F43_EF
+    // The input transform reads the frames through E = x3 - x1 and F = x2 - x0 (kept in place of x3 and x0): t3/t4 = E +- 2F,
+    // t0 = E - 4 x1, t5 = -F - x2/4 are one fma each, t1 = (E + 4F) - 3(x1 + x2) and t2 = (E - 4F) + 3(x2 - x1) three.
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        X3[k] = X3[k] - X1[k];
+        X0[k] = X2[k] - X0[k];
+    }
+#endif
     ring.c0 = lds4(ring.a_cur);
     ring.c1 = lds4(ring.a_cur + 1024);
 
@@ -287,6 +296,20 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
             zero<RB>(Y1);
             zero<RB>(Y2);
             zero<RB>(Y3);
+#if VAD_F43_EF
+            // (E = X3, F = X0, x1 = X1, x2 = X2 from here on)
+            {   const Coef k = opaque_coef<kF4, kFm3>();
+                gemm_r<RB, KG0, 2>(Y0, [&](int s) VAD_INLINE {
+                    return fmaf(fmaf(X2[s], k.p1, X1[s]), k.b, fmaf(X0[s], k.a, X3[s])); }, ring);        // (E + 4F) - 3(x1 + x2)
+                const Coef k2 = opaque_coef<kFm4, kF3>();
+                gemm_r<RB, KG0, 2>(Y1, [&](int s) VAD_INLINE {
+                    return fmaf(fmaf(X1[s], k2.m1, X2[s]), k2.b, fmaf(X0[s], k2.a, X3[s])); }, ring);     // (E - 4F) + 3(x2 - x1)
+            }
+            {   const Coef k = opaque_coef<kF2, kFm2>();
+                gemm_r<RB, KG0, 2>(Y2, [&](int s) VAD_INLINE { return fmaf(X0[s], k.a, X3[s]); }, ring);  // E + 2F
+                gemm_r<RB, KG0, 2>(Y3, [&](int s) VAD_INLINE { return fmaf(X0[s], k.b, X3[s]); }, ring);  // E - 2F
+            }
+#else
             {   const Coef k = opaque_coef<kFm4, kF4>();
                 gemm_r<RB, KG0, 2>(Y0, [&](int s) VAD_INLINE {
                     return fmaf(fmaf(X1[s], k.p1, X0[s]), k.a, fmaf(X3[s], k.p1, X2[s])); }, ring);       // (x2+x3) - 4(x0+x1)
@@ -300,6 +323,7 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
                 gemm_r<RB, KG0, 2>(Y3, [&](int s) VAD_INLINE {
                     return fmaf(fmaf(X0[s], k2.m1, X2[s]), k2.b, fmaf(X1[s], k2.m1, X3[s])); }, ring);    // (x3-x1) - 2(x2-x0)
             }
+#endif
 #pragma unroll
             for (int m = 0; m < RB; ++m)
 #pragma unroll
@@ -311,10 +335,17 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
                     Y2[m][r] = fmaf(4.f, s2, sm);
                     Y3[m][r] = fmaf(8.f, d2, df);
                 }
+#if VAD_F43_EF
+            {   const Coef k = opaque_coef<kFm4, kFm025>();
+                gemm_r<RB, KG0, 2>(Y0, [&](int s) VAD_INLINE { return fmaf(X1[s], k.a, X3[s]); }, ring);              // x3 - 5 x1 = E - 4 x1
+                gemm_r<RB, KG0, 2>(Y3, [&](int s) VAD_INLINE { return fmaf(X2[s], k.b, -X0[s]); }, ring);             // x0 - 1.25 x2 = -F - x2/4
+            }
+#else
             {   const Coef k = opaque_coef<kFm5, kFm125>();
                 gemm_r<RB, KG0, 2>(Y0, [&](int s) VAD_INLINE { return fmaf(X1[s], k.a, X3[s]); }, ring);  // x3 - 5 x1
                 gemm_r<RB, KG0, 2>(Y3, [&](int s) VAD_INLINE { return fmaf(X2[s], k.b, X0[s]); }, ring);  // x0 - 1.25 x2
             }
+#endif
             nyq_update<RB>(Y0, xn0, wn + 128, ln);
             nyq_update<RB>(Y0, xn1, wn + 256, ln);
             nyq_update<RB>(Y1, xn0, wn, ln);

@@ -24,6 +24,7 @@ CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
 VARIANTS = {
     "base": [],
+    "xbasis": ["-DVAD_F43_EF=0"],                       # F(4,3) input transform from x0..x3 instead of (E, F, x1, x2)
     "shfl": ["-DVAD_XLANE_SWAP=0"],                     # cross-lane FFT stages through ds_bpermute (round-2a form)
     "nyq0": ["-DVAD_NYQ_VALU=0"],                       # Nyquist bin as a 9th MFMA k-group (round-1 form)
     "nyq0_slot24": ["-DVAD_NYQ_VALU=0", "-DVAD_SLOT_BLOCKS=24"],
