@@ -1,4 +1,5 @@
-// kernel_front_wino.hip -- the time-parallel part of the Silero-VAD hot path (same function as kernel_front.hip:
+// kernel_front_wino.hip -- A/B form (option enc0=winograd2; the product is kernel_front_f43.hip) of the time-parallel part
+// of the Silero-VAD hot path (same function as kernel_front.hip:
 //   PCM -> framing + right reflect pad -> Hann window -> 4 x real FFT magnitude -> 4 x ReLU(Conv1d k=3)
 //       -> W_ih * feat + (b_ih + b_hh)  => gx)
 // with encoder 0 -- 57 % of the kernel's matrix work -- evaluated as two Winograd F(2,3) transforms over the frame
