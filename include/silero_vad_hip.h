@@ -79,8 +79,8 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *                 of 10, all in fp32 (csrc/kernel_front_f43.hip; "winograd4" is accepted as a synonym) --, as two F(2,3)
  *                 tiles over the frame pairs (8 GEMMs, csrc/kernel_front_wino.hip) or tap by tap (csrc/kernel_front.hip);
  *                 the last two are kept as A/B forms for the tests
- *   "fused_decimation" = "1" (default) | "0": for sr = 32000 the fp32 frontend reads every 2nd sample itself; "0"
- *                 forces the separate decimation pass that 48000 and the other multiples of 16000 use (A/B for tests)
+ *   "fused_decimation" = "1" (default) | "0": for sr = 32000 and 48000 the fp32 frontend reads every 2nd / 3rd sample
+ *                 itself; "0" forces the separate decimation pass that the higher multiples of 16000 use (A/B for tests)
  *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)
  *   "trace_ptr" = device address (bring-up only): builds compiled with -DVAD_TRACE=1 write 16
  *                 int64 phase timestamps per frontend workgroup there; normal builds ignore it  */

@@ -42,8 +42,9 @@ struct FrontArgs {
     float *ctx_out;          // [B][C] written by the waves that own t == T-1 (may alias ctx_in)
     float *gx;               // scratch, tile-major, indexed with slab-relative t
     int B;
-    int dec;                 // 0/1: pcm is at the net's rate; 2: pcm is at 32 kHz and ld, pcm, tail index RAW samples -- the
-                             // kernel reads every 2nd one (fp32 frontend only); L, T, t0, nt stay in 16 kHz terms
+    int dec;                 // 0/1: pcm is at the net's rate; 2, 3: pcm is at 32 / 48 kHz and ld, pcm, tail index RAW samples --
+                             // the kernel reads every dec-th one (fp32 frontends; 3: kernel_front_f43.hip only); L, T, t0, nt stay
+                             // in 16 kHz terms
     long long *trace;        // bring-up only (VAD_TRACE builds): 16 slots per workgroup, else null
 };
 template <typename PcmT>

@@ -235,13 +235,14 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
     hipStream_t stream = (hipStream_t)stream_v;
     if (sr > 16000 && sr % 16000 == 0) {
         // sample-rate front door: a multiple of 16 kHz is decimated to 16 kHz, x[:, ::sr/16000], exactly as the
-        // reference does (vad_annotator.py:104-112), and takes the 16 kHz path.  For 32 kHz the fp32 frontend does it
-        // while loading (no extra pass over HBM); 48 kHz and higher multiples, the f16x3 frontend and impl=reference
-        // go through a decimated copy in engine scratch.
+        // reference does (vad_annotator.py:104-112), and takes the 16 kHz path.  For 32 and 48 kHz the fp32 frontend does
+        // it while loading (no extra pass over HBM; 48 kHz: the product frontend only, the A/B forms have no stride-3
+        // instantiation); higher multiples, the f16x3 frontend and impl=reference go through a decimated copy in engine
+        // scratch.
         if (B == 0 || L == 0) return VAD_OK;
         const int k = sr / 16000;
         HIP_TRY(e, hipSetDevice(e->device));
-        if (k == 2 && !e->split && !e->impl_reference && e->fused_decimation)
+        if ((k == 2 || (k == 3 && e->enc0 == 2)) && !e->split && !e->impl_reference && e->fused_decimation)
             return forward_core<PcmT>(e, 16000, k, B, L, pcm, ld, ctx, state, probs, ldp, stream);
         const long Ld = (L + k - 1) / k, ldd = (Ld + 15) / 16 * 16;
         int rc = grow(e, &e->d_decim, &e->decim_bytes, (size_t)B * ldd * sizeof(PcmT), stream, "decimation");

@@ -435,9 +435,10 @@ hipError_t launch_front_f43(int sr, const FrontArgs &a, hipStream_t s) {
     if (a.B <= 0 || a.nt <= 0) return hipSuccess;
     const long nst = (a.B + 15) / 16, total = nst * a.nt;
     const unsigned grid = (unsigned)((total + 3) / 4);
-    // a.dec == 2: 32 kHz input, decimation folded into the loads (fft_wave.hpp load_slice; 16 kHz net only)
-    if (sr == 16000 && a.dec == 2) hipLaunchKernelGGL((front_f43_kernel<32, PcmT, 2>), dim3(grid), dim3(256), 0, s, a);
-    else if (a.dec > 1) return hipErrorInvalidValue;
+    // a.dec == 2, 3: 32 / 48 kHz input, decimation folded into the loads (fft_wave.hpp load_slice; 16 kHz net only)
+    if (a.dec > 1 && (sr != 16000 || a.dec > 3)) return hipErrorInvalidValue;
+    if (a.dec == 3) hipLaunchKernelGGL((front_f43_kernel<32, PcmT, 3>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.dec == 2) hipLaunchKernelGGL((front_f43_kernel<32, PcmT, 2>), dim3(grid), dim3(256), 0, s, a);
     else if (sr == 16000) hipLaunchKernelGGL((front_f43_kernel<32, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((front_f43_kernel<16, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
