@@ -257,11 +257,18 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     for (int k = 0; k <= Q; ++k) X1[k] = X2[k] = X3[k] = 0.f;
 #pragma clang loop unroll(disable)
     for (int v = 0; v < 4; ++v) {
+        // (an array is moved only once it holds a frame: 6 array moves per tile instead of 12)
+        if (v >= 3) {
 #pragma unroll
-        for (int k = 0; k <= Q; ++k) {
-            X0[k] = X1[k];
-            X1[k] = X2[k];
-            X2[k] = X3[k];
+            for (int k = 0; k <= Q; ++k) X0[k] = X1[k];
+        }
+        if (v >= 2) {
+#pragma unroll
+            for (int k = 0; k <= Q; ++k) X1[k] = X2[k];
+        }
+        if (v >= 1) {
+#pragma unroll
+            for (int k = 0; k <= Q; ++k) X2[k] = X3[k];
         }
         fft_frame<Q, PcmT, DEC>(X3, v, a, tab, ln);
     }
