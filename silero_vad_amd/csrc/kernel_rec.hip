@@ -70,8 +70,16 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) gnext[q] = gx[((size_t)(t + 1) * 32 + 8 * q + w) * 64];
         }
-        // gates += W_hh h_{t-1}
+        // gates += W_hh h_{t-1}.  The head of step t-1 is finished by wave 0 in the middle of this step's MFMAs: right
+        // behind the barrier it would delay that wave's MFMAs by an LDS read + exp + rcp chain, and with one barrier per
+        // step the slowest wave paces all 8 (pbuf is double buffered: step t-1's partial sums stay until step t+1's).
         const f32x4 *hb = reinterpret_cast<const f32x4 *>(&hbuf[cur][0]) + lane;
+        const bool head = t > 0 && w == 0;                   // wave-uniform
+        float ps[8];
+        if (head) {
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) ps[ww] = pbuf[cur ^ 1][ww * 16 + j];
+        }
 #pragma unroll
         for (int kg = 0; kg < 8; ++kg) {
             const f32x4 hv = hb[kg * 64];                    // units 16kg + 4g + r of stream j
@@ -80,6 +88,12 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q][kg][r], hv[r], acc[q], 0, 0, 0);
+            if (kg == 3 && head) {
+                float p = bo;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) p += ps[ww];
+                if (valid && g == 0) a.probs[(size_t)b * a.ldp + a.t0 + t - 1] = sigmoid_f(p);
+            }
         }
         // pointwise LSTM + head partial
         float part = 0.f;
@@ -97,12 +111,13 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
         *reinterpret_cast<f32x4 *>(&hbuf[cur ^ 1][(w * 64 + lane) * 4]) = h;
         if (g == 0) pbuf[cur][w * 16 + j] = part;
         __syncthreads();
-        if (w == 0 && g == 0) {
-            float p = bo;
+    }
+    if (w == 0 && g == 0) {                                  // head of the last step
+        const int last = (int)((a.nt - 1) & 1);
+        float p = bo;
 #pragma unroll
-            for (int ww = 0; ww < 8; ++ww) p += pbuf[cur][ww * 16 + j];
-            if (valid) a.probs[(size_t)b * a.ldp + a.t0 + t] = sigmoid_f(p);
-        }
+        for (int ww = 0; ww < 8; ++ww) p += pbuf[last][ww * 16 + j];
+        if (valid) a.probs[(size_t)b * a.ldp + a.t0 + a.nt - 1] = sigmoid_f(p);
     }
     if (valid) {
         *reinterpret_cast<f32x4 *>(a.state + soff) = h;
