@@ -456,6 +456,13 @@ def run_corpus(args, rank, world, local, dist, steps):
                       "buckets_per_step": int(st.get("buckets", 0) / steps),
                       "padded_over_real_samples": round(st.get("padded", 0) / max(st.get("real", 1), 1), 4),
                       "projected_10k_hours_s": round(10_000.0 / (hours * world * steps / elapsed), 1)}
+    # what the link allows: the H2D rate measured while copying / bytes per chunk of the leg's sample format -- the leg's
+    # value can approach it (fully overlapped pipeline), never exceed it
+    link = next((l["h2d_GBps_while_copying"] for l in legs.values() if l["h2d_GBps_while_copying"]), None)
+    for name, l in legs.items():
+        gbps = l["h2d_GBps_while_copying"] or link
+        l["pcie_ceiling_chunks_per_s"] = round(gbps * 1e9 / (n * (4 if name == "fp32" else 2)) * world, 1) if gbps else None
+        l["fraction_of_pcie_ceiling"] = round(l["value"] / l["pcie_ceiling_chunks_per_s"], 3) if gbps else None
     if rank != 0:
         return None
     main = legs["int16"]
