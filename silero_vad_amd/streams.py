@@ -81,19 +81,20 @@ class RaggedPlan:
 
 
 class _StagePool:
-    """Two pinned host buffers + two device buffers reused for every bucket (pinned allocation is
-    expensive; the engine call of bucket k overlaps the staging + H2D copy of bucket k+1)."""
+    """Pinned host buffers + device buffers reused for every bucket (pinned allocation is expensive): one more slot
+    than there are compute lanes, so that staging + H2D of the next bucket overlap the kernels of the buckets in flight."""
 
-    def __init__(self, device):
+    def __init__(self, device, slots=2):
         self.device = device
-        self.host = [None, None]
-        self.dev = [None, None]
-        self.done = [None, None]            # event: H2D of this slot finished (host buffer reusable)
-        self.consumed = [None, None]        # event: the kernels that read this slot's device buffer finished
+        self.slots = slots
+        self.host = [None] * slots
+        self.dev = [None] * slots
+        self.done = [None] * slots          # event: H2D of this slot finished (host buffer reusable)
+        self.consumed = [None] * slots      # event: the kernels that read this slot's device buffer finished
         self.stream = torch.cuda.Stream(device)
 
     def get(self, k, nbytes):
-        i = k & 1
+        i = k % self.slots
         if self.done[i] is not None:
             self.done[i].synchronize()
         if self.host[i] is None or self.host[i].numel() < nbytes:
@@ -109,6 +110,29 @@ class _StagePool:
                 self.dev[i] = torch.empty(cap, dtype=torch.uint8, device=self.device)
             self.consumed[i] = None
         return i
+
+
+def _compute_lanes(model, want):
+    """[(model, stream)]: lane 0 is the caller's model on the caller's stream; further lanes are sibling engines (own
+    scratch, same device and arithmetic) on their own streams.  A bucket's recurrence is latency-bound -- 4.7 us per time
+    step on as few CUs as the bucket has stream tiles -- so buckets on different lanes overlap: one lane's recurrence runs
+    beside the other lane's frontend instead of in front of it."""
+    cur = torch.cuda.current_stream(model.device)
+    lanes = [(model, cur)]
+    if want > 1 and getattr(model, "precision", "auto") != "auto" and hasattr(model, "engine") and \
+            hasattr(model.engine, "_h"):
+        sibs = getattr(model, "_lane_siblings", None)
+        if sibs is None:
+            sibs = model._lane_siblings = []
+        while len(sibs) < want - 1:
+            sib = type(model)(device=model.engine.device, precision=model.precision)
+            sibs.append((sib, torch.cuda.Stream(model.device)))
+        for sib, st in sibs[: want - 1]:
+            if sib.precision != model.precision:
+                sib.precision = model.precision
+                sib.engine.set_precision(model.precision)
+            lanes.append((sib, st))
+    return lanes
 
 
 def _stage_into(audios, idxs, width, dtype, dst: torch.Tensor):
@@ -151,7 +175,7 @@ def _repair_out_of_range(audios, idxs, probs, model, sampling_rate, n):
 
 
 def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
-                   max_bytes: int = 256 << 20, plan: RaggedPlan = None, post=None, meta=None):
+                   max_bytes: int = 256 << 20, plan: RaggedPlan = None, post=None, meta=None, lanes: int = 2):
     """Generator over the plan's buckets: yields (indices, probs[len(indices), T_bucket] on the CPU).
     Recording i of a bucket owns the first ceil(len_i / N) entries of its row.
 
@@ -159,7 +183,8 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     right after the bucket's kernels; the generator then yields (indices, [those tensors on the CPU], probs_dev) and
     the probabilities themselves never leave the GPU (ragged_speech_segments scans them there).  `meta` (indices ->
     small CPU int64 tensor) rides to the GPU with the bucket's PCM on the copy stream (pinned, asynchronous), so that
-    nothing in the loop blocks the host on the compute stream."""
+    nothing in the loop blocks the host on the compute stream.  `lanes`: buckets are issued round-robin to this many
+    engines on their own streams (_compute_lanes); results are yielded in bucket order."""
     n = chunk_size(sampling_rate)
     as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
     dtype = torch.int16 if as_i16 else torch.float32
@@ -176,10 +201,13 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             _stage_into(audios, idxs, width, dtype, host)
             yield idxs, fast(host, sampling_rate).cpu()
         return
+    lane_list = _compute_lanes(model, max(1, int(lanes)))
     pool = getattr(model, "_stage_pool", None)
-    if pool is None:
-        pool = model._stage_pool = _StagePool(dev)
+    if pool is None or pool.slots != len(lane_list) + 1:
+        pool = model._stage_pool = _StagePool(dev, len(lane_list) + 1)
     cur = torch.cuda.current_stream(dev)
+    for _, st in lane_list[1:]:
+        st.wait_stream(cur)                               # sibling lanes start behind whatever the caller has queued
     copies = []                                           # (start event, end event) of every H2D copy, for STATS
 
     def stage(k):
@@ -218,36 +246,41 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         return idxs, outs, probs_dev
 
     staged = stage(0) if plan.buckets else None
-    prev = None
+    inflight = []                                         # buckets enqueued and not yet yielded, oldest first
     for k, idxs in enumerate(plan.buckets):
         x, ev, slot, m_dev, _keep = staged
-        cur.wait_event(ev)
-        x.record_stream(cur)                              # allocated on pool.stream, read on `cur`
-        if m_dev is not None:
-            m_dev.record_stream(cur)
-        probs = fast(x, sampling_rate, guarded=False)     # async: kernels of bucket k (flagged rows: _repair_...)
-        pool.consumed[slot] = torch.cuda.Event()
-        pool.consumed[slot].record(cur)
-        back = [probs] if post is None else post(probs, idxs, m_dev)
-        outs = []
-        for o in back:                                    # pinned blocks come from torch's caching host allocator
-            h = torch.empty(o.shape, dtype=o.dtype, pin_memory=True)
-            h.copy_(o, non_blocking=True)
-            STATS["d2h_bytes"] += h.numel() * h.element_size()
-            outs.append(h)
-        done = torch.cuda.Event()
-        done.record(cur)
+        lane_model, lane_stream = lane_list[k % len(lane_list)]
+        lane_stream.wait_event(ev)
+        with torch.cuda.stream(lane_stream):
+            x.record_stream(lane_stream)                  # allocated on pool.stream, read on the lane's stream
+            if m_dev is not None:
+                m_dev.record_stream(lane_stream)
+            probs = lane_model.audio_forward_device(x, sampling_rate, guarded=False)   # async (flagged rows: _repair_...)
+            pool.consumed[slot] = torch.cuda.Event()
+            pool.consumed[slot].record(lane_stream)
+            back = [probs] if post is None else post(probs, idxs, m_dev)
+            outs = []
+            for o in back:                                # pinned blocks come from torch's caching host allocator
+                h = torch.empty(o.shape, dtype=o.dtype, pin_memory=True)
+                h.copy_(o, non_blocking=True)
+                STATS["d2h_bytes"] += h.numel() * h.element_size()
+                outs.append(h)
+            done = torch.cuda.Event()
+            done.record(lane_stream)
         staged = stage(k + 1) if k + 1 < len(plan.buckets) else None   # CPU packs k+1 meanwhile
-        if prev is not None:
-            prev[2].synchronize()
-            yield finish(prev)
-        prev = (idxs, outs, done, probs)
-    if prev is not None:
-        prev[2].synchronize()
-        for a, b in copies:
-            b.synchronize()
-            STATS["h2d_s"] += a.elapsed_time(b) / 1e3
-        yield finish(prev)
+        inflight.append((idxs, outs, done, probs))
+        while len(inflight) > len(lane_list):
+            first = inflight.pop(0)
+            first[2].synchronize()
+            yield finish(first)
+    for first in inflight:
+        first[2].synchronize()
+        yield finish(first)
+    for a, b in copies:
+        b.synchronize()
+        STATS["h2d_s"] += a.elapsed_time(b) / 1e3
+    for _, st in lane_list[1:]:
+        cur.wait_stream(st)
 
 
 def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,

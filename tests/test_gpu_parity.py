@@ -776,7 +776,8 @@ def test_bit_stable_under_foreign_load(model, golden, kind):
     dev = model.device
     x = _strided_rows(torch.from_numpy(golden["16k"]["wav"]).to(dev), B, T * n, 7919)
     eng = model.engine
-    side = torch.cuda.Stream(dev)
+    sides = [torch.cuda.Stream(dev) for _ in range(8)]    # see pick_side() below
+    side = sides[0]
     a = torch.randn(1 << 24, device=dev)
     b = torch.randn(1 << 24, device=dev)
     c = torch.zeros(1 << 24, device=dev)
@@ -807,6 +808,24 @@ def test_bit_stable_under_foreign_load(model, golden, kind):
     p0, s0 = run()
     torch.cuda.synchronize()
     per_group = 5
+    # HIP multiplexes streams onto a few hardware queues; a stream that shares the main stream's queue is simply
+    # serialised with it (which streams do depends on how many the process has created so far -- the corpus path's
+    # compute lanes and copy streams count).  Take the first candidate on which the tenant really runs beside the engine.
+    main0 = torch.cuda.current_stream(dev)
+    pe = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for cand in sides:
+        side = cand
+        torch.cuda.synchronize()
+        pe[0].record(side)
+        foreign()
+        pe[1].record(side)
+        pe[2].record(main0)
+        run()
+        pe[3].record(main0)
+        torch.cuda.synchronize()
+        s_m, e_s, e_m = pe[0].elapsed_time(pe[2]), pe[0].elapsed_time(pe[1]), pe[0].elapsed_time(pe[3])
+        if min(e_s, e_m) - max(0.0, s_m) > 0.5:           # ms in flight together
+            break
     t_alone = timed(lambda: [run() for _ in range(per_group)])
     t_foreign = timed(foreign)
     bad, launches, t_both, together = 0, 0, 0.0, 0.0
