@@ -521,7 +521,7 @@ def main():
     ap.add_argument("--streams", type=int, default=STREAMS, help=argparse.SUPPRESS)
     ap.add_argument("--chunks", type=int, default=CHUNKS_PER_STREAM, help=argparse.SUPPRESS)
     ap.add_argument("--live", type=int, default=LIVE_STREAMS, help=argparse.SUPPRESS)
-    ap.add_argument("--recordings", type=int, default=1024, help=argparse.SUPPRESS)
+    ap.add_argument("--recordings", type=int, default=4096, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true", help="N=1: skip other_precision / other_configs")
     ap.add_argument("--dry", action="store_true", help="no GPU: exercise launch/barrier/reduce/print only (gloo)")

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/silero_vad_hip.h"
+#include "host_threads.hpp"
 #include "scanner.hpp"
 
 extern "C" void vad_segment_params_default(vad_segment_params *p, int sampling_rate) {
@@ -46,7 +47,7 @@ extern "C" long vad_segment_probs_batch(const float *probs, long ldp, long n_str
     if (p->sampling_rate != 8000 && p->sampling_rate != 16000) return -2;
     for (long i = 0; i < n_streams; ++i)
         if (n_chunks[i] < 0 || n_chunks[i] > ldp || audio_len[i] < 0) return -1;
-    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int nt = threads > 0 ? threads : vad::default_host_threads(64);
     nt = (int)std::max<long>(1, std::min<long>(nt, n_streams / 64 + 1));
     auto work = [&](long lo, long hi) {
         for (long i = lo; i < hi; ++i)

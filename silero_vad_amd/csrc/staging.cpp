@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/silero_vad_hip.h"
+#include "host_threads.hpp"
 
 extern "C" int vad_stage_rows(const void *const *rows, const long *lens, long n, long width,
                               size_t elem_size, void *dst, int threads) {
@@ -18,7 +19,7 @@ extern "C" int vad_stage_rows(const void *const *rows, const long *lens, long n,
     if (!rows || !lens || !dst) return VAD_ERR_ARG;
     for (long i = 0; i < n; ++i)
         if (lens[i] < 0 || lens[i] > width || (lens[i] > 0 && !rows[i])) return VAD_ERR_ARG;
-    int nt = threads > 0 ? threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    int nt = threads > 0 ? threads : vad::default_host_threads(32);
     const size_t bytes = (size_t)n * width * elem_size;
     nt = (int)std::max<size_t>(1, std::min<size_t>(nt, bytes / (4u << 20) + 1));
     auto work = [&](long lo, long hi) {
