@@ -62,7 +62,7 @@ WORK = {
             "front_mfma_direct": 2 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),   # 4 480 (enc0 tap by tap)
             "front_split_mfma": 2 * 3 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
             # VALU issue cycles per tile beside the MFMAs (same pipe): 2 612 packed x 5.4 + 4 266 other x 2.6
-            # (SQ_INSTS_VALU - SQ_INSTS_MFMA per tile, profiles/r02j_fp32_summary.md; rates profiles/r02d_issue_pipes.md)
+            # (SQ_INSTS_VALU - SQ_INSTS_MFMA per tile, profiles/r02k_fp32_summary.md; rates profiles/r02d_issue_pipes.md)
             "front_valu_cycles": 25_200,
             "rec_mfma": 2 * 512 * 128, "front_kernel": "front_f43_kernel<32, float>",
             "front_split_kernel": "front_split_kernel<32, float>"},
@@ -71,7 +71,7 @@ WORK = {
            "front_mfma": 42 * 64 * 2048 // 16,        # 2 688 MFMAs / tile (Winograd F(4,3))
            "front_mfma_direct": 2 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),    # 3 200
            "front_split_mfma": 2 * 3 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
-           "front_valu_cycles": 12_500,                # 1 280 packed x 5.4 + 2 144 other x 2.6 (profiles/r02j_8k_summary.md)
+           "front_valu_cycles": 12_500,                # 1 280 packed x 5.4 + 2 144 other x 2.6 (profiles/r02k_8k_summary.md)
            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_f43_kernel<16, float>",
            "front_split_kernel": "front_split_kernel<16, float>"},
 }
