@@ -19,6 +19,10 @@
 #include "device_api.hpp"
 #include "layout.hpp"
 
+#ifndef VAD_REC_GATE_MAJOR
+#define VAD_REC_GATE_MAJOR 1     // 0: k-group-major MFMA order, all activations after the last MFMA (A/B)
+#endif
+
 namespace vad {
 namespace {
 
@@ -80,6 +84,48 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
 #pragma unroll
             for (int ww = 0; ww < 8; ++ww) ps[ww] = pbuf[cur ^ 1][ww * 16 + j];
         }
+#if VAD_REC_GATE_MAJOR
+        // Gate-major order -- i, f, g first (all 8 k-groups each), the o gate last -- so that the pointwise work of the first
+        // three gates, the cell update and tanh(c) are in flight while the o gate's 32 MFMAs issue; only sigmoid(o) * tanh(c)
+        // is left behind the last MFMA.  The quarter-rate transcendental chains execute beside the matrix pipe, they need
+        // not follow it (1.216 -> 1.13 ms; splitting further -- i, f | g | o -- was slower, 1.156).  Same sums in the same
+        // order per accumulator, same pointwise formulas: bit-identical results.
+        f32x4 hv[8];
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) hv[kg] = hb[kg * 64];          // units 16kg + 4g + r of stream j
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q][kg][r], hv[kg][r], acc[q], 0, 0, 0);
+        if (head) {
+            float p = bo;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) p += ps[ww];
+            if (valid && g == 0) a.probs[(size_t)b * a.ldp + a.t0 + t - 1] = sigmoid_f(p);
+        }
+        float th[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = sigmoid_f(acc[0][r]), fg = sigmoid_f(acc[1][r]), gg = tanh_f(acc[2][r]);
+            const float cn = fmaf(fg, c[r], ig * gg);
+            c[r] = cn;
+            th[r] = tanh_f(cn);
+        }
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[3][kg][r], hv[kg][r], acc[3], 0, 0, 0);
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            h[r] = sigmoid_f(acc[3][r]) * th[r];
+            part = fmaf(wo[r], fmaxf(h[r], 0.f), part);
+        }
+#else
 #pragma unroll
         for (int kg = 0; kg < 8; ++kg) {
             const f32x4 hv = hb[kg * 64];                    // units 16kg + 4g + r of stream j
@@ -106,6 +152,7 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
             h[r] = og * tanh_f(cn);
             part = fmaf(wo[r], fmaxf(h[r], 0.f), part);
         }
+#endif
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
         *reinterpret_cast<f32x4 *>(&hbuf[cur ^ 1][(w * 64 + lane) * 4]) = h;
