@@ -4,7 +4,8 @@ the network in which every matrix product can be evaluated as
     f32 / f64        plain
     h1               fp16 operands
     h3 / h3z / h4    fp16 split, 3 products (subnormals kept / flushed), 4 products
-    b3 / b6          bf16 split, 3 products (2 parts) / 6 products (3 parts)
+    b3 / b6 / b9     bf16 split, 3 products (2 parts) / 6 products (3 parts) / all 9 products of 3 parts (exact operands:
+                     three bf16 pieces carry all 24 bits of an fp32 value)
 with fp32 results, run over the 60 s (16 kHz) and 169 s (8 kHz) speech fixtures and compared with the
 golden probabilities recorded from the reference model.
     python tests/study_split_precision.py f32 h1 h3 h3z b3 b6
@@ -50,6 +51,13 @@ def mm(A,Bm):
         if n==6:
             a=splitbf(A,3); b=splitbf(Bm,3)
             return (a[0]@b[0]+a[0]@b[1]+a[1]@b[0]+a[1]@b[1]+a[0]@b[2]+a[2]@b[0]).astype(f32)
+        if n==9:
+            a=splitbf(A,3); b=splitbf(Bm,3)
+            acc=np.zeros((A.shape[0],Bm.shape[1]),f32)
+            for i in range(3):
+                for j in range(3):
+                    acc=(acc+(a[i]@b[j]).astype(f32)).astype(f32)          # nine fp32 partial sums, added in fp32
+            return acc
     raise ValueError(MODE)
 def sigmoid(x): return (1/(1+np.exp(-x.astype(np.float64)))).astype(f32)
 class Net:
