@@ -1,15 +1,28 @@
-// host_threads.hpp -- how many host threads the native helpers (staging.cpp, segmenter.cpp) may use by default.
-// std::thread::hardware_concurrency() reports the machine (256 on the MI355X hosts); a container usually owns far fewer
-// CPUs through its cgroup quota (16 there), and running more busy threads than the quota gets the whole process throttled
-// for the rest of the scheduling period -- measured: staging 4 GB on 32 threads under a 16-CPU quota took 458 ms instead
-// of 35.  So: min(affinity mask, cgroup CPU quota, cap).
+// host_threads.hpp -- the host-side worker threads of the native helpers (staging.cpp, segmenter.cpp): how many there may
+// be, where they run, and a persistent pool so that no call pays for thread creation.
+//
+// How many.  std::thread::hardware_concurrency() reports the machine (256 on the MI355X hosts); a container usually owns
+// far fewer CPUs through its cgroup quota (16 there), and running more busy threads than the quota gets the whole process
+// throttled for the rest of the scheduling period -- measured: staging 4 GB on 32 threads under a 16-CPU quota took 458 ms
+// instead of 35.  The quota belongs to the NODE, not to the process: with one process per GPU (the reference's
+// process-per-worker pattern, examples/parallel_example.ipynb cells 5, 7; here torchrun --nproc-per-node N) every rank
+// may use 1/N of it, or N ranks x 16 threads under a 16-CPU quota is exactly the oversubscription above.  So:
+//     min(affinity mask, cgroup CPU quota) / LOCAL_WORLD_SIZE, at least 1, at most `cap`
+// (LOCAL_WORLD_SIZE is what torchrun exports; SILERO_VAD_AMD_HOST_THREADS overrides the result).
+//
+// Where.  vad_bind_host_to_device (engine.hip) narrows the calling thread's affinity to the CPUs of the GPU's NUMA node;
+// pool threads are created afterwards and inherit it, and pinned buffers allocated afterwards are first touched there.
 #pragma once
 #include <sched.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <vector>
 
 namespace vad {
 
@@ -33,13 +46,117 @@ inline int cgroup_cpu_quota() {            // CPUs' worth of quota, 0 = unlimite
     return (int)std::max(1L, quota / period);
 }
 
-inline int default_host_threads(int cap) {
+inline int env_int(const char *name) {
+    const char *v = std::getenv(name);
+    if (!v || !*v) return 0;
+    const long x = std::strtol(v, nullptr, 10);
+    return x > 0 && x < (1 << 20) ? (int)x : 0;
+}
+
+// CPUs this PROCESS may keep busy: the node's budget (affinity mask, cgroup quota) divided among the ranks of the node.
+inline int host_cpu_budget() {
     int n = (int)std::max(1u, std::thread::hardware_concurrency());
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
     const int q = cgroup_cpu_quota();
     if (q > 0) n = std::min(n, q);
-    return std::max(1, std::min(n, cap));
+    const int ranks = env_int("LOCAL_WORLD_SIZE");
+    if (ranks > 1) n = std::max(1, n / ranks);
+    return n;
 }
+
+inline int default_host_threads(int cap) {
+    const int forced = env_int("SILERO_VAD_AMD_HOST_THREADS");
+    if (forced) return std::max(1, std::min(forced, 256));
+    return std::max(1, std::min(host_cpu_budget(), cap));
+}
+
+// A persistent pool: run(n, fn) executes fn(k) for k in [0, n) on the pool's threads plus the caller and returns when all
+// are done.  Threads are created on first use (after any affinity binding the process did) and sleep on a condition
+// variable between calls; one run at a time (callers are serialised by a mutex: the engine's users are single-threaded
+// per engine, but the pool is process-wide).
+class HostPool {
+public:
+    static HostPool &get() {
+        static HostPool p;
+        return p;
+    }
+    int size() {                               // worker threads + the caller
+        std::lock_guard<std::mutex> g(api_);
+        return (int)threads_.size() + 1;
+    }
+    void run(int n, const std::function<void(int)> &fn) {
+        if (n <= 0) return;
+        if (n == 1) {
+            fn(0);
+            return;
+        }
+        std::lock_guard<std::mutex> g(api_);
+        ensure(n - 1);
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &fn;
+            next_ = 0;
+            total_ = n;
+            pending_ = n;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        work();                                // the caller takes items too
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    HostPool() = default;
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    void ensure(int want) {
+        want = std::min(want, 255);
+        while ((int)threads_.size() < want) threads_.emplace_back([this] { loop(); });
+    }
+    void work() {
+        for (;;) {
+            int k;
+            const std::function<void(int)> *f;
+            {
+                std::lock_guard<std::mutex> l(m_);
+                if (!fn_ || next_ >= total_) return;
+                k = next_++;
+                f = fn_;
+            }
+            (*f)(k);
+            std::lock_guard<std::mutex> l(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return epoch_ != seen; });
+                seen = epoch_;
+                if (stop_) return;
+            }
+            work();
+        }
+    }
+    std::mutex api_, m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int next_ = 0, total_ = 0, pending_ = 0;
+    unsigned long epoch_ = 0;
+    bool stop_ = false;
+};
 
 }  // namespace vad

@@ -69,6 +69,8 @@ VARIANTS = {
     "w8": ["-DVAD_SPLIT_WAVES=8"],
     "prio1": ["-DVAD_SPLIT_PRIO=1"], "prio3": ["-DVAD_SPLIT_PRIO=3"],
     "ntpcm": ["-DVAD_SPLIT_NT_PCM=1"], "ntgx": ["-DVAD_SPLIT_NT_GX=1"],
+    "rec_inphase": ["-DVAD_REC_SKEW=0"],               # round-2 recurrence: all 8 waves in phase, one barrier per step
+    "rec_noprio": ["-DVAD_REC_PRIO=0"],                # skewed recurrence without s_setprio on the tail wave
     "recd1": ["-DVAD_REC_DEPTH=1"], "recd3": ["-DVAD_REC_DEPTH=3"],
     # "pk*": the split translation units WITH packed-fp32 VALU instructions -- reproduces the corruption
     # described in kernel_front_split.hip under two workgroups per CU (tools/split_stress.py)
