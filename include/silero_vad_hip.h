@@ -15,9 +15,13 @@
  *     asynchronous with respect to the host unless stated otherwise;
  *   - one engine per GPU; an engine is not thread-safe (the reference model object is not
  *     either: src/silero_vad/utils_vad.py:51-92 mutates _state/_context per call);
- *   - the arithmetic is fp32 throughout, as in the reference (the opt-in
- *     alternative is described under option "precision" below); sample rates 16000 (chunk N=512,
- *     context C=64) and 8000 (N=256, C=32).
+ *   - the arithmetic is fp32 throughout, as in the reference: every contraction is a chain
+ *     of v_mfma_f32_16x16x4_f32 (an fmaf chain, one rounding per product); what differs from the reference is WHICH
+ *     fp32 sums are formed -- the STFT is a real FFT instead of the dense DFT-basis convolution, encoder 0 is evaluated in
+ *     Winograd F(4,3) form (transformed weights, formed in double and rounded once) -- not their precision.  Agreement
+ *     with the reference is therefore by tolerance, not bitwise: max |dp| 2e-6 on the reference's fixtures, <= 2e-5
+ *     asserted on everything the GPU suite runs (the contract is 1e-4), final (h, c) within 1e-4;
+ *   - sample rates 16000 (chunk N=512, context C=64) and 8000 (N=256, C=32); multiples of 16000 are decimated.
  */
 #ifndef SILERO_VAD_HIP_H
 #define SILERO_VAD_HIP_H
@@ -50,6 +54,11 @@ enum vad_status {
  * and uploads it to `device`.                                                                  */
 int  vad_create(const void *weights, size_t nbytes, int device, vad_engine **out);
 void vad_destroy(vad_engine *e);
+/* A second handle on the same GPU: shares the read-only weight images (no second copy) and starts with the same options,
+ * owns its scratch.  An engine and its clones may have calls in flight on different streams at the same time (one engine
+ * may not: its scratch is per call).  The reference gets concurrency by one model object per process
+ * (examples/parallel_example.ipynb cell 5); inside one process on one GPU this is the equivalent.  Destroy every handle. */
+int  vad_clone(const vad_engine *e, vad_engine **out);
 const char *vad_strerror(int status);
 const char *vad_last_error(const vad_engine *e);   /* detail text of the last failing call */
 int  vad_device(const vad_engine *e);
@@ -61,24 +70,14 @@ int  vad_geometry(int sr, int *chunk, int *context);
 /* Options (strings so that bindings need no enum mirror):
  *   "impl"      = "mfma" (default, the product path) | "reference" (slow all-VALU kernels kept
  *                 as an on-device A/B for tests; never the default)
- *   "precision" = "fp32" (default) | "f16x3".  fp32: every contraction is an exact
- *                 v_mfma_f32_16x16x4_f32 chain (bitwise an fmaf chain) -- the reference's arithmetic.
- *                 f16x3 (OPT-IN, narrower than fp32): every product is evaluated as a 3-term fp16 split
- *                 (a_hi b_hi + a_hi b_lo + a_lo b_hi, x_hi = fp16(x), x_lo = fp16(x - x_hi)) on the f16
- *                 matrix cores with fp32 accumulation.  An operand keeps max(2^-22 |x|, 2^-25) absolute
- *                 accuracy: 22 significant bits for |x| >= 2^-3, fewer below (x_lo falls into the fp16
- *                 subnormals), so this is an absolute-error approximation, NOT fp32-equivalent; measured
- *                 |dp| <= 1.2e-5 against the reference on the fixtures.  Its activations must stay below
- *                 the fp16 range (65504): a stream that leaves it gets NaN probabilities from that chunk
- *                 on and must be rerun with "fp32".  It also requires a single-tenant GPU: see DESIGN.md
- *                 section 4.2b (packed-fp32 VALU in a co-resident wave corrupts f16 MFMA results).
+ *   "precision" = "fp32": the only arithmetic (accepted so that a binding may state it; anything else is VAD_ERR_OPTION)
  *   "gx_cap_mib"= cap, in MiB, of the engine's scratch for the LSTM input-gate pre-activations (default 6144);
  *                 a call whose B x T needs more is processed in time slabs, transparently
- *   "enc0"      = "winograd" (default) | "winograd2" | "direct": how the fp32 frontend evaluates encoder 0 (more than
- *                 half of its matrix work): as ONE Winograd F(4,3) tile over the chunk's 4 STFT frames -- 6 GEMMs instead
- *                 of 10, all in fp32 (csrc/kernel_front_f43.hip; "winograd4" is accepted as a synonym) --, as two F(2,3)
- *                 tiles over the frame pairs (8 GEMMs, csrc/kernel_front_wino.hip) or tap by tap (csrc/kernel_front.hip);
- *                 the last two are kept as A/B forms for the tests
+ *   "enc0"      = "winograd" (default; "winograd4" is a synonym): encoder 0 -- more than half of the frontend's matrix
+ *                 work -- as ONE Winograd F(4,3) tile over the chunk's 4 STFT frames, 6 GEMMs instead of 10, all in fp32
+ *                 (csrc/kernel_front_f43.hip).  The test build libsilero_vad_hip_ab.so (__graft_entry__.build, -DVAD_AB=1)
+ *                 also accepts "winograd2" (two F(2,3) tiles, csrc/kernel_front_wino.hip) and "direct" (tap by tap,
+ *                 csrc/kernel_front.hip: bitwise the plain fmaf chain over the taps) as A/B forms for the parity tests
  *   "fused_decimation" = "1" (default) | "0": for sr = 32000 and 48000 the fp32 frontend reads every 2nd / 3rd sample
  *                 itself; "0" forces the separate decimation pass that the higher multiples of 16000 use (A/B for tests)
  *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)
@@ -104,7 +103,7 @@ int  vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ct
  * A last partial chunk is right-padded with zeros, as the reference does (:141-148).
  * `sr` may also be a multiple of 16000 (32000, 48000, ...): the input is then decimated to 16 kHz,
  * x[:, ::sr/16000] (no filter, first sample kept -- vad_annotator.py:104-112, utils_vad.py:39-42), on
- * the device -- for 32 kHz inside the frontend's own loads, without an extra pass over HBM -- and L / T
+ * the device -- for 32 and 48 kHz inside the frontend's own loads, without an extra pass over HBM -- and L / T
  * refer to the input / to ceil(ceil(L / k) / 512) chunks.
  *   pcm    dev [B][L]   row stride `ld`
  *   probs  dev [B][T]   row stride `ldp`                                                        */
@@ -117,7 +116,8 @@ int  vad_forward_audio_i16(vad_engine *e, int sr, int B, long L, const int16_t *
                            float *ctx, float *state, float *probs, long ldp, void *stream);
 
 /* Pre-size the engine-owned scratch for (sr, B, T) so that later calls allocate nothing (needed
- * before capturing vad_step/vad_forward_audio into a hipGraph).  Synchronous.                    */
+ * before capturing vad_step/vad_forward_audio into a hipGraph; T counts chunks at the net's rate, sr may be a
+ * multiple of 16000 -- the worst-case tail copy of a 48 kHz fp32 input is included).  Synchronous.                 */
 int  vad_reserve(vad_engine *e, int sr, int B, long T);
 size_t vad_scratch_bytes(const vad_engine *e);
 /* The engine's scratch only ever grows; when a later call (or vad_reserve) needs more than it has, the
@@ -163,7 +163,7 @@ long vad_segment_probs(const float *probs, long n, long audio_len, const vad_seg
  * vad_forward_audio (the reference fans this out as one Python process per file,
  * examples/parallel_example.ipynb cells 5, 7).  Stream i's segments go to
  * out[i * cap_per_stream ...], their number (may exceed cap_per_stream) to counts[i].  Streams are
- * split over `threads` host threads (<= 0: all hardware threads).  Returns the total number of
+ * split over `threads` persistent host threads (<= 0: vad_host_threads()).  Returns the total number of
  * segments, <0 on bad arguments.                                                                */
 long vad_segment_probs_batch(const float *probs, long ldp, long n_streams, const long *n_chunks,
                              const long *audio_len, const vad_segment_params *p, vad_segment *out,
@@ -188,29 +188,45 @@ int  vad_segment_probs_device(vad_engine *e, const float *probs, long ldp, const
  * is then copied to the GPU and handed to vad_forward_audio[_i16]).  Zero padding on the right is what
  * the reference does to a recording's last chunk (src/silero_vad/utils_vad.py:326-327); the network
  * is causal, so padding further does not change the recording's own probabilities.  The copy is
- * split over `threads` host threads (<= 0: up to 32).                                              */
+ * split over `threads` persistent host threads (<= 0: vad_host_threads(), at most 32).              */
 int  vad_stage_rows(const void *const *rows, const long *lens, long n, long width, size_t elem_size,
                     void *dst, int threads);
+
+/* The same packing WITHOUT a host-side copy, for recordings that already sit in page-locked host memory (hipHostMalloc,
+ * torch pin_memory, or vad_host_register below): rows[i] / lens[i] as above, dst = DEVICE [n][width] (16-byte aligned,
+ * width * elem_size a multiple of 16).  Asynchronous on `stream`; rows must stay valid until the stream has passed the call.
+ *   how = 0  copy engines: one H2D DMA per row (any alignment, no CU time) behind one fill of the batch
+ *   how = 1  one gather kernel that reads the rows over PCIe and writes the padded batch (kernel_ingest.hip): a single
+ *            launch for any number of rows -- what the continuous-refill scheduler needs (thousands of short rows per slab)
+ * For pageable sources use vad_stage_rows + one copy instead.                                                          */
+int  vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, long n, long width, size_t elem_size,
+                     void *dst, int how, void *stream);
+/* Page-lock / unlock a host range so that it can be a vad_upload_rows source (hipHostRegister; a decoder's output
+ * buffers, a memory-mapped corpus shard).  Process-wide.                                                              */
+int  vad_host_register(void *p, size_t bytes);
+int  vad_host_unregister(void *p);
+
+/* Host threads the native helpers (vad_stage_rows, vad_segment_probs_batch) use by default in THIS process:
+ * min(CPU affinity, cgroup CPU quota) / LOCAL_WORLD_SIZE, i.e. the node's CPU budget divided among the one-process-per-GPU
+ * ranks torchrun started (SILERO_VAD_AMD_HOST_THREADS overrides).                                                     */
+int  vad_host_threads(void);
+/* Narrow the calling thread's CPU affinity to the CPUs of `device`'s NUMA node (threads and pinned buffers created
+ * afterwards follow).  Returns the node, or -1 if it is unknown or outside the process' CPU mask (nothing changed).   */
+int  vad_bind_host_to_device(int device);
 
 /* ---- test / bring-up hooks (not part of the drop-in surface) -------------------------------------
  * Host-only: size and contents of the packed weight images the kernels consume, so CPU tests can
  * check the fragment packing without a GPU.  which: 0 = frontend GEMM stream (enc0 "direct"), 1 = recurrent
- * W_hh image, 2 = small tables (biases, head, window, twiddles), 5 = frontend stream in Winograd form.  */
+ * W_hh image, 2 = small tables (biases, head, window, twiddles), 5 = frontend stream in Winograd F(2,3) form,
+ * 6 = frontend stream in Winograd F(4,3) form (the product's).                                             */
 long vad_debug_packed_floats(const vad_engine *e, int sr, int which);
 int  vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n);
-/* which = 3 / 4: the fp16x3 split frontend / recurrent images (precision=f16x3), returned as raw
- * 4-byte words holding two halves each.                                                          */
 /* Host-only engine for the hooks above (no device needed).                                       */
 int  vad_create_host_only(const void *weights, size_t nbytes, vad_engine **out);
 /* Device: run the frontend only and return the LSTM input-gate pre-activations
  * gx[B][T][512] = W_ih * enc(stft(x)) + b_ih + b_hh  (row-major, gate order i,f,g,o).            */
 int  vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, long ld,
                         const float *ctx, float *gx, void *stream);
-
-/* Device: one v_mfma_f32_16x16x32_f16 on host-supplied fragments a, b [64 lanes][8 halves] ->
- * d [64 lanes][4 floats]; pins the operand-slot pairing and the subnormal behaviour the fp16x3 split
- * arithmetic relies on.  Synchronous.                                                           */
-int  vad_debug_mfma_f16(vad_engine *e, const uint16_t *a, const uint16_t *b, float *d);
 
 /* Device: y[i] = sigmoid(x[i]) (kind 0) or tanh(x[i]) (kind 1) exactly as the recurrent kernels evaluate them
  * (v_exp_f32 / v_rcp_f32 based, csrc/activations.hpp); x, y device pointers.  For the accuracy test.        */

@@ -12,6 +12,9 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 # SILERO_VAD_AMD_LIB selects another build of the SAME library (tools/variants.py A/B kernels)
 LIB_PATH = Path(os.environ.get("SILERO_VAD_AMD_LIB") or PKG / "libsilero_vad_hip.so")
+# the test build: the product's sources plus the superseded A/B forms of the frontend (option enc0=direct|winograd2);
+# loaded only by the parity tests that compare those forms with the product (Engine(..., library=lib_ab()))
+LIB_AB_PATH = PKG / "libsilero_vad_hip_ab.so"
 WEIGHTS_PATH = PKG / "data" / "silero_vad_v6.weights"
 
 VAD_OK = 0
@@ -35,6 +38,7 @@ f32p, i16p = POINTER(c_float), POINTER(c_int16)
 SYMBOLS = {
     "vad_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
     "vad_destroy": (None, [c_void_p]),
+    "vad_clone": (c_int, [c_void_p, POINTER(c_void_p)]),
     "vad_strerror": (c_char_p, [c_int]),
     "vad_last_error": (c_char_p, [c_void_p]),
     "vad_device": (c_int, [c_void_p]),
@@ -57,30 +61,48 @@ SYMBOLS = {
     "vad_segment_probs_device": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p,
                                          POINTER(SegmentParams), c_void_p, c_long, c_void_p, c_void_p]),
     "vad_stage_rows": (c_int, [POINTER(c_void_p), POINTER(c_long), c_long, c_long, c_size_t, c_void_p, c_int]),
+    "vad_upload_rows": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_long), c_long, c_long, c_size_t, c_void_p, c_int,
+                                c_void_p]),
+    "vad_host_register": (c_int, [c_void_p, c_size_t]),
+    "vad_host_unregister": (c_int, [c_void_p]),
+    "vad_host_threads": (c_int, []),
+    "vad_bind_host_to_device": (c_int, [c_int]),
     "vad_debug_packed_floats": (c_long, [c_void_p, c_int, c_int]),
     "vad_debug_packed_copy": (c_int, [c_void_p, c_int, c_int, f32p, c_long]),
     "vad_create_host_only": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
-    "vad_debug_mfma_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "vad_debug_activation": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p]),
     "vad_debug_foreign_load": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p]),
     "vad_debug_frontend": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
+_lib_ab = None
+
+
+def _load(path):
+    if not path.exists():
+        raise OSError(f"{path} not built: run `python __graft_entry__.py` (hipcc, gfx950)")
+    handle = ctypes.CDLL(str(path))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(handle, name)
+        fn.restype, fn.argtypes = res, args
+    return handle
 
 
 def lib():
-    """Load the shared library once; raises OSError/AttributeError if it or a symbol is missing."""
+    """Load the product library once; raises OSError/AttributeError if it or a symbol is missing."""
     global _lib
     if _lib is None:
-        if not LIB_PATH.exists():
-            raise OSError(f"{LIB_PATH} not built: run `python __graft_entry__.py` (hipcc, gfx950)")
-        handle = ctypes.CDLL(str(LIB_PATH))
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(handle, name)
-            fn.restype, fn.argtypes = res, args
-        _lib = handle
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+def lib_ab():
+    """The test build (A/B forms of the frontend); only tests ask for it."""
+    global _lib_ab
+    if _lib_ab is None:
+        _lib_ab = _load(LIB_AB_PATH)
+    return _lib_ab
 
 
 class VadError(RuntimeError):
@@ -90,7 +112,7 @@ class VadError(RuntimeError):
         super().__init__(f"{msg}{': ' + detail if detail else ''} [VAD_ERR_{STATUS_NAMES.get(status, status)}]")
 
 
-def check(handle, status):
+def check(handle, status, library=None):
     if status != VAD_OK:
-        detail = lib().vad_last_error(handle).decode() if handle else ""
+        detail = (library or lib()).vad_last_error(handle).decode() if handle else ""
         raise VadError(status, detail)

@@ -47,6 +47,7 @@ struct FrontArgs {
                              // in 16 kHz terms
     long long *trace;        // bring-up only (VAD_TRACE builds): 16 slots per workgroup, else null
 };
+// (A/B form, test builds only -- VAD_AB, libsilero_vad_hip_ab.so: encoder 0 tap by tap, straight-line code, kernel_front.hip)
 template <typename PcmT>
 hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s);
 // Same function, encoder 0 as one Winograd F(4,3) tile over the 4 frames, loop-structured code (kernel_front_f43.hip);
@@ -54,7 +55,7 @@ hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s);
 template <typename PcmT>
 hipError_t launch_front_f43(int sr, const FrontArgs &a, hipStream_t s);
 // Same function, encoder 0 as two Winograd F(2,3) tiles over the frame pairs, straight-line code (kernel_front_wino.hip);
-// `wfront` points to the F(2,3) image (layout.hpp w_* units).  Kept as an A/B form (option enc0=winograd2).
+// `wfront` points to the F(2,3) image (layout.hpp w_* units).  A/B form, test builds only (VAD_AB; option enc0=winograd2).
 template <typename PcmT>
 hipError_t launch_front_wino(int sr, const FrontArgs &a, hipStream_t s);
 
@@ -71,13 +72,13 @@ struct RecArgs {
 };
 hipError_t launch_rec(int sr, const RecArgs &a, hipStream_t s);
 
-// fp16x3 split variants (kernel_front_split.hip, kernel_rec_split.hip): same arguments, `wfront` /
-// `whh` point to the split images (layout.hpp "split").
-template <typename PcmT>
-hipError_t launch_front_split(int sr, const FrontArgs &a, hipStream_t s);
-hipError_t launch_rec_split(int sr, const RecArgs &a, hipStream_t s);
-// one v_mfma_f32_16x16x32_f16: a, b device [64 lanes][8 halves], d device [64 lanes][4 floats]
-hipError_t launch_mfma_f16_probe(const void *a, const void *b, float *d, hipStream_t s);
+// Ingest (kernel_ingest.hip): rows[i].len elements (esz bytes each) at rows[i].ptr -- PINNED host memory, or device memory --
+// -> dst[i][0 .. width), zero padded.  `rows` itself is read by the kernel (pinned or device memory).
+struct RowDesc {
+    const void *ptr;
+    long len;
+};
+hipError_t launch_gather_rows(const RowDesc *rows, long n, long width, int esz, void *dst, hipStream_t s);
 
 // Segmenter on the device (kernel_scan.hip): lane i scans probs[i * ldp ...] (or probs[row_off[i] ...] if row_off is
 // not null), n_chunks[i] entries (or n_chunks_all if n_chunks is null), writes its segments to out[i * cap ...] and

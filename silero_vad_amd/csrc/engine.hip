@@ -1,53 +1,90 @@
 // engine.hip -- the C ABI (include/silero_vad_hip.h): engine lifetime, scratch, kernel launches.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/silero_vad_hip.h"
 #include "device_api.hpp"
+#include "host_threads.hpp"
 #include "layout.hpp"
 #include "weights.hpp"
 
+#ifndef VAD_AB
+#define VAD_AB 0        // 1: the test build (libsilero_vad_hip_ab.so) that also carries the A/B forms of the fp32 frontend
+#endif
+
+// Read-only device data of one weight container: shared by an engine and its clones (vad_clone).
+struct vad_images {
+    int device = -1;
+    uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
+    vad::RefNet ref[2] = {};
+    float *d_front4[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
+#if VAD_AB
+    float *d_front[2] = {}, *d_front_wino[2] = {};
+#endif
+    ~vad_images() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        for (int ni = 0; ni < 2; ++ni) {
+            if (d_front4[ni]) (void)hipFree(d_front4[ni]);
+            if (d_whh[ni]) (void)hipFree(d_whh[ni]);
+            if (d_tables[ni]) (void)hipFree(d_tables[ni]);
+#if VAD_AB
+            if (d_front[ni]) (void)hipFree(d_front[ni]);
+            if (d_front_wino[ni]) (void)hipFree(d_front_wino[ni]);
+#endif
+        }
+        if (d_blob) (void)hipFree(d_blob);
+    }
+};
+
 struct vad_engine {
-    vad::Weights weights;
+    std::shared_ptr<vad::Weights> weights;          // host: container + packed images (shared with clones)
+    std::shared_ptr<vad_images> img;                // device: the packed images (shared with clones)
     bool host_only = false;
     int device = -1;
     std::string err;
     bool impl_reference = false;
-    bool split = false;                             // precision: exact fp32 MFMA (default) | fp16x3 split MFMA (opt-in)
-    bool split_rec = false;                         // (bring-up: the two kernels can be chosen separately)
-    int enc0 = 2;                                   // fp32 frontend, encoder 0: 0 direct, 1 Winograd F(2,3), 2 F(4,3) (option "enc0")
+    int enc0 = 2;                                   // fp32 frontend, encoder 0: 2 Winograd F(4,3) (the product); test builds: 0 direct, 1 F(2,3)
     bool profile = false;
-    bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the fp32 frontend's loads (option "fused_decimation")
+    bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the frontend's loads (option "fused_decimation")
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
 
-    // device images
-    uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
-    vad::RefNet ref[2] = {};
-    float *d_front[2] = {}, *d_front_wino[2] = {}, *d_front_wino4[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
-    uint16_t *d_front_split[2] = {}, *d_whh_split[2] = {};
-
-    // scratch
+    // scratch (per engine: a clone has its own, so that an engine and its clones may be in flight on different streams)
     float *d_gx = nullptr;
     size_t gx_floats = 0;
     float *d_ctx_new = nullptr;
     size_t ctx_floats = 0;
-    void *d_tail = nullptr;                         // [B][N] zero padded last chunk (L % N != 0)
+    void *d_tail = nullptr;                         // [B][N * dec] zero padded last chunk (L % N != 0)
     size_t tail_bytes = 0;
     void *d_realign = nullptr;                      // aligned copy of a misaligned input (rare)
     size_t realign_bytes = 0;
-    void *d_decim = nullptr;                        // 16 kHz copy of a 32/48/... kHz input
+    void *d_decim = nullptr;                        // 16 kHz copy of a 64/80/... kHz input
     size_t decim_bytes = 0;
     unsigned long scratch_gen = 0;                  // bumped whenever a scratch buffer is reallocated: a hipGraph that
                                                     // captured calls of this engine holds the OLD addresses (vad_scratch_generation)
     long slab_steps = 0;                            // time steps per gx slab for the last reserve
     size_t gx_cap = 6ull << 30;                     // cap of the gx scratch; longer inputs are slabbed (option gx_cap_mib)
+
+    // vad_upload_rows: a ring of pinned row tables (the gather kernel reads them over PCIe), one event per slot
+    static constexpr int kTabSlots = 8;
+    vad::RowDesc *h_tab[kTabSlots] = {};
+    long tab_cap[kTabSlots] = {};
+    hipEvent_t tab_ev[kTabSlots] = {};
+    bool tab_busy[kTabSlots] = {};
+    int tab_next = 0;
 
     // profiling: 3 events per (call, slab), read back lazily by vad_kernel_times
     std::vector<hipEvent_t> ev_pool;
@@ -84,7 +121,9 @@ int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
     const long slab = slab_for(e, B, T);
     const size_t need_gx = (size_t)nst * slab * 32 * 256;
     const size_t need_ctx = (size_t)B * (sr == 16000 ? 64 : 32);
-    const size_t need_tail = (size_t)B * (sr == 16000 ? 512 : 256) * sizeof(float);
+    // worst case of the tail copy: fp32 samples at 48 kHz (dec = 3) -- sized here so that no forward call has to grow it
+    // (a growth is a device synchronisation and cannot happen while the call is being captured into a hipGraph)
+    const size_t need_tail = (size_t)B * (sr == 16000 ? 512 * 3 : 256) * sizeof(float);
     if (need_gx > e->gx_floats || need_ctx > e->ctx_floats || need_tail > e->tail_bytes) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
@@ -182,9 +221,12 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
     for (long t0 = 0; t0 < T; t0 += slab) {
         const long nt = std::min(slab, T - t0);
         vad::FrontArgs fa{};
-        fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni])
-                             : e->enc0 == 2 ? e->d_front_wino4[ni] : e->enc0 == 1 ? e->d_front_wino[ni] : e->d_front[ni];
-        fa.tables = e->d_tables[ni];
+#if VAD_AB
+        fa.wfront = e->enc0 == 2 ? e->img->d_front4[ni] : e->enc0 == 1 ? e->img->d_front_wino[ni] : e->img->d_front[ni];
+#else
+        fa.wfront = e->img->d_front4[ni];
+#endif
+        fa.tables = e->img->d_tables[ni];
         fa.pcm = pcm;
         fa.tail = tail;
         fa.ld = ld; fa.L = Ld; fa.T = T; fa.t0 = t0; fa.nt = nt;
@@ -195,8 +237,8 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         fa.dec = dec;
         fa.trace = e->trace;
         vad::RecArgs ra{};
-        ra.whh = e->split_rec ? reinterpret_cast<const float *>(e->d_whh_split[ni]) : e->d_whh[ni];
-        ra.tables = e->d_tables[ni];
+        ra.whh = e->img->d_whh[ni];
+        ra.tables = e->img->d_tables[ni];
         ra.gx = e->d_gx;
         ra.state = state;
         ra.probs = probs;
@@ -212,13 +254,14 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             e->ev_used += 3;
             HIP_TRY(e, hipEventRecord(ev[0], stream));
         }
-        if (e->split) HIP_TRY(e, vad::launch_front_split<PcmT>(sr, fa, stream));
-        else if (e->enc0 == 2) HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
-        else if (e->enc0 == 1) HIP_TRY(e, vad::launch_front_wino<PcmT>(sr, fa, stream));
-        else HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
+#if VAD_AB
+        if (e->enc0 == 1) HIP_TRY(e, vad::launch_front_wino<PcmT>(sr, fa, stream));
+        else if (e->enc0 == 0) HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
+        else
+#endif
+        HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
-        if (e->split_rec) HIP_TRY(e, vad::launch_rec_split(sr, ra, stream));
-        else HIP_TRY(e, vad::launch_rec(sr, ra, stream));
+        HIP_TRY(e, vad::launch_rec(sr, ra, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[2], stream));
     }
     HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -237,12 +280,11 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
         // sample-rate front door: a multiple of 16 kHz is decimated to 16 kHz, x[:, ::sr/16000], exactly as the
         // reference does (vad_annotator.py:104-112), and takes the 16 kHz path.  For 32 and 48 kHz the fp32 frontend does
         // it while loading (no extra pass over HBM; 48 kHz: the product frontend only, the A/B forms have no stride-3
-        // instantiation); higher multiples, the f16x3 frontend and impl=reference go through a decimated copy in engine
-        // scratch.
+        // instantiation); higher multiples and impl=reference go through a decimated copy in engine scratch.
         if (B == 0 || L == 0) return VAD_OK;
         const int k = sr / 16000;
         HIP_TRY(e, hipSetDevice(e->device));
-        if ((k == 2 || (k == 3 && e->enc0 == 2)) && !e->split && !e->impl_reference && e->fused_decimation)
+        if ((k == 2 || (k == 3 && e->enc0 == 2)) && !e->impl_reference && e->fused_decimation)
             return forward_core<PcmT>(e, 16000, k, B, L, pcm, ld, ctx, state, probs, ldp, stream);
         const long Ld = (L + k - 1) / k, ldd = (Ld + 15) / 16 * 16;
         int rc = grow(e, &e->d_decim, &e->decim_bytes, (size_t)B * ldd * sizeof(PcmT), stream, "decimation");
@@ -258,7 +300,7 @@ int forward_impl(vad_engine *e, int sr, int B, long L, const PcmT *pcm, long ld,
     if (e->impl_reference) {
         const int N = sr == 16000 ? 512 : 256;
         if (ldp < (L + N - 1) / N) return fail(e, VAD_ERR_ARG, "ldp < T");
-        HIP_TRY(e, vad::launch_ref_forward<PcmT>(e->ref[ni], sr, B, L, pcm, ld, ctx, state, probs, ldp, stream));
+        HIP_TRY(e, vad::launch_ref_forward<PcmT>(e->img->ref[ni], sr, B, L, pcm, ld, ctx, state, probs, ldp, stream));
         return VAD_OK;
     }
     return forward_core<PcmT>(e, sr, 1, B, L, pcm, ld, ctx, state, probs, ldp, stream);
@@ -305,7 +347,8 @@ int vad_create_host_only(const void *weights, size_t nbytes, vad_engine **out) {
     *out = nullptr;
     vad_engine *e = new (std::nothrow) vad_engine();
     if (!e) return VAD_ERR_ALLOC;
-    const std::string err = e->weights.load(weights, nbytes);
+    e->weights = std::make_shared<vad::Weights>();
+    const std::string err = e->weights->load(weights, nbytes);
     if (!err.empty()) {
         delete e;
         return VAD_ERR_WEIGHTS;
@@ -334,26 +377,30 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
         return code;
     };
     if (hipSetDevice(device) != hipSuccess) return bail(VAD_ERR_HIP);
+    e->img = std::make_shared<vad_images>();
+    vad_images &im = *e->img;
+    im.device = device;
     for (int ni = 0; ni < 2; ++ni) {
-        if (upload(e, &e->d_front[ni], e->weights.packed[ni].front)) return bail(VAD_ERR_HIP);
-        if (upload(e, &e->d_front_wino[ni], e->weights.packed[ni].front_wino)) return bail(VAD_ERR_HIP);
-        if (upload(e, &e->d_front_wino4[ni], e->weights.packed[ni].front_wino4)) return bail(VAD_ERR_HIP);
-        if (upload(e, &e->d_whh[ni], e->weights.packed[ni].whh)) return bail(VAD_ERR_HIP);
-        if (upload(e, &e->d_tables[ni], e->weights.packed[ni].tables)) return bail(VAD_ERR_HIP);
-        if (upload(e, &e->d_front_split[ni], e->weights.packed[ni].front_split)) return bail(VAD_ERR_HIP);
-        if (upload(e, &e->d_whh_split[ni], e->weights.packed[ni].whh_split)) return bail(VAD_ERR_HIP);
+        const vad::PackedNet &pk = e->weights->packed[ni];
+        if (upload(e, &im.d_front4[ni], pk.front_wino4)) return bail(VAD_ERR_HIP);
+        if (upload(e, &im.d_whh[ni], pk.whh)) return bail(VAD_ERR_HIP);
+        if (upload(e, &im.d_tables[ni], pk.tables)) return bail(VAD_ERR_HIP);
+#if VAD_AB
+        if (upload(e, &im.d_front[ni], pk.front)) return bail(VAD_ERR_HIP);
+        if (upload(e, &im.d_front_wino[ni], pk.front_wino)) return bail(VAD_ERR_HIP);
+#endif
     }
     // canonical tensors for impl=reference
-    const auto &blob = e->weights.blob;
-    if (hipMalloc((void **)&e->d_blob, blob.size()) != hipSuccess) return bail(VAD_ERR_ALLOC);
-    if (hipMemcpy(e->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess)
+    const auto &blob = e->weights->blob;
+    if (hipMalloc((void **)&im.d_blob, blob.size()) != hipSuccess) return bail(VAD_ERR_ALLOC);
+    if (hipMemcpy(im.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess)
         return bail(VAD_ERR_HIP);
     for (int ni = 0; ni < 2; ++ni) {
-        const vad::NetTensors &t = e->weights.net[ni];
+        const vad::NetTensors &t = e->weights->net[ni];
         auto dev = [&](const float *p) {
-            return reinterpret_cast<const float *>(e->d_blob + ((const uint8_t *)p - blob.data()));
+            return reinterpret_cast<const float *>(im.d_blob + ((const uint8_t *)p - blob.data()));
         };
-        vad::RefNet &r = e->ref[ni];
+        vad::RefNet &r = im.ref[ni];
         r.basis = dev(t.basis);
         for (int l = 0; l < 4; ++l) { r.ew[l] = dev(t.ew[l]); r.eb[l] = dev(t.eb[l]); }
         r.w_ih = dev(t.w_ih); r.w_hh = dev(t.w_hh); r.b_ih = dev(t.b_ih); r.b_hh = dev(t.b_hh);
@@ -368,24 +415,39 @@ void vad_destroy(vad_engine *e) {
     if (!e->host_only && e->device >= 0) {
         (void)hipSetDevice(e->device);
         (void)hipDeviceSynchronize();
-        for (int ni = 0; ni < 2; ++ni) {
-            if (e->d_front[ni]) (void)hipFree(e->d_front[ni]);
-            if (e->d_front_wino[ni]) (void)hipFree(e->d_front_wino[ni]);
-            if (e->d_front_wino4[ni]) (void)hipFree(e->d_front_wino4[ni]);
-            if (e->d_whh[ni]) (void)hipFree(e->d_whh[ni]);
-            if (e->d_tables[ni]) (void)hipFree(e->d_tables[ni]);
-            if (e->d_front_split[ni]) (void)hipFree(e->d_front_split[ni]);
-            if (e->d_whh_split[ni]) (void)hipFree(e->d_whh_split[ni]);
-        }
-        if (e->d_blob) (void)hipFree(e->d_blob);
         if (e->d_gx) (void)hipFree(e->d_gx);
         if (e->d_ctx_new) (void)hipFree(e->d_ctx_new);
         if (e->d_tail) (void)hipFree(e->d_tail);
         if (e->d_realign) (void)hipFree(e->d_realign);
         if (e->d_decim) (void)hipFree(e->d_decim);
+        for (int i = 0; i < vad_engine::kTabSlots; ++i) {
+            if (e->h_tab[i]) (void)hipHostFree(e->h_tab[i]);
+            if (e->tab_ev[i]) (void)hipEventDestroy(e->tab_ev[i]);
+        }
         for (auto &ev : e->ev_pool) (void)hipEventDestroy(ev);
     }
-    delete e;
+    delete e;                                        // the shared images go with their last owner (vad_images::~vad_images)
+}
+
+// A second handle on the same GPU that shares the (read-only) weight images and carries the same options, with its OWN
+// scratch: what a caller needs to keep two calls in flight on two streams (streams.py issues the buckets of a corpus
+// round-robin to such "lanes": one lane's latency-bound recurrence runs beside the other lane's frontend).
+int vad_clone(const vad_engine *src, vad_engine **out) {
+    if (!src || !out) return VAD_ERR_ARG;
+    *out = nullptr;
+    if (src->host_only) return VAD_ERR_NO_DEVICE;
+    vad_engine *e = new (std::nothrow) vad_engine();
+    if (!e) return VAD_ERR_ALLOC;
+    e->weights = src->weights;
+    e->img = src->img;
+    e->device = src->device;
+    e->impl_reference = src->impl_reference;
+    e->enc0 = src->enc0;
+    e->fused_decimation = src->fused_decimation;
+    e->gx_cap = src->gx_cap;
+    e->trace = src->trace;
+    *out = e;
+    return VAD_OK;
 }
 
 int vad_set_option(vad_engine *e, const char *name, const char *value) {
@@ -397,22 +459,20 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         else return fail(e, VAD_ERR_OPTION, "impl must be mfma|reference");
         return VAD_OK;
     }
-    if (n == "precision") {
-        if (v == "f16x3") e->split = e->split_rec = true;
-        else if (v == "fp32") e->split = e->split_rec = false;
-        else return fail(e, VAD_ERR_OPTION, "precision must be f16x3|fp32");
+    if (n == "precision") {                          // one arithmetic: fp32 (the reference's); accepted so that bindings may state it
+        if (v != "fp32") return fail(e, VAD_ERR_OPTION, "precision must be fp32 (the engine computes in fp32 only)");
         return VAD_OK;
     }
-    if (n == "precision_front" || n == "precision_rec") {   // bring-up: mix the two kernels
-        if (v != "f16x3" && v != "fp32") return fail(e, VAD_ERR_OPTION, "precision must be f16x3|fp32");
-        (n == "precision_front" ? e->split : e->split_rec) = (v == "f16x3");
-        return VAD_OK;
-    }
-    if (n == "enc0") {                               // fp32 frontend: how encoder 0 is evaluated
+    if (n == "enc0") {                               // how the fp32 frontend evaluates encoder 0
         if (v == "winograd" || v == "winograd4") e->enc0 = 2;
+#if VAD_AB
         else if (v == "winograd2") e->enc0 = 1;
         else if (v == "direct") e->enc0 = 0;
         else return fail(e, VAD_ERR_OPTION, "enc0 must be winograd|winograd4|winograd2|direct");
+#else
+        else return fail(e, VAD_ERR_OPTION, "enc0 must be winograd (the A/B forms winograd2|direct exist only in the test build, "
+                                            "libsilero_vad_hip_ab.so)");
+#endif
         return VAD_OK;
     }
     if (n == "fused_decimation") {                   // "0": always decimate into scratch first (A/B for tests)
@@ -475,6 +535,7 @@ int vad_segment_probs_device(vad_engine *e, const float *probs, long ldp, const 
 int vad_reserve(vad_engine *e, int sr, int B, long T) {
     if (!e) return VAD_ERR_ARG;
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    if (sr > 16000 && sr % 16000 == 0) sr = 16000;       // a multiple of 16 kHz runs on the 16 kHz net (T counts 16 kHz chunks)
     if (net_index(sr) < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "bad sr");
     if (B <= 0 || T <= 0) return fail(e, VAD_ERR_ARG, "bad argument");
     HIP_TRY(e, hipSetDevice(e->device));
@@ -511,42 +572,19 @@ int vad_kernel_times(vad_engine *e, float *front_ms, float *rec_ms, long *calls)
 long vad_debug_packed_floats(const vad_engine *e, int sr, int which) {
     const int ni = net_index(sr);
     if (!e || ni < 0) return -1;
-    const vad::PackedNet &p = e->weights.packed[ni];
-    return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size()
-         : which == 2 ? (long)p.tables.size() : which == 3 ? (long)p.front_split.size() / 2
-         : which == 4 ? (long)p.whh_split.size() / 2 : which == 5 ? (long)p.front_wino.size()
-         : which == 6 ? (long)p.front_wino4.size() : -1;
+    const vad::PackedNet &p = e->weights->packed[ni];
+    return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size() : which == 2 ? (long)p.tables.size()
+         : which == 5 ? (long)p.front_wino.size() : which == 6 ? (long)p.front_wino4.size() : -1;
 }
 
 int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n) {
     const int ni = net_index(sr);
     if (!e || ni < 0 || !dst) return VAD_ERR_ARG;
-    const vad::PackedNet &p = e->weights.packed[ni];
-    if (which == 3 || which == 4) {                 // split images: raw 4-byte words (two halves each)
-        const std::vector<uint16_t> &h = which == 3 ? p.front_split : p.whh_split;
-        if (n != (long)h.size() / 2) return VAD_ERR_ARG;
-        std::memcpy(dst, h.data(), h.size() * sizeof(uint16_t));
-        return VAD_OK;
-    }
+    const vad::PackedNet &p = e->weights->packed[ni];
     const std::vector<float> *v = which == 0 ? &p.front : which == 1 ? &p.whh : which == 2 ? &p.tables
                                   : which == 5 ? &p.front_wino : which == 6 ? &p.front_wino4 : nullptr;
     if (!v || n != (long)v->size()) return VAD_ERR_ARG;
     std::memcpy(dst, v->data(), v->size() * sizeof(float));
-    return VAD_OK;
-}
-
-int vad_debug_mfma_f16(vad_engine *e, const uint16_t *a, const uint16_t *b, float *d) {
-    if (!e || !a || !b || !d) return VAD_ERR_ARG;
-    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
-    HIP_TRY(e, hipSetDevice(e->device));
-    uint8_t *buf = nullptr;
-    HIP_TRY(e, hipMalloc((void **)&buf, 3072));
-    hipError_t rc = hipMemcpy(buf, a, 1024, hipMemcpyHostToDevice);
-    if (rc == hipSuccess) rc = hipMemcpy(buf + 1024, b, 1024, hipMemcpyHostToDevice);
-    if (rc == hipSuccess) rc = vad::launch_mfma_f16_probe(buf, buf + 1024, reinterpret_cast<float *>(buf + 2048), nullptr);
-    if (rc == hipSuccess) rc = hipMemcpy(d, buf + 2048, 1024, hipMemcpyDeviceToHost);
-    (void)hipFree(buf);
-    if (rc != hipSuccess) return hip_fail(e, rc, "mfma probe");
     return VAD_OK;
 }
 
@@ -562,7 +600,7 @@ int vad_debug_foreign_load(vad_engine *e, int kind, int blocks, long iters, void
     if (!e || kind < 0 || kind > 1 || blocks < 0 || iters < 0) return VAD_ERR_ARG;
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, vad::launch_foreign_spin(e->d_tables[0], blocks, iters, kind, (hipStream_t)stream));
+    HIP_TRY(e, vad::launch_foreign_spin(e->img->d_tables[0], blocks, iters, kind, (hipStream_t)stream));
     return VAD_OK;
 }
 
@@ -583,9 +621,12 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     if (L % N || ((size_t)pcm & 15) || (ld * sizeof(float)) % 16 || ((size_t)ctx & 15))
         return fail(e, VAD_ERR_ARG, "debug frontend: whole chunks and 16-byte aligned rows only");
     vad::FrontArgs fa{};
-    fa.wfront = e->split ? reinterpret_cast<const float *>(e->d_front_split[ni])
-                         : e->enc0 == 2 ? e->d_front_wino4[ni] : e->enc0 == 1 ? e->d_front_wino[ni] : e->d_front[ni];
-    fa.tables = e->d_tables[ni];
+#if VAD_AB
+    fa.wfront = e->enc0 == 2 ? e->img->d_front4[ni] : e->enc0 == 1 ? e->img->d_front_wino[ni] : e->img->d_front[ni];
+#else
+    fa.wfront = e->img->d_front4[ni];
+#endif
+    fa.tables = e->img->d_tables[ni];
     fa.pcm = pcm;
     fa.ld = ld; fa.L = L; fa.T = T; fa.t0 = 0; fa.nt = T;
     fa.ctx_in = ctx;
@@ -593,12 +634,153 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.gx = e->d_gx;
     fa.B = B;
     fa.trace = e->trace;
-    if (e->split) HIP_TRY(e, vad::launch_front_split<float>(sr, fa, stream));
-    else if (e->enc0 == 2) HIP_TRY(e, vad::launch_front_f43<float>(sr, fa, stream));
-    else if (e->enc0 == 1) HIP_TRY(e, vad::launch_front_wino<float>(sr, fa, stream));
-    else HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
+#if VAD_AB
+    if (e->enc0 == 1) HIP_TRY(e, vad::launch_front_wino<float>(sr, fa, stream));
+    else if (e->enc0 == 0) HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
+    else
+#endif
+    HIP_TRY(e, vad::launch_front_f43<float>(sr, fa, stream));
     HIP_TRY(e, vad::launch_unpack_gx(e->d_gx, gx, B, T, stream));
     return VAD_OK;
+}
+
+
+// ---- host-side ingest without a host-side copy ---------------------------------------------------------------------------
+namespace {
+struct Registered {
+    size_t bytes;
+    void *dev;
+};
+std::mutex g_reg_mutex;
+std::map<const uint8_t *, Registered> g_registered;       // hipHostRegister'ed ranges and their device-side addresses
+
+// device-visible address of a pinned host pointer: registered ranges translate, hipHostMalloc'ed memory is identity-mapped
+const void *device_view(const void *p) {
+    std::lock_guard<std::mutex> g(g_reg_mutex);
+    if (g_registered.empty()) return p;
+    auto it = g_registered.upper_bound(static_cast<const uint8_t *>(p));
+    if (it == g_registered.begin()) return p;
+    --it;
+    const size_t off = static_cast<const uint8_t *>(p) - it->first;
+    return off < it->second.bytes ? static_cast<const uint8_t *>(it->second.dev) + off : p;
+}
+}  // namespace
+
+int vad_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return VAD_ERR_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return VAD_ERR_HIP;
+    }
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess || !dev) dev = p;
+    std::lock_guard<std::mutex> g(g_reg_mutex);
+    g_registered[static_cast<const uint8_t *>(p)] = Registered{bytes, dev};
+    return VAD_OK;
+}
+
+int vad_host_unregister(void *p) {
+    if (!p) return VAD_ERR_ARG;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mutex);
+        g_registered.erase(static_cast<const uint8_t *>(p));
+    }
+    return hipHostUnregister(p) == hipSuccess ? VAD_OK : VAD_ERR_HIP;
+}
+
+int vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, long n, long width, size_t elem_size,
+                    void *dst, int how, void *stream_v) {
+    if (!e) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    if (n < 0 || width < 0 || (elem_size != 2 && elem_size != 4) || (how != 0 && how != 1))
+        return fail(e, VAD_ERR_ARG, "bad argument");
+    if (n == 0 || width == 0) return VAD_OK;
+    if (!rows || !lens || !dst) return fail(e, VAD_ERR_ARG, "null pointer");
+    if (((size_t)dst & 15) || (width * elem_size) % 16) return fail(e, VAD_ERR_ARG, "dst and its row pitch must be 16-byte aligned");
+    for (long i = 0; i < n; ++i)
+        if (lens[i] < 0 || lens[i] > width || (lens[i] > 0 && !rows[i])) return fail(e, VAD_ERR_ARG, "bad row");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (how == 0) {
+        // copy engines: one H2D DMA per row (any alignment; no CU time), the padding by one fill of the batch first
+        HIP_TRY(e, hipMemsetAsync(dst, 0, (size_t)n * width * elem_size, stream));
+        for (long i = 0; i < n; ++i)
+            if (lens[i])
+                HIP_TRY(e, hipMemcpyAsync(static_cast<uint8_t *>(dst) + (size_t)i * width * elem_size, rows[i],
+                                          (size_t)lens[i] * elem_size, hipMemcpyHostToDevice, stream));
+        return VAD_OK;
+    }
+    // gather kernel: the row table goes into a pinned slot the kernel reads itself; a slot is reused once its kernel is done
+    const int slot = e->tab_next;
+    e->tab_next = (slot + 1) % vad_engine::kTabSlots;
+    if (e->tab_busy[slot]) {
+        HIP_TRY(e, hipEventSynchronize(e->tab_ev[slot]));
+        e->tab_busy[slot] = false;
+    }
+    if (e->tab_cap[slot] < n) {
+        if (e->h_tab[slot]) (void)hipHostFree(e->h_tab[slot]);
+        e->h_tab[slot] = nullptr;
+        e->tab_cap[slot] = 0;
+        const long cap = std::max<long>(n, 1024);
+        if (hipHostMalloc((void **)&e->h_tab[slot], (size_t)cap * sizeof(vad::RowDesc), hipHostMallocDefault) != hipSuccess)
+            return fail(e, VAD_ERR_ALLOC, "cannot allocate the pinned row table");
+        e->tab_cap[slot] = cap;
+    }
+    if (!e->tab_ev[slot]) HIP_TRY(e, hipEventCreateWithFlags(&e->tab_ev[slot], hipEventDisableTiming));
+    for (long i = 0; i < n; ++i) e->h_tab[slot][i] = vad::RowDesc{lens[i] ? device_view(rows[i]) : nullptr, lens[i]};
+    HIP_TRY(e, vad::launch_gather_rows(e->h_tab[slot], n, width, (int)elem_size, dst, stream));
+    HIP_TRY(e, hipEventRecord(e->tab_ev[slot], stream));
+    e->tab_busy[slot] = true;
+    return VAD_OK;
+}
+
+int vad_host_threads(void) { return vad::default_host_threads(256); }
+
+int vad_bind_host_to_device(int device) {
+    // CPUs of the GPU's NUMA node (sysfs), intersected with what the process may use; the calling thread is bound there,
+    // threads created afterwards (the helper pool) inherit it, memory it allocates afterwards is first touched there
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    for (char *c = bdf; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+    char path[256];
+    std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE *f = std::fopen(path, "r")) {
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    if (node < 0) return -1;
+    std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = std::fopen(path, "r");
+    if (!f) return -1;
+    cpu_set_t cur, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(cur), &cur) != 0) {
+        std::fclose(f);
+        return -1;
+    }
+    int a = 0, b = 0, got = 0;
+    while (std::fscanf(f, "%d", &a) == 1) {                   // "0-63,128-191"
+        b = a;
+        int c = std::fgetc(f);
+        if (c == '-') {
+            if (std::fscanf(f, "%d", &b) != 1) break;
+            c = std::fgetc(f);
+        }
+        for (int k = a; k <= b && k < CPU_SETSIZE; ++k)
+            if (CPU_ISSET(k, &cur)) {
+                CPU_SET(k, &want);
+                ++got;
+            }
+        if (c != ',') break;
+    }
+    std::fclose(f);
+    if (got == 0) return -1;                                  // the node's CPUs are outside this process' mask: leave it alone
+    if (sched_setaffinity(0, sizeof(want), &want) != 0) return -1;
+    return node;
 }
 
 }  // extern "C"

@@ -71,8 +71,8 @@ inline int default_host_threads(int cap) {
     return std::max(1, std::min(host_cpu_budget(), cap));
 }
 
-// A persistent pool: run(n, fn) executes fn(k) for k in [0, n) on the pool's threads plus the caller and returns when all
-// are done.  Threads are created on first use (after any affinity binding the process did) and sleep on a condition
+// A persistent pool: run(nthreads, n, fn) executes fn(k) for k in [0, n) on at most nthreads - 1 pool threads plus the
+// caller and returns when all are done.  Threads are created on first use (after any affinity binding the process did) and sleep on a condition
 // variable between calls; one run at a time (callers are serialised by a mutex: the engine's users are single-threaded
 // per engine, but the pool is process-wide).
 class HostPool {
@@ -85,16 +85,18 @@ public:
         std::lock_guard<std::mutex> g(api_);
         return (int)threads_.size() + 1;
     }
-    void run(int n, const std::function<void(int)> &fn) {
+    void run(int nthreads, int n, const std::function<void(int)> &fn) {
         if (n <= 0) return;
-        if (n == 1) {
-            fn(0);
+        nthreads = std::min(nthreads, n);
+        if (nthreads <= 1) {
+            for (int k = 0; k < n; ++k) fn(k);
             return;
         }
         std::lock_guard<std::mutex> g(api_);
-        ensure(n - 1);
+        ensure(nthreads - 1);
         {
             std::lock_guard<std::mutex> l(m_);
+            limit_ = nthreads - 1;
             fn_ = &fn;
             next_ = 0;
             total_ = n;
@@ -121,7 +123,10 @@ private:
     }
     void ensure(int want) {
         want = std::min(want, 255);
-        while ((int)threads_.size() < want) threads_.emplace_back([this] { loop(); });
+        while ((int)threads_.size() < want) {
+            const int id = (int)threads_.size();
+            threads_.emplace_back([this, id] { loop(id); });
+        }
     }
     void work() {
         for (;;) {
@@ -138,7 +143,7 @@ private:
             if (--pending_ == 0) done_.notify_all();
         }
     }
-    void loop() {
+    void loop(int id) {
         unsigned long seen = 0;
         for (;;) {
             {
@@ -146,6 +151,7 @@ private:
                 cv_.wait(l, [&] { return epoch_ != seen; });
                 seen = epoch_;
                 if (stop_) return;
+                if (id >= limit_) continue;        // this run asked for fewer threads than the pool holds
             }
             work();
         }
@@ -154,7 +160,7 @@ private:
     std::condition_variable cv_, done_;
     std::vector<std::thread> threads_;
     const std::function<void(int)> *fn_ = nullptr;
-    int next_ = 0, total_ = 0, pending_ = 0;
+    int next_ = 0, total_ = 0, pending_ = 0, limit_ = 0;
     unsigned long epoch_ = 0;
     bool stop_ = false;
 };

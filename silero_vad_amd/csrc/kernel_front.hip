@@ -518,19 +518,6 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
 #endif
 }
 
-__global__ void unpack_gx_kernel(const float *gx, float *out, int B, long T) {
-    // out[b][t][row] ; gx[st][t][mb][lane][r] with row = 16 mb + 4 g + r, b = 16 st + j
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)B * T * 512;
-    if (idx >= total) return;
-    const int row = (int)(idx % 512);
-    const long t = (idx / 512) % T;
-    const long b = idx / (512 * T);
-    const int mb = row >> 4, g = (row >> 2) & 3, r = row & 3, j = (int)(b & 15);
-    const long st = b >> 4;
-    out[idx] = gx[(((st * T + t) * 32 + mb) * 64 + (g * 16 + j)) * 4 + r];
-}
-
 }  // namespace
 
 template <typename PcmT>
@@ -549,12 +536,5 @@ hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s) {
 }
 template hipError_t launch_front<float>(int, const FrontArgs &, hipStream_t);
 template hipError_t launch_front<int16_t>(int, const FrontArgs &, hipStream_t);
-
-hipError_t launch_unpack_gx(const float *gx, float *out, int B, long T, hipStream_t s) {
-    const long total = (long)B * T * 512;
-    if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(unpack_gx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gx, out, B, T);
-    return hipGetLastError();
-}
 
 }  // namespace vad

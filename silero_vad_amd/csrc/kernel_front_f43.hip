@@ -41,6 +41,9 @@
 namespace vad {
 namespace {
 
+#ifndef VAD_BV_BATCH
+#define VAD_BV_BATCH 1           // 1: a step's four B operands are formed first, then its 8 MFMAs issue back to back (gemm_r)
+#endif
 constexpr int kUnitBytes = (int)vadl::kWUnitFloats * 4;      // 16 blocks of 1 KiB
 #define VAD_INLINE __attribute__((always_inline))
 
@@ -134,12 +137,26 @@ __device__ __forceinline__ void gemm_r(f32x4 (&acc)[M], BF bfun, Ring &r) {
             }
             __builtin_amdgcn_sched_barrier(0);
             constexpr int i = u * 8 + st, kg = i / (M / 2), mp = 2 * (i % (M / 2));
+#if VAD_BV_BATCH
+            // A VALU instruction between two fp32 MFMAs costs its issue plus a ~10-cycle switch (profiles/r03a_issue_pipes2.md):
+            // form the step's four B operands first, then issue its 8 MFMAs back to back -- one switch per step instead of four
+            float bv[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bv[ks] = bfun(kg * 4 + ks);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[mp + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.c0[ks], bv[ks], acc[mp + 0], 0, 0, 0);
+                acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.c1[ks], bv[ks], acc[mp + 1], 0, 0, 0);
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const float bv = bfun(kg * 4 + ks);
                 acc[mp + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.c0[ks], bv, acc[mp + 0], 0, 0, 0);
                 acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.c1[ks], bv, acc[mp + 1], 0, 0, 0);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             r.c0 = n0;
             r.c1 = n1;

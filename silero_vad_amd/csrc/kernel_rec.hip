@@ -20,7 +20,7 @@
 #include "layout.hpp"
 
 #ifndef VAD_REC_SKEW
-#define VAD_REC_SKEW 1           // 1: rec_skew_kernel (the two waves of a SIMD half a step apart), 0: rec_kernel (all waves in phase; A/B)
+#define VAD_REC_SKEW 0           // 0: rec_kernel (all waves in phase; the product), 1: rec_skew_kernel (A/B; measured slower, see there)
 #endif
 #ifndef VAD_REC_GATE_MAJOR
 #define VAD_REC_GATE_MAJOR 1     // 0: k-group-major MFMA order, all activations after the last MFMA (A/B)
@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
 }
 
 
-// ---- the product recurrence: the same arithmetic, the two waves of a SIMD half a step apart --------------------------
+// ---- A/B form (VAD_REC_SKEW=1; NOT the product: 1.188 ms against rec_kernel's 1.136 per C2 launch, profiles/r03a_issue_pipes2.md):
+// the same arithmetic, the two waves of a SIMD half a step apart -------------------------------------------------------
 // rec_kernel above puts all 8 waves in phase: everybody's MFMAs, then everybody's activation tail, the barrier, the
 // LDS round trip of h -- and for that tail (~1 us of a 4.4 us step) the matrix pipe of all four SIMDs idles.  Here the
 // waves form two halves, A = waves 0..3 (hidden units 0..63 = k-groups 0..3 of the next step) and B = waves 4..7

@@ -155,7 +155,7 @@ template hipError_t launch_decimate<int16_t>(const int16_t *, long, int16_t *, l
 // A kernel that does nothing but VALU fp32 FMAs for `iters` rounds, in one-wave workgroups with a handful of
 // registers, so that its waves fit beside anything.  kind 0: packed fp32 (v_pk_fma_f32), kind 1: scalar fp32
 // (v_fma_f32).  tests/test_gpu_parity.py launches it on a second stream while the engine runs, to pin down
-// whether another tenant's packed-fp32 VALU work disturbs the f16 matrix pipe.
+// that the engine's results do not depend on what another tenant of the GPU is doing (test_bit_stable_under_foreign_load).
 __global__ void __launch_bounds__(64) foreign_spin_kernel(float *sink, long iters, int kind) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 a{1.0f + threadIdx.x * 1e-3f, 0.5f}, b{0.25f, 0.75f};
@@ -178,6 +178,30 @@ hipError_t launch_foreign_spin(float *sink, int blocks, long iters, int kind, hi
     hipLaunchKernelGGL(foreign_spin_kernel, dim3((unsigned)blocks), dim3(64), 0, s, sink, iters, kind);
     return hipGetLastError();
 }
+
+// ---- test hook: gx (MFMA D-fragment order) -> row-major [B][T][512] for vad_debug_frontend ----------------------------
+namespace {
+__global__ void unpack_gx_kernel(const float *gx, float *out, int B, long T) {
+    // out[b][t][row] ; gx[st][t][mb][lane][r] with row = 16 mb + 4 g + r, b = 16 st + j
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * T * 512;
+    if (idx >= total) return;
+    const int row = (int)(idx % 512);
+    const long t = (idx / 512) % T;
+    const long b = idx / (512 * T);
+    const int mb = row >> 4, g = (row >> 2) & 3, r = row & 3, j = (int)(b & 15);
+    const long st = b >> 4;
+    out[idx] = gx[(((st * T + t) * 32 + mb) * 64 + (g * 16 + j)) * 4 + r];
+}
+
+}  // namespace
+hipError_t launch_unpack_gx(const float *gx, float *out, int B, long T, hipStream_t s) {
+    const long total = (long)B * T * 512;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_gx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gx, out, B, T);
+    return hipGetLastError();
+}
+
 
 template hipError_t launch_ref_forward<float>(const RefNet &, int, int, long, const float *, long,
                                               float *, float *, float *, long, hipStream_t);

@@ -126,38 +126,6 @@ constexpr long front_wino4_floats(int Q) { return (long)w4_units(Q) * kWUnitFloa
 // ---- recurrent image: [wave 8][gate 4][kgroup 8][lane 64][4] ------------------------------------
 constexpr long whh_floats() { return 8L * 4 * 8 * 256; }
 
-// ---- fp16x3 "split" images (kernel_front_split.hip, kernel_rec_split.hip) ---------------------------
-// Every fp32 weight w is stored as two halves hi = fp16(w), lo = fp16(w - hi) (round to nearest), and
-// every product a*b is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32
-// accumulation (the dropped lo*lo term is < 2^-22 |a b|).  A and B operands of that MFMA hold 8 halves
-// per lane: lane (g, i|j) supplies k-slots (g, e), e < 8 -- whatever k the hardware assigns to a slot,
-// it is the same for A and B, and a dot product may be summed in any order.
-//   chain layout, K32 step u:  slot (g, e) <-> channel 32u + 16 (e >> 2) + 4 g + (e & 3)
-//                              (= D fragments 2u and 2u+1 of the producing layer, registers e & 3)
-//   mag layout,   K32 step u:  slot (g, e) <-> bin 4 (8u + e) + P[g]; the Nyquist bin 4Q is applied as
-//                              an fp32 rank-1 update from Tab::w_nyq instead of a fifth, almost empty step
-// Frontend image: segments of [u][mblock][hi|lo][lane 64][8 halves] (2 KiB per (u, mblock) pair).
-// Encoder 0 is split by output-row half h (rows 64h..64h+63) and encoder 1 by the matching K half, so
-// that half of enc0's output can be consumed before the other half is produced.
-enum SSeg {
-    SE0 = 0,      // SE0 + 6h + tap        enc0 rows 64h.., M = 4, U = Q/8
-    SE1 = 3,      // SE1 + 6h + tap        enc1 K half h,   M = 4, U = 2
-    SE2T1 = 12, SE2T2, SE3T1, SIH0, SIH1, SIH2, SIH3, NSSEG
-};
-constexpr int sseg_mblocks(int s) { return s < SE3T1 ? 4 : 8; }
-constexpr int sseg_usteps(int s, int Q) {
-    return s < SE2T1 ? ((s % 6) < 3 ? Q / 8 : 2) : s < SIH0 ? 2 : 4;
-}
-constexpr long sseg_words(int s, int Q) { return (long)sseg_usteps(s, Q) * sseg_mblocks(s) * 512; }
-constexpr long sseg_offset(int s, int Q) {       // in 4-byte words
-    long o = 0;
-    for (int i = 0; i < s; ++i) o += sseg_words(i, Q);
-    return o;
-}
-constexpr long front_split_words(int Q) { return sseg_offset(NSSEG, Q); }
-// recurrent split image: [wave 8][gate 4][u 4][hi|lo][lane 64][8 halves]
-constexpr long whh_split_words() { return 8L * 4 * 4 * 512; }
-
 // ---- small tables (floats) ----------------------------------------------------------------------
 struct Tab {
     int b_e0, b_e1, b_e2, b_e3, b_g, w_out, b_out, window, tw1, tw2, w_nyq, total;
@@ -176,7 +144,7 @@ constexpr Tab make_tab(int F, int Q) {
     // twiddles are stored in the operand order of the packed complex multiply (kernel_front.hip):
     t.tw1 = o; o += 4 * Q * 4;    // [g][q]  (-s, s, c, 0),  c + i s = exp(-2 pi i P[g] q / (4Q))
     t.tw2 = o; o += 4 * Q * 4;    // [g][k'] (c, -c, s, 0),  c + i s = exp(-2 pi i (4k' + P[g]) / (8Q))
-    t.w_nyq = o; o += 3 * 128;    // [tap][row] encoder-0 weights of the Nyquist bin (split kernels: fp32 rank-1 update)
+    t.w_nyq = o; o += 3 * 128;    // [tap][row] encoder-0 weights of the Nyquist bin (applied as an fp32 rank-1 update on the VALU)
     t.total = o;
     return t;
 }

@@ -5,7 +5,6 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
-#include <thread>
 #include <vector>
 
 #include "../../include/silero_vad_hip.h"
@@ -57,13 +56,12 @@ extern "C" long vad_segment_probs_batch(const float *probs, long ldp, long n_str
     if (nt == 1) {
         work(0, n_streams);
     } else {
-        std::vector<std::thread> pool;
-        const long per = (n_streams + nt - 1) / nt;
-        for (int k = 0; k < nt; ++k) {
+        const int blocks = (int)std::min<long>(n_streams, 4L * nt);
+        const long per = (n_streams + blocks - 1) / blocks;
+        vad::HostPool::get().run(nt, blocks, [&](int k) {
             const long lo = k * per, hi = std::min(n_streams, lo + per);
-            if (lo < hi) pool.emplace_back(work, lo, hi);
-        }
-        for (auto &th : pool) th.join();
+            if (lo < hi) work(lo, hi);
+        });
     }
     long total = 0;
     for (long i = 0; i < n_streams; ++i) total += counts[i];

@@ -1,12 +1,12 @@
 // staging.cpp -- host-side packing of ragged recordings into one zero-padded [n][width] batch, the
 // layout vad_forward_audio takes (the reference pads each recording's last chunk with zeros and
 // handles one file per worker process: src/silero_vad/utils_vad.py:326-327,
-// examples/parallel_example.ipynb cells 5, 7).  Pure memcpy/memset work, split over host threads so
-// that filling a pinned staging buffer keeps up with the PCIe link.
+// examples/parallel_example.ipynb cells 5, 7).  Pure memcpy/memset work, split over the persistent host
+// workers so that filling a pinned staging buffer keeps up with the PCIe link.  This is the path for
+// PAGEABLE sources; recordings that already sit in pinned memory skip it (vad_upload_rows, engine.hip).
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
-#include <thread>
 #include <vector>
 
 #include "../../include/silero_vad_hip.h"
@@ -34,12 +34,13 @@ extern "C" int vad_stage_rows(const void *const *rows, const long *lens, long n,
         work(0, n);
         return VAD_OK;
     }
-    std::vector<std::thread> pool;
-    const long per = (n + nt - 1) / nt;
-    for (int k = 0; k < nt; ++k) {
+    // persistent workers (host_threads.hpp): no thread is created per bucket.  Rows are dealt out in 4 x nt blocks so
+    // that a few long rows do not leave the other workers idle.
+    const int blocks = (int)std::min<long>(n, 4L * nt);
+    const long per = (n + blocks - 1) / blocks;
+    vad::HostPool::get().run(nt, blocks, [&](int k) {
         const long lo = k * per, hi = std::min(n, lo + per);
-        if (lo < hi) pool.emplace_back(work, lo, hi);
-    }
-    for (auto &t : pool) t.join();
+        if (lo < hi) work(lo, hi);
+    });
     return VAD_OK;
 }

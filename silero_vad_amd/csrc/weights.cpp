@@ -70,69 +70,6 @@ void pack_segment(float *dst, int M, int KS, F w) {
                 }
 }
 
-// ---- fp16x3 split images (layout.hpp "split") ------------------------------------------------------
-inline void split_half(float w, uint16_t &hi, uint16_t &lo) {
-    const _Float16 h = (_Float16)w;                    // round to nearest even
-    const _Float16 l = (_Float16)(w - (float)h);       // w - h is exact in fp32
-    std::memcpy(&hi, &h, 2);
-    std::memcpy(&lo, &l, 2);
-}
-// channel carried by slot (g, e) of K32 step u of a chain-layout activation
-inline int chain_chan32(int u, int g, int e) { return 32 * u + 16 * (e >> 2) + 4 * g + (e & 3); }
-
-// dst = [u][mblock][hi|lo][lane][8 halves]; w(row, u, g, e) = weight multiplying slot (g, e) of step u
-template <class F>
-void pack_split_segment(uint16_t *dst, int M, int U, F w) {
-    for (int u = 0; u < U; ++u)
-        for (int m = 0; m < M; ++m)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 8; ++e) {
-                    const int gg = lane >> 4, i = lane & 15;
-                    uint16_t *pair = dst + ((size_t)u * M + m) * 1024;
-                    split_half(w(16 * m + i, u, gg, e), pair[lane * 8 + e], pair[512 + lane * 8 + e]);
-                }
-}
-
-void pack_net_split(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
-    using namespace vadl;
-    const int Q = g.Q, K = g.K;
-    p.front_split.assign((size_t)front_split_words(Q) * 2, 0);
-    auto seg = [&](int s) { return p.front_split.data() + (size_t)sseg_offset(s, Q) * 2; };
-    for (int h = 0; h < 2; ++h)
-        for (int tau = 0; tau < 3; ++tau) {
-            pack_split_segment(seg(SE0 + 6 * h + tau), 4, Q / 8, [&](int row, int u, int gg, int e) {
-                const int bin = 4 * (8 * u + e) + kResidue[gg];
-                return t.ew[0][((size_t)(64 * h + row) * K + bin) * 3 + tau];
-            });
-            pack_split_segment(seg(SE1 + 6 * h + tau), 4, 2, [&](int row, int u, int gg, int e) {
-                return t.ew[1][((size_t)row * 128 + 64 * h + chain_chan32(u, gg, e)) * 3 + tau];
-            });
-        }
-    for (int tau = 1; tau < 3; ++tau)
-        pack_split_segment(seg(SE2T1 + tau - 1), 4, 2, [&](int row, int u, int gg, int e) {
-            return t.ew[2][((size_t)row * 64 + chain_chan32(u, gg, e)) * 3 + tau];
-        });
-    pack_split_segment(seg(SE3T1), 8, 2, [&](int row, int u, int gg, int e) {
-        return t.ew[3][((size_t)row * 64 + chain_chan32(u, gg, e)) * 3 + 1];
-    });
-    for (int q = 0; q < 4; ++q)
-        pack_split_segment(seg(SIH0 + q), 8, 4, [&](int row, int u, int gg, int e) {
-            return t.w_ih[(size_t)(128 * q + row) * 128 + chain_chan32(u, gg, e)];
-        });
-    // recurrent image [wave][gate][u][hi|lo][lane][8]
-    p.whh_split.assign((size_t)whh_split_words() * 2, 0);
-    for (int w = 0; w < 8; ++w)
-        for (int q = 0; q < 4; ++q)
-            for (int u = 0; u < 4; ++u)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 8; ++e) {
-                        const int gg = lane >> 4, i = lane & 15;
-                        uint16_t *pair = p.whh_split.data() + (((size_t)w * 4 + q) * 4 + u) * 1024;
-                        split_half(t.w_hh[(size_t)(128 * q + 16 * w + i) * 128 + chain_chan32(u, gg, e)],
-                                   pair[lane * 8 + e], pair[512 + lane * 8 + e]);
-                    }
-}
-
 // Winograd image (layout.hpp "Winograd frontend image"): whole units, enc0 as the 4 transformed matrices
 void pack_net_wino(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
     using namespace vadl;
@@ -298,7 +235,6 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
     for (int tau = 0; tau < 3; ++tau)
         for (int row = 0; row < 128; ++row)
             T[tb.w_nyq + tau * 128 + row] = t.ew[0][((size_t)row * K + 4 * Q) * 3 + tau];
-    pack_net_split(t, g, p);
     pack_net_wino(t, g, p);
     pack_net_wino4(t, g, p);
 }

@@ -27,8 +27,6 @@ struct PackedNet {
     std::vector<float> front_wino4;  // the same with enc0 as one F(4,3) tile, units in program order (layout.hpp w4_*)
     std::vector<float> whh;      // recurrent image
     std::vector<float> tables;   // biases, head, window, twiddles, Nyquist-bin weights
-    std::vector<uint16_t> front_split;   // fp16 hi/lo frontend image (layout.hpp SSeg order)
-    std::vector<uint16_t> whh_split;     // fp16 hi/lo recurrent image
 };
 
 struct Weights {

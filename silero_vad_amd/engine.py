@@ -10,8 +10,8 @@
     model.sample_rates, model._state, model._context
 
 with the same validation rules and ValueError texts (vad_annotator.py:17,91-127).  Arithmetic is
-done by the gfx950 kernels behind the C ABI (include/silero_vad_hip.h); PyTorch is used only for
-device memory and streams.  There is no CPU fallback: constructing the model without a usable
+done by the gfx950 kernels behind the C ABI (include/silero_vad_hip.h), in fp32; PyTorch is used only
+for device memory and streams.  There is no CPU fallback: constructing the model without a usable
 GPU raises.
 """
 import contextlib
@@ -21,7 +21,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import check, lib
+from ._lib import lib
 
 _MSG_DIMS = "Too many dimensions for input audio chunk {}"
 _MSG_RATES = "Supported sampling rates: {} (or multiply of 16000)"
@@ -30,32 +30,54 @@ _MSG_SAMPLES = ("Provided number of samples is {} (Supported values: 256 for 800
                 "512 for 16000)")
 
 
-class Engine:
-    """Thin RAII wrapper of a `vad_engine*` (one per GPU)."""
+def _net_rate(sr: int):
+    """(rate of the net that serves `sr`, decimation step): multiples of 16 kHz run on the 16 kHz net
+    (vad_annotator.py:104-112)."""
+    if sr > 16000 and sr % 16000 == 0:
+        return 16000, sr // 16000
+    return sr, 1
 
-    def __init__(self, device=0, weights_path=None):
+
+class Engine:
+    """Thin RAII wrapper of a `vad_engine*` (one per GPU; `clone()` gives further handles that share the weights)."""
+
+    def __init__(self, device=0, weights_path=None, library=None, _handle=None):
         if not torch.cuda.is_available():
             raise RuntimeError("silero_vad_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() "
                                "is False and there is no CPU fallback")
-        blob = open(weights_path or _lib.WEIGHTS_PATH, "rb").read()
+        self._L = library or lib()
         self.device = int(device)
+        self.precision = "fp32"                      # the engine's one arithmetic (include/silero_vad_hip.h)
+        self.options = {}                            # what set_option was given (clones start with the same)
+        if _handle is not None:
+            self._h = _handle
+            return
+        blob = open(weights_path or _lib.WEIGHTS_PATH, "rb").read()
         self._h = ctypes.c_void_p()
-        status = lib().vad_create(blob, len(blob), self.device, ctypes.byref(self._h))
+        status = self._L.vad_create(blob, len(blob), self.device, ctypes.byref(self._h))
         if status != _lib.VAD_OK:
             self._h = None
             raise _lib.VadError(status, f"vad_create(device={device})")
         impl = os.environ.get("SILERO_VAD_AMD_IMPL")
         if impl:
             self.set_option("impl", impl)
-        self.precision = "fp32"                      # the engine's default (include/silero_vad_hip.h)
-        prec = os.environ.get("SILERO_VAD_AMD_PRECISION")
-        if prec:
-            self.set_precision(prec)
+
+    def _check(self, status):
+        _lib.check(self._h, status, self._L)
+
+    def clone(self):
+        """A second handle on the same GPU: shared weight images, the same options, its own scratch -- so that two
+        calls can be in flight on two streams (vad_clone)."""
+        h = ctypes.c_void_p()
+        self._check(self._L.vad_clone(self._h, ctypes.byref(h)))
+        e = Engine(self.device, library=self._L, _handle=h)
+        e.options = dict(self.options)
+        return e
 
     def close(self):
         if getattr(self, "_h", None):
             try:
-                lib().vad_destroy(self._h)
+                self._L.vad_destroy(self._h)
             except Exception:        # interpreter shutdown: module globals may already be gone
                 pass
             self._h = None
@@ -63,25 +85,25 @@ class Engine:
     __del__ = close
 
     def set_option(self, name, value):
-        check(self._h, lib().vad_set_option(self._h, name.encode(), str(value).encode()))
+        self._check(self._L.vad_set_option(self._h, name.encode(), str(value).encode()))
+        if name not in ("profile", "trace_ptr"):
+            self.options[name] = str(value)
 
     def set_precision(self, precision):
-        """"fp32" (exact, the default) | "f16x3" (opt-in: fp16 x 3 split products on the f16 matrix
-        cores, fp32 sums; narrower than fp32, see include/silero_vad_hip.h)."""
+        """The engine computes in fp32 only; kept so that callers may state it."""
         self.set_option("precision", precision)
-        self.precision = precision
 
     def reserve(self, sr, B, T):
-        check(self._h, lib().vad_reserve(self._h, sr, B, T))
+        self._check(self._L.vad_reserve(self._h, sr, B, T))
 
     def scratch_generation(self):
         """Changes whenever the engine reallocated scratch: captured hipGraphs must then be re-captured."""
-        return int(lib().vad_scratch_generation(self._h))
+        return int(self._L.vad_scratch_generation(self._h))
 
     def kernel_times(self):
         """(front_ms, rec_ms, calls): kernel GPU time summed over the calls since the last query."""
         f, r, n = ctypes.c_float(), ctypes.c_float(), ctypes.c_long()
-        check(self._h, lib().vad_kernel_times(self._h, ctypes.byref(f), ctypes.byref(r), ctypes.byref(n)))
+        self._check(self._L.vad_kernel_times(self._h, ctypes.byref(f), ctypes.byref(r), ctypes.byref(n)))
         return f.value, r.value, n.value
 
     @staticmethod
@@ -89,35 +111,41 @@ class Engine:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def forward_audio(self, pcm, sr, ctx, state, probs=None):
-        """pcm [B, L] (float32 or int16, cuda), ctx [B, C], state [2, B, 128] updated in place.
-        Returns probs [B, T] (cuda)."""
+        """pcm [B, L] (float32 or int16, cuda) at `sr` (8000, 16000, or a multiple of 16000: decimated on the
+        device), ctx [B, C], state [2, B, 128] updated in place.  Returns probs [B, T] (cuda)."""
         assert pcm.is_cuda and pcm.dim() == 2 and pcm.stride(1) == 1
         B, L = pcm.shape
-        n = 512 if sr == 16000 else 256
-        T = (L + n - 1) // n
+        net, step = _net_rate(sr)
+        n = 512 if net == 16000 else 256
+        T = ((L + step - 1) // step + n - 1) // n
         if probs is None:
             probs = torch.empty((B, T), dtype=torch.float32, device=pcm.device)
-        fn = lib().vad_forward_audio if pcm.dtype == torch.float32 else lib().vad_forward_audio_i16
         if pcm.dtype not in (torch.float32, torch.int16):
             raise TypeError(f"pcm dtype must be float32 or int16, got {pcm.dtype}")
+        fn = self._L.vad_forward_audio if pcm.dtype == torch.float32 else self._L.vad_forward_audio_i16
         ld = pcm.stride(0) if B > 1 else L          # a size-1 dim may carry any stride (e.g. 0)
         ldp = probs.stride(0) if B > 1 else T
-        check(self._h, fn(self._h, sr, B, L, pcm.data_ptr(), ld, ctx.data_ptr(),
-                          state.data_ptr(), probs.data_ptr(), ldp, self._stream()))
+        self._check(fn(self._h, sr, B, L, pcm.data_ptr(), ld, ctx.data_ptr(),
+                       state.data_ptr(), probs.data_ptr(), ldp, self._stream()))
         return probs
 
     def step(self, pcm, sr, ctx, state, prob):
         B = pcm.shape[0]
-        check(self._h, lib().vad_step(self._h, sr, B, pcm.data_ptr(), pcm.stride(0) if B > 1 else pcm.shape[1], ctx.data_ptr(),
-                                      state.data_ptr(), prob.data_ptr(), self._stream()))
+        self._check(self._L.vad_step(self._h, sr, B, pcm.data_ptr(), pcm.stride(0) if B > 1 else pcm.shape[1],
+                                     ctx.data_ptr(), state.data_ptr(), prob.data_ptr(), self._stream()))
         return prob
+
+    def upload_rows(self, rows, lens, n, width, elem_size, dst, how=0):
+        """Ragged rows in PINNED host memory -> dst[n, width] on the GPU, zero padded, on the current stream
+        (vad_upload_rows; how 0: copy engines, 1: gather kernel).  rows / lens: ctypes arrays."""
+        self._check(self._L.vad_upload_rows(self._h, rows, lens, n, width, elem_size, dst.data_ptr(), how, self._stream()))
 
     def debug_frontend(self, pcm, sr, ctx):
         B, L = pcm.shape
         n = 512 if sr == 16000 else 256
         gx = torch.empty((B, L // n, 512), dtype=torch.float32, device=pcm.device)
-        check(self._h, lib().vad_debug_frontend(self._h, sr, B, L, pcm.data_ptr(), pcm.stride(0) if B > 1 else L,
-                                                ctx.data_ptr(), gx.data_ptr(), self._stream()))
+        self._check(self._L.vad_debug_frontend(self._h, sr, B, L, pcm.data_ptr(), pcm.stride(0) if B > 1 else L,
+                                               ctx.data_ptr(), gx.data_ptr(), self._stream()))
         return gx
 
 
@@ -125,16 +153,12 @@ class HipSileroVAD:
     """Drop-in for the reference's model object (TorchScript `VADRNNJITMerge` / `OnnxWrapper`)."""
 
     def __init__(self, device=0, engine=None, precision="fp32"):
-        """precision: "fp32" (default) = the reference's arithmetic on the exact fp32 matrix kernels.
-        Opt-in: "f16x3" pins the fp16x3 split kernels (narrower than fp32; include/silero_vad_hip.h,
-        option "precision"); "auto" runs f16x3 and transparently reruns a call in fp32 if it reports an
-        out-of-fp16-range input (NaN probability)."""
-        if precision not in ("auto", "f16x3", "fp32"):
-            raise ValueError("precision must be auto|f16x3|fp32")
+        """precision: "fp32" -- the reference's arithmetic, the only one the engine has (the parameter is kept for
+        source compatibility with earlier rounds)."""
+        if precision != "fp32":
+            raise ValueError("precision must be fp32")
         self.engine = engine or Engine(device)
-        self.precision = precision
-        if engine is None and precision != "auto":
-            self.engine.set_precision(precision)
+        self.precision = "fp32"
         self.device = getattr(self.engine, "torch_device", None) or torch.device("cuda", self.engine.device)
         self.sample_rates = [8000, 16000]
         self.reset_states()
@@ -144,41 +168,11 @@ class HipSileroVAD:
         # engine is always a GPU (Engine() raises otherwise)
         return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
 
-    @contextlib.contextmanager
-    def _selected(self):
-        """An engine may be shared by several wrappers (and by direct users): select this wrapper's kernels
-        for the duration of one call and put the engine back the way it was found."""
-        want = "f16x3" if self.precision == "auto" else self.precision
-        before = self.engine.precision
-        if before != want:
-            self.engine.set_precision(want)
-        try:
-            yield
-        finally:
-            if self.engine.precision != before:
-                self.engine.set_precision(before)
-
-    def _guarded(self, run):
-        """Run `run()` (which advances self._state / self._context in place and returns probabilities);
-        in "auto" mode, if the f16x3 kernels flag the input (NaN), restore the carried state and rerun
-        in fp32.  The check reads the probabilities back, i.e. synchronises, as every caller of the
-        reference protocol does anyway (`.item()` / `.cpu()`)."""
-        if self.precision != "auto" or self.engine.precision != "f16x3":
-            return run()
-        st0, ctx0 = self._state.clone(), self._context.clone()
-        out = run()
-        if bool(torch.isnan(out).any()):
-            self._state.copy_(st0)
-            self._context.copy_(ctx0)
-            self.engine.set_precision("fp32")
-            try:
-                out = run()
-            finally:
-                self.engine.set_precision("f16x3")
-        return out
-
     # -- reference: vad_annotator.py:91-127 / utils_vad.py:33-49 --------------------------------------
     def _validate_input(self, x, sr: int):
+        """The reference's rules, returning what the reference returns (the decimated view for multiples of 16 kHz).
+        The forward paths below apply the same rules through `_front_door`, which does NOT materialise `x[:, ::k]`:
+        the kernels read every k-th sample themselves."""
         if not torch.is_tensor(x):
             x = torch.as_tensor(x)
         if x.dim() == 1:
@@ -194,6 +188,25 @@ class HipSileroVAD:
             raise ValueError(_MSG_SHORT)
         return x, sr
 
+    def _front_door(self, x, sr: int):
+        """`_validate_input` with the decimation left to the device: (x2d at the RAW rate, raw rate, net rate,
+        samples per row at the net's rate).  Same errors, in the same order."""
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(x)
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        if x.dim() > 2:
+            raise ValueError(_MSG_DIMS.format(x.dim()))
+        net, step = (16000, sr // 16000) if (sr != 16000 and sr % 16000 == 0) else (sr, 1)
+        if net not in self.sample_rates:
+            raise ValueError(_MSG_RATES.format(self.sample_rates))
+        n_net = (x.shape[1] + step - 1) // step          # len(x[0, ::step])
+        if n_net == 0 or net / n_net > 31.25:
+            raise ValueError(_MSG_SHORT)
+        if not getattr(self.engine, "fused_front_door", True) and step > 1:   # CPU stand-in engines (tests)
+            return x[:, ::step], net, net, n_net
+        return x, sr, net, n_net
+
     def reset_states(self, batch_size=1):
         self._state = torch.zeros(0)
         self._context = torch.zeros(0)
@@ -203,7 +216,8 @@ class HipSileroVAD:
     def _to_device(self, x):
         if x.dtype != torch.int16:
             x = x.to(torch.float32)
-        return x.to(self.device, non_blocking=True).contiguous()
+        x = x.to(self.device, non_blocking=True)
+        return x if x.stride(-1) == 1 else x.contiguous()     # rows may be strided (the engine takes a row pitch)
 
     def _ensure_state(self, sr, batch_size):
         if self._last_sr and self._last_sr != sr:
@@ -218,18 +232,21 @@ class HipSileroVAD:
 
     # -- reference: vad_annotator.py:14-90 ------------------------------------------------------------
     def __call__(self, x, sr: int):
-        x, sr = self._validate_input(x, sr)
+        x, sr_raw, sr, n_net = self._front_door(x, sr)
         num_samples = 512 if sr == 16000 else 256
-        if x.shape[-1] != num_samples:
-            raise ValueError(_MSG_SAMPLES.format(x.shape[-1]))
+        if n_net != num_samples:
+            raise ValueError(_MSG_SAMPLES.format(n_net))
         batch_size = x.shape[0]
         self._ensure_state(sr, batch_size)
-        with self._device_ctx(), self._selected():
+        with self._device_ctx():
             xd = self._to_device(x)
             if xd.dtype == torch.int16:
                 xd = xd.to(torch.float32) / 32768.0
             out = torch.empty((batch_size, 1), dtype=torch.float32, device=self.device)
-            out = self._guarded(lambda: self.engine.step(xd, sr, self._context, self._state, out))
+            if sr_raw == sr:
+                self.engine.step(xd, sr, self._context, self._state, out)
+            else:       # 32 / 48 / ... kHz: one chunk through the front door (every k-th sample is read on the device)
+                self.engine.forward_audio(xd, sr_raw, self._context, self._state, out)
         self._last_sr = sr
         self._last_batch_size = batch_size
         return out
@@ -240,27 +257,22 @@ class HipSileroVAD:
     def audio_forward(self, x, sr: int):
         return self.audio_forward_device(x, sr).cpu()
 
-    def audio_forward_device(self, x, sr: int, guarded=None):
-        """audio_forward that leaves the probabilities in HBM.  No host synchronisation -- except in "auto" mode,
-        where the f16x3 range check has to read them back (pass guarded=False to skip the check and handle flagged
-        rows yourself, as the ragged corpus path does)."""
-        if guarded is None:
-            guarded = self.precision == "auto"
-        x, sr = self._validate_input(x, sr)
+    def audio_forward_device(self, x, sr: int):
+        """audio_forward that leaves the probabilities in HBM: no host synchronisation."""
+        x, sr_raw, sr, _ = self._front_door(x, sr)
         self.reset_states()
         batch_size = x.shape[0]
         self._ensure_state(sr, batch_size)
-        with self._device_ctx(), self._selected():
+        with self._device_ctx():
             xd = self._to_device(x)
-            run = lambda: self.engine.forward_audio(xd, sr, self._context, self._state)
-            probs = self._guarded(run) if guarded else run()
+            probs = self.engine.forward_audio(xd, sr_raw, self._context, self._state)
         self._last_sr = sr
         self._last_batch_size = batch_size
         return probs
 
 
 def load_silero_vad(onnx=False, opset_version=16, device=0, precision="fp32"):
-    """Reference signature (src/silero_vad/model.py:6) plus `device` and `precision`.
+    """Reference signature (src/silero_vad/model.py:6) plus `device`.
     `onnx`/`opset_version` are accepted for source compatibility and ignored: there is one backend,
-    the HIP engine."""
+    the HIP engine, and one arithmetic, fp32."""
     return HipSileroVAD(device=device, precision=precision)

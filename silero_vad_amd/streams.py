@@ -7,7 +7,9 @@
   is right-padded with zeros to its bucket's length yields bit-identical probabilities for its
   own ceil(len / N) chunks.  The plan sorts recordings by length and cuts buckets so that padding
   waste and bytes per GPU call stay bounded; each bucket is one lock-step ``vad_forward_audio``
-  call fed from pinned host staging (int16 halves the PCIe bytes).
+  call.  Recordings that already sit in PINNED host memory are DMA'd / gathered straight into the device batch
+  (vad_upload_rows: no host-side copy at all); pageable ones go through a threaded copy into pinned staging first
+  (vad_stage_rows).  int16 halves the PCIe bytes.
 
 * ``StreamPool`` -- live streams (configs[4]).  Per-stream LSTM state and context stay resident
   in HBM (the resumable unit of the reference model object, vad_annotator.py:7-8,72,87); one
@@ -101,13 +103,17 @@ class _StagePool:
             self.meta[i] = torch.empty(max(n, 1024), dtype=torch.int64, pin_memory=True)
         return self.meta[i][:n]
 
-    def get(self, k, nbytes):
+    def get(self, k, nbytes, dev_bytes=None):
+        """Slot for bucket k with `nbytes` of pinned staging (0: the source is pinned already, no staging) and
+        `dev_bytes` (default: nbytes) of device buffer."""
         i = k % self.slots
+        dev_bytes = nbytes if dev_bytes is None else dev_bytes
         if self.done[i] is not None:
             self.done[i].synchronize()
-        if self.host[i] is None or self.host[i].numel() < nbytes:
-            cap = max(nbytes, 1 << 20)
-            self.host[i] = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        if nbytes and (self.host[i] is None or self.host[i].numel() < nbytes):
+            self.host[i] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        if self.dev[i] is None or self.dev[i].numel() < dev_bytes:
+            cap = max(dev_bytes, 1 << 20)
             # The device buffer is written on self.stream first: allocate it there, so that a block the caching
             # allocator recycles is ordered after its previous use on that stream, and make self.stream wait for
             # whatever the consumer stream still has in flight (the block may come from its pool, e.g. the
@@ -121,65 +127,76 @@ class _StagePool:
 
 
 def _compute_lanes(model, want):
-    """[(model, stream)]: lane 0 is the caller's model on the caller's stream; further lanes are sibling engines (own
-    scratch, same device and arithmetic) on their own streams.  A bucket's recurrence is latency-bound -- 4.7 us per time
-    step on as few CUs as the bucket has stream tiles -- so buckets on different lanes overlap: one lane's recurrence runs
-    beside the other lane's frontend instead of in front of it."""
+    """[(model, stream)]: lane 0 is the caller's model on the caller's stream; further lanes are CLONES of its engine
+    (vad_clone: the same weight images and options, their own scratch -- no second weight copy, no option drift) on
+    their own streams.  A bucket's recurrence is latency-bound -- 4.4 us per time step on as few CUs as the bucket has
+    stream tiles -- so buckets on different lanes overlap: one lane's recurrence runs beside the other lane's frontend
+    instead of in front of it.  Memory: each lane holds its own gx scratch (up to the engine's gx_cap_mib)."""
     cur = torch.cuda.current_stream(model.device)
     lanes = [(model, cur)]
-    if want > 1 and getattr(model, "precision", "auto") != "auto" and hasattr(model, "engine") and \
-            hasattr(model.engine, "_h"):
+    eng = getattr(model, "engine", None)
+    if want > 1 and eng is not None and hasattr(eng, "clone"):
         sibs = getattr(model, "_lane_siblings", None)
-        if sibs is None:
-            sibs = model._lane_siblings = []
+        if sibs is None or getattr(model, "_lane_options", None) != dict(eng.options):
+            sibs = model._lane_siblings = []             # the primary's options changed: fresh clones carry the new ones
+            model._lane_options = dict(eng.options)
         while len(sibs) < want - 1:
-            sib = type(model)(device=model.engine.device, precision=model.precision)
-            sibs.append((sib, torch.cuda.Stream(model.device)))
-        for sib, st in sibs[: want - 1]:
-            if sib.precision != model.precision:
-                sib.precision = model.precision
-                sib.engine.set_precision(model.precision)
-            lanes.append((sib, st))
+            sibs.append((type(model)(engine=eng.clone()), torch.cuda.Stream(model.device)))
+        lanes.extend(sibs[: want - 1])
     return lanes
 
 
-def _stage_into(audios, idxs, width, dtype, dst: torch.Tensor):
-    """Pack recordings `idxs` into dst[len(idxs), width] (zero padded) with the native threaded copy."""
-    n = len(idxs)
-    rows = (ctypes.c_void_p * n)()
-    lens = (ctypes.c_long * n)()
-    keep = []
-    for r, i in enumerate(idxs):
-        a = audios[i]
-        a = a if torch.is_tensor(a) else torch.as_tensor(a)
-        if a.dim() != 1:
-            raise ValueError("More than one dimension in audio. Are you trying to process audio with 2 channels?")
-        if a.dtype != dtype or not a.is_contiguous() or a.is_cuda:
-            if dtype == torch.int16 and a.dtype != torch.int16:
+class _Sources:
+    """The recordings of one call as flat arrays: host address and length of each, made contiguous / of one dtype once,
+    and whether ALL of them sit in page-locked memory (then no host-side copy is needed at all)."""
+
+    def __init__(self, audios, dtype, check_pinned):
+        n = len(audios)
+        self.keep = []
+        self.ptr = np.zeros(n, dtype=np.uint64)
+        self.len = np.zeros(n, dtype=np.int64)
+        pinned_storage = {}
+        all_pinned = check_pinned and n > 0
+        for i, a in enumerate(audios):
+            a = a if torch.is_tensor(a) else torch.as_tensor(a)
+            if a.dim() != 1:
+                raise ValueError("More than one dimension in audio. Are you trying to process audio with 2 channels?")
+            if (a.dtype == torch.int16) != (dtype == torch.int16):
+                # (an int16 recording among float ones would be read as floats in [-32768, 32767]: never silently)
                 raise TypeError("mixed int16 / float recordings in one call")
-            a = a.to("cpu", dtype).contiguous()
-        keep.append(a)
-        rows[r] = a.data_ptr()
-        lens[r] = a.shape[0]
-    rc = lib().vad_stage_rows(rows, lens, n, width, dst.element_size(), dst.data_ptr(), 0)
+            if a.dtype != dtype or not a.is_contiguous() or a.is_cuda:
+                a = a.to("cpu", dtype).contiguous()      # (a strided view of int16 PCM lands here: same dtype, new layout)
+            self.keep.append(a)
+            self.ptr[i] = a.data_ptr() if a.numel() else 0
+            self.len[i] = a.shape[0]
+            if all_pinned and a.numel():
+                key = a.untyped_storage().data_ptr()
+                if key not in pinned_storage:
+                    pinned_storage[key] = bool(a.is_pinned())
+                all_pinned = pinned_storage[key]
+        self.pinned = bool(all_pinned)
+
+    def tables(self, idxs):
+        rows = np.ascontiguousarray(self.ptr[idxs])
+        lens = np.ascontiguousarray(self.len[idxs])
+        return (rows, lens, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p)),
+                lens.ctypes.data_as(ctypes.POINTER(ctypes.c_long)))
+
+
+def _upload_mode():
+    """How pinned recordings reach the GPU: "dma" (copy engines, one per row), "gather" (one kernel that reads host
+    memory), "stage" (force the pageable path).  SILERO_VAD_AMD_UPLOAD overrides the per-scheduler default."""
+    import os
+    return os.environ.get("SILERO_VAD_AMD_UPLOAD", "")
+
+
+def _stage_into(src: "_Sources", idxs, width, dst: torch.Tensor):
+    """Pack recordings `idxs` into dst[len(idxs), width] (zero padded) with the native threaded copy."""
+    _, _, rows_p, lens_p = tabs = src.tables(idxs)
+    rc = lib().vad_stage_rows(rows_p, lens_p, len(idxs), width, dst.element_size(), dst.data_ptr(), 0)
+    del tabs
     if rc:
         raise _lib.VadError(rc, "vad_stage_rows")
-
-
-def _repair_out_of_range(audios, idxs, probs, model, sampling_rate, n):
-    """The opt-in f16x3 kernels answer NaN for a recording whose activations leave the fp16 range
-    (include/silero_vad_hip.h, option "precision"; |pcm| far above 1).  With the wrapper's "auto" policy such
-    rows are recomputed one by one through the guarded `audio_forward`, which falls back to the fp32 kernels."""
-    if getattr(model, "precision", None) != "auto":
-        return probs
-    bad = torch.isnan(probs).any(dim=1).nonzero().flatten().tolist()
-    for row in bad:
-        a = torch.as_tensor(audios[idxs[row]])
-        if a.shape[0] < n:
-            a = torch.nn.functional.pad(a, (0, n - a.shape[0]))
-        p = model.audio_forward(a[None], sampling_rate)[0]
-        probs[row, : p.numel()] = p
-    return probs
 
 
 def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
@@ -192,7 +209,10 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     the probabilities themselves never leave the GPU (ragged_speech_segments scans them there).  `meta` (indices ->
     small CPU int64 tensor) rides to the GPU with the bucket's PCM on the copy stream (pinned, asynchronous), so that
     nothing in the loop blocks the host on the compute stream.  `lanes`: buckets are issued round-robin to this many
-    engines on their own streams (_compute_lanes); results are yielded in bucket order."""
+    engines on their own streams (_compute_lanes); results are yielded in bucket order.
+
+    Ingest: recordings in pinned host memory go straight to the device batch (vad_upload_rows: no host copy);
+    pageable ones are packed into pinned staging by the native threaded copy and copied from there."""
     n = chunk_size(sampling_rate)
     as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
     dtype = torch.int16 if as_i16 else torch.float32
@@ -202,11 +222,13 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     fast = model.audio_forward_device
     dev = getattr(model, "device", None)
     on_gpu = dev is not None and torch.device(dev).type == "cuda"
+    mode = _upload_mode()
+    src = _Sources(audios, dtype, check_pinned=on_gpu and mode != "stage" and hasattr(getattr(model, "engine", None), "upload_rows"))
     if not on_gpu:                                        # CPU stand-in models (tests)
         for idxs in plan.buckets:
             width = max(plan.lengths[idxs[0]], n)
             host = torch.empty((len(idxs), width), dtype=dtype)
-            _stage_into(audios, idxs, width, dtype, host)
+            _stage_into(src, idxs, width, host)
             yield idxs, fast(host, sampling_rate).cpu()
         return
     lane_list = _compute_lanes(model, max(1, int(lanes)))
@@ -214,6 +236,18 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     if pool is None or pool.slots != len(lane_list) + 1:
         pool = model._stage_pool = _StagePool(dev, len(lane_list) + 1)
     cur = torch.cuda.current_stream(dev)
+    direct = src.pinned
+    how = 1 if mode == "gather" else 0
+    align = 16 // esz                                      # device rows are 16-byte aligned: the kernels' vector loads
+    # every lane's scratch is sized up front for the largest bucket it can meet: a growth inside the loop would
+    # synchronise the device and stall all lanes (vad_reserve)
+    if plan.buckets and hasattr(getattr(model, "engine", None), "reserve"):
+        shapes = [(len(b), (max(plan.lengths[b[0]], n) + n - 1) // n) for b in plan.buckets]
+        big = max(shapes, key=lambda bt: ((bt[0] + 15) // 16) * bt[1])
+        wide = max(shapes, key=lambda bt: bt[0])
+        for lane_model, _ in lane_list:
+            for bt in {big, wide}:
+                lane_model.engine.reserve(sampling_rate, bt[0], bt[1])
     for _, st in lane_list[1:]:
         st.wait_stream(cur)                               # sibling lanes start behind whatever the caller has queued
     copies = []                                           # (start event, end event) of every H2D copy, for STATS
@@ -221,16 +255,13 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     def stage(k):
         idxs = plan.buckets[k]
         # at least one full window: audio_forward rejects shorter inputs (vad_annotator.py:124)
-        width = max(plan.lengths[idxs[0]], n)
+        L = max(plan.lengths[idxs[0]], n)
+        width = (L + align - 1) // align * align          # row pitch
         nbytes = len(idxs) * width * esz
-        i = pool.get(k, nbytes)
-        host = pool.host[i][:nbytes].view(dtype).view(len(idxs), width)
-        t0 = time.perf_counter()
-        _stage_into(audios, idxs, width, dtype, host)
-        STATS["stage_s"] += time.perf_counter() - t0
+        i = pool.get(k, nbytes if not direct else 0, nbytes)
         STATS["h2d_bytes"] += nbytes
         STATS["buckets"] += 1
-        STATS["padded"] += len(idxs) * width
+        STATS["padded"] += len(idxs) * L
         STATS["real"] += sum(plan.lengths[j] for j in idxs)
         d = pool.dev[i][:nbytes].view(dtype).view(len(idxs), width)
         if pool.consumed[i] is not None:                  # the device buffer's previous reader is done
@@ -240,59 +271,74 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             mt = meta(idxs)
             m_host = pool.meta_buffer(i, mt.numel()).view(mt.shape)
             m_host.copy_(mt)
+        t0 = time.perf_counter()
+        if not direct:
+            host = pool.host[i][:nbytes].view(dtype).view(len(idxs), width)
+            _stage_into(src, idxs, width, host)
+            STATS["stage_s"] += time.perf_counter() - t0
         with torch.cuda.stream(pool.stream):
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record(pool.stream)
-            d.copy_(host, non_blocking=True)
+            if direct:
+                tabs = src.tables(idxs)
+                model.engine.upload_rows(tabs[2], tabs[3], len(idxs), width, esz, d, how)
+                STATS["upload_call_s"] += time.perf_counter() - t0
+            else:
+                d.copy_(host, non_blocking=True)
             m_dev = m_host.to(dev, non_blocking=True) if m_host is not None else None
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(pool.stream)
         copies.append((ev0, ev))
         pool.done[i] = ev
-        return d, ev, i, m_dev, m_host
+        return d[:, :L], ev, i, m_dev, m_host
 
     def finish(done_bucket):
         idxs, outs, _, probs_dev = done_bucket
         if post is None:
-            return idxs, _repair_out_of_range(audios, idxs, outs[0], model, sampling_rate, n)
+            return idxs, outs[0]
         return idxs, outs, probs_dev
 
-    staged = stage(0) if plan.buckets else None
-    inflight = []                                         # buckets enqueued and not yet yielded, oldest first
-    for k, idxs in enumerate(plan.buckets):
-        x, ev, slot, m_dev, _keep = staged
-        lane_model, lane_stream = lane_list[k % len(lane_list)]
-        lane_stream.wait_event(ev)
-        with torch.cuda.stream(lane_stream):
-            x.record_stream(lane_stream)                  # allocated on pool.stream, read on the lane's stream
-            if m_dev is not None:
-                m_dev.record_stream(lane_stream)
-            probs = lane_model.audio_forward_device(x, sampling_rate, guarded=False)   # async (flagged rows: _repair_...)
-            pool.consumed[slot] = torch.cuda.Event()
-            pool.consumed[slot].record(lane_stream)
-            back = [probs] if post is None else post(probs, idxs, m_dev)
-            outs = []
-            for o in back:                                # pinned blocks come from torch's caching host allocator
-                h = torch.empty(o.shape, dtype=o.dtype, pin_memory=True)
-                h.copy_(o, non_blocking=True)
-                STATS["d2h_bytes"] += h.numel() * h.element_size()
-                outs.append(h)
-            done = torch.cuda.Event()
-            done.record(lane_stream)
-        staged = stage(k + 1) if k + 1 < len(plan.buckets) else None   # CPU packs k+1 meanwhile
-        inflight.append((idxs, outs, done, probs))
-        while len(inflight) > len(lane_list):
-            first = inflight.pop(0)
+    try:
+        staged = stage(0) if plan.buckets else None
+        inflight = []                                     # buckets enqueued and not yet yielded, oldest first
+        for k, idxs in enumerate(plan.buckets):
+            x, ev, slot, m_dev, _keep = staged
+            lane_model, lane_stream = lane_list[k % len(lane_list)]
+            lane_stream.wait_event(ev)
+            with torch.cuda.stream(lane_stream):
+                x.record_stream(lane_stream)              # allocated on pool.stream, read on the lane's stream
+                if m_dev is not None:
+                    m_dev.record_stream(lane_stream)
+                probs = lane_model.audio_forward_device(x, sampling_rate)   # asynchronous
+                pool.consumed[slot] = torch.cuda.Event()
+                pool.consumed[slot].record(lane_stream)
+                back = [probs] if post is None else post(probs, idxs, m_dev)
+                outs = []
+                for o in back:                            # pinned blocks come from torch's caching host allocator
+                    h = torch.empty(o.shape, dtype=o.dtype, pin_memory=True)
+                    h.copy_(o, non_blocking=True)
+                    STATS["d2h_bytes"] += h.numel() * h.element_size()
+                    outs.append(h)
+                done = torch.cuda.Event()
+                done.record(lane_stream)
+            staged = stage(k + 1) if k + 1 < len(plan.buckets) else None   # the next bucket is on its way meanwhile
+            inflight.append((idxs, outs, done, probs))
+            while len(inflight) > len(lane_list):
+                first = inflight.pop(0)
+                first[2].synchronize()
+                yield finish(first)
+        for first in inflight:
             first[2].synchronize()
             yield finish(first)
-    for first in inflight:
-        first[2].synchronize()
-        yield finish(first)
-    for a, b in copies:
-        b.synchronize()
-        STATS["h2d_s"] += a.elapsed_time(b) / 1e3
-    for _, st in lane_list[1:]:
-        cur.wait_stream(st)
+    finally:
+        # also when the consumer stops early or an exception propagates: the sibling lanes' work is ordered before
+        # whatever the caller enqueues next, and the copy events are drained
+        for _, st in lane_list[1:]:
+            cur.wait_stream(st)
+        cur.wait_stream(pool.stream)
+        for a, b in copies:
+            b.synchronize()
+            STATS["h2d_s"] += a.elapsed_time(b) / 1e3
 
 
 def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
@@ -318,7 +364,7 @@ def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
     """Speech segments (sample indices) of many recordings: bucketed GPU batches, then the segmenter.
     scan_kw: the threshold/duration arguments of get_speech_timestamps.
 
-    device_scan (default: on for a GPU model with pinned arithmetic): the scan runs on the GPU right behind the
+    device_scan (default: on for a GPU model backed by the native engine): the scan runs on the GPU right behind the
     kernels of its bucket (vad_segment_probs_device, one lane per recording) and only counts + segment lists come
     back over PCIe; otherwise the probabilities are copied to the host and scanned by the native threaded scanner.
     Both give the same segments (one source, csrc/scanner.hpp)."""
@@ -328,7 +374,7 @@ def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
     dev = getattr(model, "device", None)
     on_gpu = dev is not None and torch.device(dev).type == "cuda"
     if device_scan is None:
-        device_scan = on_gpu and getattr(model, "precision", None) != "auto"
+        device_scan = on_gpu and hasattr(getattr(model, "engine", None), "_h")
     if device_scan:
         params = _segment_params(sampling_rate, **scan_kw)
         cap0 = 24                                              # segments per recording copied back optimistically
@@ -535,16 +581,10 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
     slots = max(1, min(int(slots), sum(1 for m in lengths if m > 0)))
     plan = plan or RefillPlan(lengths, slots, slab_chunks, n)
     B, S, width = plan.slots, plan.slab_chunks, plan.slab_chunks * n
-    host_audio = []
-    for a in audios:                                   # contiguous CPU tensors of one dtype (views are fine)
-        a = a if torch.is_tensor(a) else torch.as_tensor(a)
-        if a.dim() != 1:
-            raise ValueError("More than one dimension in audio. Are you trying to process audio with 2 channels?")
-        if a.dtype != dtype or not a.is_contiguous() or a.is_cuda:
-            if as_i16:
-                raise TypeError("mixed int16 / float recordings in one call")
-            a = a.to("cpu", dtype).contiguous()
-        host_audio.append(a)
+    mode = _upload_mode()
+    src = _Sources(audios, dtype, check_pinned=on_gpu and mode != "stage" and hasattr(eng, "upload_rows"))
+    direct = src.pinned                                # pinned recordings: one gather kernel per slab, no host copy
+    how = 0 if mode == "dma" else 1
     base = np.zeros(len(audios) + 1, dtype=np.int64)   # recording i owns out_flat[base[i] : base[i] + n_chunks(i)]
     for i in range(len(audios)):
         base[i + 1] = base[i] + (plan.n_chunks(i) if lengths[i] > 0 else 0)
@@ -564,7 +604,9 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
         STATS["padded"] += plan.padded_chunks() * n
         STATS["real"] += sum(m for m in lengths if m > 0)
 
-        ptr0 = np.array([a.data_ptr() if a.numel() else 0 for a in host_audio], dtype=np.uint64)
+        ptr0 = src.ptr
+        if on_gpu and hasattr(eng, "reserve"):
+            eng.reserve(sampling_rate, B, S)
 
         def stage(k):
             e = plan.slab_arrays[k]                                        # [entries, 5], vectorised bookkeeping
@@ -583,14 +625,15 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
             nbytes = B * width * esz
             t0 = time.perf_counter()
             if on_gpu:
-                i = pool.get(k, nbytes)
-                host = pool.host[i][:nbytes].view(dtype).view(B, width)
+                i = pool.get(k, 0 if direct else nbytes, nbytes)
+                host = None if direct else pool.host[i][:nbytes].view(dtype).view(B, width)
             else:
                 i, host = 0, torch.empty((B, width), dtype=dtype)
-            rc = lib().vad_stage_rows(rows_p, lens_p, B, width, esz, host.data_ptr(), 0)
-            if rc:
-                raise _lib.VadError(rc, "vad_stage_rows")
-            STATS["stage_s"] += time.perf_counter() - t0
+            if host is not None:
+                rc = lib().vad_stage_rows(rows_p, lens_p, B, width, esz, host.data_ptr(), 0)
+                if rc:
+                    raise _lib.VadError(rc, "vad_stage_rows")
+                STATS["stage_s"] += time.perf_counter() - t0
             STATS["buckets"] += 1
             if not on_gpu:
                 return host, None, i, torch.from_numpy(dst.reshape(-1)), torch.from_numpy(np.ascontiguousarray(resets))
@@ -603,7 +646,11 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
             if pool.consumed[i] is not None:
                 pool.stream.wait_event(pool.consumed[i])
             with torch.cuda.stream(pool.stream):
-                d.copy_(host, non_blocking=True)
+                if direct:
+                    eng.upload_rows(rows_p, lens_p, B, width, esz, d, how)
+                    STATS["upload_call_s"] += time.perf_counter() - t0
+                else:
+                    d.copy_(host, non_blocking=True)
                 m_d = m.to(dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(pool.stream)
@@ -664,10 +711,7 @@ def refill_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
 
 
 # ---- live streams --------------------------------------------------------------------------------------
-# Live streams: StreamPool drives the engine directly (no host synchronisation per tick) with whatever arithmetic
-# the engine is set to -- fp32 by default.  The wrapper's "auto" fallback does not apply here: with the opt-in
-# f16x3 arithmetic a stream whose input leaves the fp16 range (|pcm| far above 1) reports NaN from that tick on
-# until it is reset.
+# Live streams: StreamPool drives the engine directly (no host synchronisation per tick), fp32 like everything else.
 class StreamPool:
     """`capacity` concurrently live streams on one GPU, one `tick` per 32 ms chunk.
 

@@ -21,15 +21,21 @@ from . import _lib
 from ._lib import lib
 
 
-def _speech_probs(audio, model, sampling_rate, window, progress_cb):
-    n = len(audio)
+def _speech_probs(audio, model, sampling_rate, window, progress_cb, step=1):
+    """Speech probability of every `window`-sample chunk of `audio` (utils_vad.py:323-336).  `audio` is at
+    `sampling_rate * step` Hz when step > 1 (a multiple of 16 kHz): a model with `audio_forward_device` is then handed
+    the RAW signal and rate and reads every step-th sample on the GPU (the reference's `audio[::step]`,
+    utils_vad.py:301-307, without the decimated copy); any other model object gets the decimated view."""
+    n = (len(audio) + step - 1) // step                  # len(audio[::step])
     fast = getattr(model, "audio_forward_device", None)
     if fast is not None and n > 0:
         x = audio.unsqueeze(0)
         if n < window:      # the reference pads every chunk to a full window (utils_vad.py:326-327), so a
-            x = torch.nn.functional.pad(x, (0, window - n))   # recording shorter than one window is legal here
-        probs = fast(x, sampling_rate)[0].cpu()          # (a HipSileroVAD in "auto" mode applies its fp32 rerun here)
+            x = torch.nn.functional.pad(x, (0, window * step - len(audio)))   # recording shorter than one window is legal here
+        probs = fast(x, sampling_rate * step)[0].cpu()
     else:
+        if step > 1:
+            audio = audio[::step]
         model.reset_states()
         vals = []
         for start in range(0, n, window):
@@ -114,15 +120,14 @@ def get_speech_timestamps(audio: torch.Tensor,
     step = 1
     if sampling_rate > 16000 and (sampling_rate % 16000 == 0):
         step = sampling_rate // 16000
-        sampling_rate = 16000
-        audio = audio[::step]
+        sampling_rate = 16000                            # (the decimation itself, audio[::step], happens in _speech_probs)
         warnings.warn('Sampling rate is a multiply of 16000, casting to 16000 manually!')
     if sampling_rate not in [8000, 16000]:
         raise ValueError("Currently silero VAD models support 8000 and 16000 (or multiply of 16000) sample rates")
 
     window = 512 if sampling_rate == 16000 else 256
-    total = len(audio)
-    probs = _speech_probs(audio, model, sampling_rate, window, progress_tracking_callback)
+    total = (len(audio) + step - 1) // step              # len(audio[::step]), utils_vad.py:305
+    probs = _speech_probs(audio, model, sampling_rate, window, progress_tracking_callback, step)
     speeches = segment_probs(probs, total, sampling_rate, threshold, neg_threshold,
                              min_speech_duration_ms, max_speech_duration_s, min_silence_duration_ms,
                              speech_pad_ms, min_silence_at_max_speech, use_max_poss_sil_at_max_speech)

@@ -311,177 +311,6 @@ def rec_step(whh, tables, tb, gx, h, c):
     return sigmoid_f(p.astype(f32)), hn, cn
 
 
-# ---- fp16x3 split kernels (kernel_front_split.hip, kernel_rec_split.hip) ----------------------------
-def mfma_16x16x32_f16(a, b, acc):
-    """v_mfma_f32_16x16x32_f16: a, b [64 lanes][8 halves]; lane (g, i) of a holds A[row i][slots (g, e)],
-    lane (g, j) of b holds B[slots (g, e)][col j]; D[4g + r][j] in acc[r][16g + j]."""
-    A = a.astype(np.float64).reshape(4, 16, 8)        # [g][i][e]
-    Bm = b.astype(np.float64).reshape(4, 16, 8)       # [g][j][e]
-    D = np.einsum("gie,gje->ij", A, Bm).astype(f32)
-    out = acc.copy()
-    for r in range(4):
-        out[r] += D[4 * G + r, J]
-    return out
-
-
-def split2(x):
-    """fp32 [...] -> (hi, lo) float16, round to nearest (v_cvt_pk_f16_f32)."""
-    hi = x.astype(np.float16)
-    lo = (x - hi.astype(f32)).astype(np.float16)
-    return hi, lo
-
-
-SSEG = {"E0": 0, "E1": 3, "E2T1": 12, "E2T2": 13, "E3T1": 14, "IH0": 15, "N": 19}
-
-
-def sseg_mblocks(s):
-    return 4 if s < SSEG["E3T1"] else 8
-
-
-def sseg_usteps(s, Q):
-    if s < SSEG["E2T1"]:
-        return Q // 8 if (s % 6) < 3 else 2
-    return 2 if s < SSEG["IH0"] else 4
-
-
-def sseg_offset(s, Q):        # in halves
-    return sum(sseg_usteps(i, Q) * sseg_mblocks(i) * 1024 for i in range(s))
-
-
-class FrontSplitEmu(FrontEmu):
-    """kernel_front_split.hip on one 16-chunk tile; `image` = the uint16 split image (float16 view)."""
-
-    def __init__(self, sr, image, tables):
-        self.Q = 32 if sr == 16000 else 16
-        self.img = image.view(np.float16)
-        self.tab = tables
-        self.tb = Tab(8 * self.Q, self.Q)
-        assert len(tables) == self.tb.total
-        assert len(self.img) == sseg_offset(SSEG["N"], self.Q)
-        self.mx = 0.0
-
-    def pack_mag(self, X):
-        """X [Q+1][64] -> list over K32 steps of (hi [64][8], lo [64][8])."""
-        ops = []
-        for u in range(self.Q // 8):
-            v = X[8 * u: 8 * u + 8].T.copy()                # [lane][e]
-            self.mx = max(self.mx, float(np.abs(v).max()))
-            ops.append(split2(v))
-        return ops
-
-    def relu_pack(self, D):
-        """D [NB][4][64] -> NB/2 operands; slot e = (block 2u + (e >> 2), register e & 3)."""
-        ops = []
-        for u in range(D.shape[0] // 2):
-            v = np.maximum(np.concatenate([D[2 * u], D[2 * u + 1]], 0), 0).T.copy()    # [lane][8]
-            self.mx = max(self.mx, float(np.abs(v).max()))
-            ops.append(split2(v))
-        return ops
-
-    def gemm_split(self, seg, uses):
-        """uses: list of (acc [M][4][64], operands); acc += A_seg * B with hi*hi + hi*lo + lo*hi."""
-        Q = self.Q
-        M, U = sseg_mblocks(seg), sseg_usteps(seg, Q)
-        base = sseg_offset(seg, Q)
-        for u in range(U):
-            for m in range(M):
-                pair = self.img[base + (u * M + m) * 1024: base + (u * M + m + 1) * 1024]
-                ah, al = pair[:512].reshape(64, 8), pair[512:].reshape(64, 8)
-                for acc, ops in uses:
-                    bh, bl = ops[u]
-                    acc[m] = mfma_16x16x32_f16(ah, bh, acc[m])
-                    acc[m] = mfma_16x16x32_f16(ah, bl, acc[m])
-                    acc[m] = mfma_16x16x32_f16(al, bh, acc[m])
-
-    def nyq(self, Y, xn, tau, h):
-        tb = self.tb
-        for m in range(4):
-            for r in range(4):
-                w = self.tab[tb.w_nyq + tau * 128 + 64 * h + 16 * m + 4 * G + r]
-                Y[m, r] = w * xn + Y[m, r]
-
-    def run(self, x):
-        tb, S = self.tb, SSEG
-        Xf = [self.fft_pass(x, v) for v in range(4)]
-        X = [self.pack_mag(Xf[v]) for v in range(4)]
-        xn = [Xf[v][self.Q][J] for v in range(4)]            # lane j (group 0) holds the Nyquist magnitude
-        Z0, Z1 = self.init_bias(4, tb.b_e1), self.init_bias(4, tb.b_e1)
-        for h in range(2):                                   # frames 0, 1
-            Ya, Yb = self.init_bias(4, tb.b_e0 + 64 * h), self.init_bias(4, tb.b_e0 + 64 * h)
-            e0, e1 = S["E0"] + 6 * h, S["E1"] + 6 * h
-            self.gemm_split(e0 + 0, [(Yb, X[0])])
-            self.gemm_split(e0 + 1, [(Ya, X[0]), (Yb, X[1])])
-            self.gemm_split(e0 + 2, [(Ya, X[1]), (Yb, X[2])])
-            self.nyq(Yb, xn[0], 0, h); self.nyq(Ya, xn[0], 1, h); self.nyq(Yb, xn[1], 1, h)
-            self.nyq(Ya, xn[1], 2, h); self.nyq(Yb, xn[2], 2, h)
-            Pa, Pb = self.relu_pack(Ya), self.relu_pack(Yb)
-            self.gemm_split(e1 + 1, [(Z0, Pa)])
-            self.gemm_split(e1 + 2, [(Z0, Pb)])
-            self.gemm_split(e1 + 0, [(Z1, Pb)])
-        for h in range(2):                                   # frames 2, 3
-            Ya, Yb = self.init_bias(4, tb.b_e0 + 64 * h), self.init_bias(4, tb.b_e0 + 64 * h)
-            e0, e1 = S["E0"] + 6 * h, S["E1"] + 6 * h
-            self.gemm_split(e0 + 0, [(Ya, X[1]), (Yb, X[2])])
-            self.gemm_split(e0 + 1, [(Ya, X[2]), (Yb, X[3])])
-            self.gemm_split(e0 + 2, [(Ya, X[3])])
-            self.nyq(Ya, xn[1], 0, h); self.nyq(Yb, xn[2], 0, h); self.nyq(Ya, xn[2], 1, h)
-            self.nyq(Yb, xn[3], 1, h); self.nyq(Ya, xn[3], 2, h)
-            Pa, Pb = self.relu_pack(Ya), self.relu_pack(Yb)
-            self.gemm_split(e1 + 1, [(Z1, Pa)])
-            self.gemm_split(e1 + 2, [(Z1, Pb)])
-        Q0, Q1 = self.relu_pack(Z0), self.relu_pack(Z1)
-        V = self.init_bias(4, tb.b_e2)
-        self.gemm_split(S["E2T1"], [(V, Q0)])
-        self.gemm_split(S["E2T2"], [(V, Q1)])
-        Fe = self.init_bias(8, tb.b_e3)
-        self.gemm_split(S["E3T1"], [(Fe, self.relu_pack(V))])
-        Pf = self.relu_pack(Fe)
-        gx = np.zeros((32, 4, 64), f32)
-        for q in range(4):
-            Gq = self.init_bias(8, tb.b_g + 128 * q)
-            self.gemm_split(S["IH0"] + q, [(Gq, Pf)])
-            gx[8 * q: 8 * q + 8] = Gq
-        return {"X": Xf, "feat": np.maximum(Fe, 0), "gx": gx, "mx": self.mx}
-
-
-def rec_split_step(whh_img, tables, tb, gx, h, c):
-    """kernel_rec_split.hip, one step, one 16-stream tile."""
-    W = whh_img.view(np.float16).reshape(8, 4, 4, 2, 64, 8)      # [wave][gate][u][hi|lo][lane][e]
-    hreg = np.zeros((8, 64, 4), f32)                             # wave w, lane (g, j): h[16w + 4g + r][j]
-    for w in range(8):
-        for r in range(4):
-            hreg[w, :, r] = h[J, 16 * w + 4 * G + r]
-    ops = []
-    for u in range(4):
-        v = np.concatenate([hreg[2 * u], hreg[2 * u + 1]], 1)    # [lane][8]
-        ops.append(split2(v))
-    hn, cn = np.zeros_like(h), np.zeros_like(c)
-    part_all = np.zeros((8, 16), f32)
-    for w in range(8):
-        acc = [gx[8 * q + w].copy() for q in range(4)]
-        for u in range(4):
-            bh, bl = ops[u]
-            for q in range(4):
-                acc[q] = mfma_16x16x32_f16(W[w, q, u, 0], bh, acc[q])
-                acc[q] = mfma_16x16x32_f16(W[w, q, u, 0], bl, acc[q])
-                acc[q] = mfma_16x16x32_f16(W[w, q, u, 1], bh, acc[q])
-        part = np.zeros(64, f32)
-        for r in range(4):
-            cl = c[J, 16 * w + 4 * G + r]
-            ig, fg = sigmoid_f(acc[0][r]), sigmoid_f(acc[1][r])
-            gg, og = tanh_f(acc[2][r]), sigmoid_f(acc[3][r])
-            cnew = fg * cl + ig * gg
-            hnew = og * tanh_f(cnew)
-            cn[J, 16 * w + 4 * G + r] = cnew
-            hn[J, 16 * w + 4 * G + r] = hnew
-            part = part + tables[tb.w_out + 16 * w + 4 * G + r] * np.maximum(hnew, 0)
-        part = part + shfl_xor(part, 16)
-        part = part + shfl_xor(part, 32)
-        part_all[w] = part[:16]
-    p = tables[tb.b_out] + part_all.sum(0)
-    return sigmoid_f(p.astype(f32)), hn, cn
-
-
 # ---- kernel_front_wino.hip: encoder 0 as two Winograd F(2,3) transforms, weight stream in whole units ------------
 def w_rb(Q):
     return 64 // Q

@@ -11,6 +11,8 @@ import torch
 class ReplayEngine:
     device = 0
     torch_device = torch.device("cpu")
+    fused_front_door = False         # the oracle takes 8 / 16 kHz only: HipSileroVAD decimates on the host for this stand-in
+    options = {}
 
     def __init__(self, oracle):
         self.oracle = oracle

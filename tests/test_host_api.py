@@ -66,54 +66,3 @@ def test_get_speech_timestamps_argument_errors(built):
     assert get_speech_timestamps(torch.zeros(0), Dummy()) == []
 
 
-class _FakeEngine:
-    """Stands in for the C-ABI engine: 'f16x3' answers NaN (and poisons the carried state) when the input is
-    louder than 4, 'fp32' never does -- the contract of include/silero_vad_hip.h, option "precision"."""
-    device = 0
-
-    def __init__(self):
-        self.precision = "f16x3"
-        self.calls = []
-
-    def set_precision(self, p):
-        self.precision = p
-
-
-def _guard_model(policy):
-    from silero_vad_amd.engine import HipSileroVAD
-    m = HipSileroVAD.__new__(HipSileroVAD)
-    m.engine = _FakeEngine()
-    m.precision = policy
-    m.device = torch.device("cpu")
-    m.sample_rates = [8000, 16000]
-    m.reset_states()
-    m._state = torch.zeros(2, 1, 128)
-    m._context = torch.zeros(1, 64)
-    return m
-
-
-def _fake_step(m, x):
-    def run():
-        m.engine.calls.append(m.engine.precision)
-        loud = bool(x.abs().max() > 4) and m.engine.precision == "f16x3"
-        m._state += float("nan") if loud else 1.0            # the kernels update the state in place
-        m._context += 1.0
-        return torch.full((1, 1), float("nan") if loud else 0.25)
-    return run
-
-
-def test_auto_precision_reruns_out_of_range_calls_in_fp32():
-    m = _guard_model("auto")
-    out = m._guarded(_fake_step(m, torch.ones(512)))
-    assert out.item() == 0.25 and m.engine.calls == ["f16x3"]
-    out = m._guarded(_fake_step(m, 100 * torch.ones(512)))
-    assert out.item() == 0.25                                   # answered by the fp32 rerun
-    assert m.engine.calls == ["f16x3", "f16x3", "fp32"]
-    assert m.engine.precision == "f16x3"                        # policy restored
-    assert torch.all(m._state == 2.0) and torch.all(m._context == 2.0)   # state advanced exactly twice, no NaN left
-
-
-def test_pinned_precision_is_not_second_guessed():
-    m = _guard_model("f16x3")
-    out = m._guarded(_fake_step(m, 100 * torch.ones(512)))
-    assert torch.isnan(out).all() and m.engine.calls == ["f16x3"]        # NaN is the documented answer

@@ -20,7 +20,7 @@ def packed(built):
     assert L.vad_create_host_only(blob, len(blob), ctypes.byref(h)) == 0
     out = {}
     for sr in (16000, 8000):
-        for which in range(7):
+        for which in (0, 1, 2, 5, 6):
             n = L.vad_debug_packed_floats(h, sr, which)
             a = np.empty(n, np.float32)
             assert L.vad_debug_packed_copy(h, sr, which, a.ctypes.data_as(_lib.f32p), n) == 0
@@ -43,26 +43,6 @@ def test_wave_program_matches_reference_activations(packed, golden, tag):
     assert np.abs(feat - ref).max() < 3e-5
     prob, hn, cn = E.rec_step(packed[sr, 1], packed[sr, 2], emu.tb, out["gx"],
                               g["stage_state_in"][0], g["stage_state_in"][1])
-    assert np.abs(prob - g["stage_prob"][:, 0]).max() < 1e-5
-    assert state_err(np.stack([hn, cn]), g["stage_state_out"]) < 2e-5
-
-
-@pytest.mark.parametrize("tag", ["16k", "8k"])
-def test_split_wave_program_matches_reference_activations(packed, golden, tag):
-    """The fp16x3 split kernels' program (frame pairs, row halves, Nyquist rank-1 update, packed
-    (hi, lo) operands) on the split images the C++ packer produces."""
-    sr, g = SRS[tag], golden[tag]
-    emu = E.FrontSplitEmu(sr, packed[sr, 3], packed[sr, 2])
-    out = emu.run(g["stage_x"])
-    feat = E.chain_to_dense(out["feat"])
-    ref = g["stage_enc3"][:, :, 0]
-    assert np.abs(feat - ref).max() < 3e-5
-    assert 1.0 < out["mx"] < 65000.0
-    # same gx as the fp32 program, to fp32 round-off
-    gx32 = E.FrontEmu(sr, packed[sr, 0], packed[sr, 2]).run(g["stage_x"])["gx"]
-    assert np.abs(out["gx"] - gx32).max() < 2e-4 * max(1.0, np.abs(gx32).max())
-    prob, hn, cn = E.rec_split_step(packed[sr, 4], packed[sr, 2], emu.tb, out["gx"],
-                                    g["stage_state_in"][0], g["stage_state_in"][1])
     assert np.abs(prob - g["stage_prob"][:, 0]).max() < 1e-5
     assert state_err(np.stack([hn, cn]), g["stage_state_out"]) < 2e-5
 

@@ -171,3 +171,72 @@ def test_refill_equals_one_recording_at_a_time(oracle, sr):
         if len(a):
             want = oracle.audio_forward(np.pad(a.numpy().astype(np.float32) / 32768.0, (0, max(0, n - len(a))))[None], sr)[0]
             assert np.abs(p.numpy() - want).max() < 1e-6
+
+
+def test_refill_and_buckets_accept_strided_int16_views(oracle):
+    """Advisor finding (round 2): `batch_speech_timestamps(int16 audios, sampling_rate=32000, scheduler="refill")` hands
+    `a[::2]` views to the scheduler; a non-contiguous int16 recording is the SAME dtype and must simply be made
+    contiguous, not rejected as "mixed int16 / float"."""
+    import warnings
+    from replay_engine import ReplayEngine
+    from silero_vad_amd import batch_speech_timestamps, refill_probs, ragged_probs
+    from silero_vad_amd.engine import HipSileroVAD
+    sr, n = 16000, 512
+    rng = np.random.default_rng(4)
+    t = np.arange(40 * n * 2) / (2 * sr)
+    raw = ((0.3 * np.sin(2 * np.pi * 210 * t) * (np.sin(2 * np.pi * 1.2 * t) > 0) + 0.02 * rng.standard_normal(len(t))) * 32767)
+    raws = [torch.from_numpy(np.roll(raw, -911 * i)[: 2 * m].astype(np.int16)) for i, m in enumerate((9 * n, 17 * n + 5, 30 * n, n))]
+    views = [a[::2] for a in raws]
+    assert not views[0].is_contiguous()
+    model = HipSileroVAD(engine=ReplayEngine(oracle))
+    want = [oracle.audio_forward(np.pad(v.numpy().astype(np.float32) / 32768.0, (0, max(0, n - len(v))))[None], sr)[0] for v in views]
+    for got in (refill_probs(views, model, sr, slots=3, slab_chunks=4), ragged_probs(views, model, sr)):
+        for p, w in zip(got, want):
+            assert np.abs(p.numpy() - w).max() < 1e-6
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = batch_speech_timestamps(raws, model, sampling_rate=32000, scheduler="refill", threshold=0.1, min_speech_duration_ms=64)
+        b = batch_speech_timestamps(raws, model, sampling_rate=32000, scheduler="buckets", threshold=0.1, min_speech_duration_ms=64)
+    assert a == b
+    with pytest.raises(TypeError, match="mixed int16 / float"):
+        refill_probs([views[0], views[1].to(torch.float32)], model, sr)
+
+
+def test_host_thread_budget_is_divided_among_local_ranks(built):
+    """One process per GPU (torchrun --nproc-per-node N exports LOCAL_WORLD_SIZE): every rank may use 1/N of the node's
+    CPU budget for its staging / scan workers, never all of it (8 x 16 threads under a 16-CPU quota is the
+    oversubscription csrc/host_threads.hpp measured at 13x)."""
+    import subprocess
+    import sys
+    code = "from silero_vad_amd import _lib; print(_lib.lib().vad_host_threads())"
+    def run(**env):
+        import os
+        e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+        for k in ("LOCAL_WORLD_SIZE", "SILERO_VAD_AMD_HOST_THREADS"):
+            if k not in env:
+                e.pop(k, None)
+        return int(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.split()[-1])
+    one = run()
+    assert one >= 1
+    assert run(LOCAL_WORLD_SIZE=8) == max(1, one // 8)
+    assert run(LOCAL_WORLD_SIZE=2) == max(1, one // 2)
+    assert run(LOCAL_WORLD_SIZE=8, SILERO_VAD_AMD_HOST_THREADS=5) == 5
+
+
+def test_stage_rows_on_the_persistent_pool(built):
+    """vad_stage_rows on many threads, repeatedly (the pool's workers are created once and reused), with a thread
+    count that changes between calls."""
+    import ctypes
+    from silero_vad_amd import _lib
+    rng = np.random.default_rng(8)
+    base = rng.integers(-3000, 3000, 1 << 22).astype(np.int16)
+    width, n = 300_000, 40
+    for threads in (7, 3, 12, 1, 7):
+        lens = rng.integers(0, width + 1, n)
+        offs = rng.integers(0, len(base) - width, n)
+        rows = (ctypes.c_void_p * n)(*[base.ctypes.data + 2 * int(o) for o in offs])
+        clens = (ctypes.c_long * n)(*[int(v) for v in lens])
+        dst = np.full((n, width), 9, np.int16)
+        assert _lib.lib().vad_stage_rows(rows, clens, n, width, 2, dst.ctypes.data, threads) == 0
+        for i in range(n):
+            assert np.array_equal(dst[i, :lens[i]], base[offs[i]:offs[i] + lens[i]]) and not dst[i, lens[i]:].any()

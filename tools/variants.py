@@ -69,8 +69,10 @@ VARIANTS = {
     "w8": ["-DVAD_SPLIT_WAVES=8"],
     "prio1": ["-DVAD_SPLIT_PRIO=1"], "prio3": ["-DVAD_SPLIT_PRIO=3"],
     "ntpcm": ["-DVAD_SPLIT_NT_PCM=1"], "ntgx": ["-DVAD_SPLIT_NT_GX=1"],
-    "rec_inphase": ["-DVAD_REC_SKEW=0"],               # round-2 recurrence: all 8 waves in phase, one barrier per step
-    "rec_noprio": ["-DVAD_REC_PRIO=0"],                # skewed recurrence without s_setprio on the tail wave
+    "rec_skew": ["-DVAD_REC_SKEW=1"],                  # recurrence with the two waves of a SIMD half a step apart (slower: r03a)
+    "rec_skew_noprio": ["-DVAD_REC_SKEW=1", "-DVAD_REC_PRIO=0"],
+    "bvbatch": ["-DVAD_BV_BATCH=1"],                   # frontend: a step's four B operands first, then its 8 MFMAs back to back
+    "nobvbatch": ["-DVAD_BV_BATCH=0"],
     "recd1": ["-DVAD_REC_DEPTH=1"], "recd3": ["-DVAD_REC_DEPTH=3"],
     # "pk*": the split translation units WITH packed-fp32 VALU instructions -- reproduces the corruption
     # described in kernel_front_split.hip under two workgroups per CU (tools/split_stress.py)
