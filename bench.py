@@ -1,32 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: speech-probability throughput of the Silero-VAD hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|8k|stream|corpus] [--precision fp32|f16x3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|8k|stream|corpus|plumbing]
 
 `--gpus N` (N > 1) works both ways the driver may start it: under `python -m torch.distributed.run
 --nproc-per-node N ... bench.py --gpus N` (RANK/LOCAL_RANK/WORLD_SIZE in the environment), and as a plain
 `python bench.py --gpus N`, which re-executes itself under torch.distributed.run on 127.0.0.1.
 
 Default workload `c2` (BASELINE.json configs[1], SURVEY.md section 8d "C2"): synthetic 16 kHz PCM, 512-sample
-chunks, 4096 independent streams per GPU x 256 chunks per stream, fp32, already resident in HBM, exact fp32
+chunks, 4096 independent streams per GPU x 256 chunks per stream, fp32, already resident in HBM, fp32
 arithmetic (`dtype: "f32"`, the reference's).  One "step" = one pass of the hot path over that batch = ONE
 vad_forward_audio call through the C ABI (zeroed context/state, like the reference's audio_forward).  Streams
 are sharded across ranks with no data-path collective (weak scaling: every rank owns 4096 streams); the only
 communication is the barrier + MAX-reduce of the elapsed time that the measurement contract asks for.
 
-At N = 1 the same JSON line also carries, for the record (none of them is the headline `value`):
-  other_precision  the opt-in f16x3 arithmetic on the same data, same ramp/steps protocol
-  other_configs    8k     configs[2]: 8 kHz, 256-sample chunks, 4096 streams x 256 chunks (the 8 kHz net)
-                   stream configs[4]: 8192 live streams per GPU (65 536 per 8-GPU node), persistent state in
-                          HBM, one hipGraph-captured vad_step per 32 ms tick; reports tick latency
-                   corpus configs[3] (bounded sample): ragged int16 recordings in host memory -> pinned staging
-                          -> H2D overlapped with compute -> probs -> native segmenter.  PCIe + host inclusive.
+The same JSON line also carries, for the record (none of them is the headline `value`):
+  other_configs    8k       configs[2]: 8 kHz, 256-sample chunks, 4096 streams x 256 chunks (the 8 kHz net)   [N = 1]
+                   stream   configs[4]: 8192 live streams per GPU (65 536 per 8-GPU node), persistent state in
+                            HBM, one hipGraph-captured vad_step per 32 ms tick; reports tick latency          [any N]
+                   corpus   configs[3]: every rank runs a FULL per-GPU shard of the 10 000 h corpus (1 250 h =
+                            151 552 ragged recordings, 37 passes of 4096 over fresh offsets) from pinned host
+                            memory -> device batch (no host copy) -> probs -> segmenter on the GPU -> segment
+                            lists, sharded by duration and gathered to rank 0; wall time, PCIe- and host-inclusive,
+                            with a 1-in-10^4 recording parity sample checked after the timed region          [any N]
+                   plumbing configs[0]: the reference's default usage -- B = 1 `model(chunk, sr).item()` per-call
+                            latency (eager and hipGraph) and get_speech_timestamps on the 60 s fixture       [N = 1]
   roofline         dominant kernel (frontend: STFT + encoder + W_ih GEMM): EXECUTED fp32 MFMA flops per launch /
                    average launch duration (hipEvents recorded by the engine around that kernel on the launch
                    stream during the timed steps) against the dense fp32 MFMA peak; always <= 1
   cpu_baseline     the reference's own ATen CPU operators (oracle/aten_port.py, kind "aten-port") timed on this
                    box's host cores under BASELINE.md section 3 protocols R1-R4 (rank 0, N = 1 only)
-`--config 8k|stream|corpus` runs one of the other configs as the main leg instead.
+`--config 8k|stream|corpus|plumbing` runs one of the other configs as the main leg instead.
 """
 import argparse
 import glob
@@ -46,34 +50,27 @@ CHUNKS_PER_STREAM = 256  # per step
 LIVE_STREAMS = 8192      # per GPU (stream): 65 536 per 8-GPU node
 CLOCK_RAMP_STEPS = 40    # untimed steps before the warm-up: DVFS ramp, see run_batch
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
-PEAK_F16_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 # Work per chunk.  "flop"/"bytes": the reference's DENSE arithmetic and its I/O --
 # "useful reference work".  "front_mfma" / "rec_mfma": matrix flops our kernels EXECUTE (rFFT frontend on the VALU
-# instead of the DFT-basis conv, encoder 0 as Winograd F(2,3) over frame pairs (4 instead of 5 GEMMs per pair), zero-padding
-# taps skipped, the Nyquist bin applied on the VALU) = MFMA instructions per
-# 16-chunk tile (tools/isa_mix.py; SQ_INSTS_MFMA / tiles in profiles/) x 2048 flop / 16 -- the numerator of
-# roofline.frac.  f16x3: three f16 products per product.
+# instead of the DFT-basis conv, encoder 0 as ONE Winograd F(4,3) tile over the 4 frames (6 instead of 10 GEMMs), zero-padding
+# taps skipped, the Nyquist bin applied on the VALU) = MFMA instructions per 16-chunk tile (SQ_INSTS_MFMA / tiles in
+# profiles/) x 2048 flop / 16 -- the numerator of roofline.frac.
 WORK = {
     16000: {"chunk": 512, "flop": 1_359_104, "bytes": 2_052,
             "front_dense": 2 * (264_192 + 198_144 + 49_152 + 12_288 + 24_576 + 65_536),
-            "front_mfma": 54 * 64 * 2048 // 16,       # 3 456 MFMAs / tile: 54 weight units x 64 (enc0 as one Winograd F(4,3) tile)
-            "front_mfma_direct": 2 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),   # 4 480 (enc0 tap by tap)
-            "front_split_mfma": 2 * 3 * (10 * 128 * 128 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
+            "front_mfma": 54 * 64 * 2048 // 16,       # 3 456 MFMAs / tile: 54 weight units x 64
             # VALU issue cycles per tile beside the MFMAs (same pipe): 2 612 packed x 5.4 + 4 266 other x 2.6
-            # (SQ_INSTS_VALU - SQ_INSTS_MFMA per tile, profiles/r02k_fp32_summary.md; rates profiles/r02d_issue_pipes.md)
+            # (SQ_INSTS_VALU - SQ_INSTS_MFMA per tile, profiles/r02k_fp32_summary.md; rates profiles/r02d_issue_pipes.md,
+            #  confirmed by profiles/r03a_issue_pipes2.md: an fp32 MFMA owns the SIMD's vector issue, the times add)
             "front_valu_cycles": 25_200,
-            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_f43_kernel<32, float>",
-            "front_split_kernel": "front_split_kernel<32, float>"},
+            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_f43_kernel<32, float>"},
     8000: {"chunk": 256, "flop": 767_232, "bytes": 1_028,
            "front_dense": 2 * (66_560 + 99_840 + 49_152 + 12_288 + 24_576 + 65_536),
-           "front_mfma": 42 * 64 * 2048 // 16,        # 2 688 MFMAs / tile (Winograd F(4,3))
-           "front_mfma_direct": 2 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),    # 3 200
-           "front_split_mfma": 2 * 3 * (10 * 128 * 64 + 5 * 64 * 128 + 2 * 64 * 64 + 128 * 64 + 512 * 128),
+           "front_mfma": 42 * 64 * 2048 // 16,        # 2 688 MFMAs / tile
            "front_valu_cycles": 12_500,                # 1 280 packed x 5.4 + 2 144 other x 2.6 (profiles/r02k_8k_summary.md)
-           "rec_mfma": 2 * 512 * 128, "front_kernel": "front_f43_kernel<16, float>",
-           "front_split_kernel": "front_split_kernel<16, float>"},
+           "rec_mfma": 2 * 512 * 128, "front_kernel": "front_f43_kernel<16, float>"},
 }
 GX_BYTES = 2048          # engine-internal: fp32 LSTM input-gate pre-activations per chunk, written and read once
 
@@ -211,72 +208,70 @@ def issue_pipe(w, chunks_per_launch, front_ms_avg):
             "definition": "(MFMA + VALU issue cycles per tile) x tiles per SIMD / 2.4 GHz, over the measured launch time"}
 
 
-def roofline(sr, chunks_per_launch, front_ms_avg, rec_ms_avg, B, T, precision):
+def roofline(sr, chunks_per_launch, front_ms_avg, rec_ms_avg, B, T):
     """Dominant kernel = the frontend (STFT + encoder + W_ih).  achieved = matrix flops the kernel EXECUTES per
-    launch / its average launch duration, peak = the dense peak of the pipe it runs on (fp32 MFMA 157.3 TF, or
-    the f16 peak for the opt-in f16x3 kernels): frac <= 1.  The reference's dense flop count for the same part of
-    the path ("useful work") is reported separately and is never divided into `frac`.  traffic = HBM bytes per
-    launch of this kernel from the committed PMC pass; `path` relates the whole path (both kernels) to the
-    algorithmic bytes of SURVEY 8(d)."""
+    launch / its average launch duration, peak = the dense fp32 MFMA peak (157.3 TF): frac <= 1.  The reference's
+    dense flop count for the same part of the path ("useful work") is reported separately and is never divided into
+    `frac`.  `traffic` is null: this run collects no PMC counters; `traffic_profiled` quotes the HBM bytes per launch
+    of this kernel from the newest committed rocprofv3 --pmc passes of this same command (profiles/), labelled as such;
+    `path` relates the whole path (both kernels) to the algorithmic bytes of SURVEY 8(d) the same way."""
     w = WORK[sr]
-    split = precision == "f16x3"
     s = front_ms_avg / 1e3
-    ex_flop = w["front_split_mfma"] if split else w["front_mfma"]
-    ex_peak = PEAK_F16_TFLOPS if split else PEAK_F32_TFLOPS
+    ex_flop = w["front_mfma"]
     execd = chunks_per_launch * ex_flop / s / 1e12
-    kname = w["front_split_kernel"] if split else w["front_kernel"]
-    rname = "rec_split_kernel" if split else "rec_kernel"
+    kname = w["front_kernel"]
     tr_f = pmc_traffic(kname.split(",")[0], sr, B, T)
-    tr_r = pmc_traffic(rname, sr, B, T)
+    tr_r = pmc_traffic("rec_kernel", sr, B, T)
     alg = chunks_per_launch * w["bytes"]
     kio = chunks_per_launch * (w["chunk"] * 4 + GX_BYTES)
     path_traffic = (tr_f["bytes"] + tr_r["bytes"]) if (tr_f and tr_r) else None
-    out = {"bound": "mfma", "kernel": kname, "dtype": "f16" if split else "f32",
-           "achieved": round(execd, 3), "peak": ex_peak, "unit": "TFLOP/s", "frac": round(execd / ex_peak, 4),
+    note = "replayed from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE); NOT measured by this run"
+    out = {"bound": "mfma", "kernel": kname, "dtype": "f32",
+           "achieved": round(execd, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(execd / PEAK_F32_TFLOPS, 4),
            "flop_per_launch": chunks_per_launch * ex_flop, "avg_launch_ms": round(front_ms_avg, 4),
            "definition": "executed MFMA flops of the dominant kernel per launch / its hipEvent launch duration, "
-                         "against the dense peak of the matrix pipe it runs on",
-           "traffic": tr_f["bytes"] if tr_f else None, "traffic_detail": tr_f,
+                         "against the dense fp32 MFMA peak",
+           "traffic": None,
+           "traffic_profiled": dict(tr_f, note=note) if tr_f else None,
            "kernel_io_bytes": kio,
            "useful_dense": {"flop_per_launch": chunks_per_launch * w["front_dense"],
                             "tflops": round(chunks_per_launch * w["front_dense"] / s / 1e12, 3),
                             "note": "the reference's dense flop count for this part of the path (DFT-basis conv, every "
                                     "tap); the kernel executes fewer -- not a utilisation figure"},
-           "issue_pipe": None if split else issue_pipe(w, chunks_per_launch, front_ms_avg),
+           "issue_pipe": issue_pipe(w, chunks_per_launch, front_ms_avg),
            "hbm": {"achieved": round(kio / s / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                    "frac": round(kio / s / 1e9 / PEAK_HBM_GBPS, 4),
                    "note": "this kernel's own I/O (PCM in + gx out) against the HBM roofline: far from binding"},
            "path": {"algorithmic_bytes": alg, "algorithmic_bytes_per_chunk": w["bytes"],
-                    "traffic": path_traffic,
-                    "traffic_over_algorithmic": round(path_traffic / alg, 3) if path_traffic else None,
-                    "traffic_detail": {"front": tr_f, "rec": tr_r},
-                    "mfma_flop_per_chunk": ex_flop + w["rec_mfma"] * (3 if split else 1)}}
+                    "traffic": None,
+                    "traffic_profiled": path_traffic,
+                    "traffic_profiled_over_algorithmic": round(path_traffic / alg, 3) if path_traffic else None,
+                    "traffic_profiled_detail": {"front": tr_f, "rec": tr_r, "note": note},
+                    "mfma_flop_per_chunk": ex_flop + w["rec_mfma"]}}
     if rec_ms_avg:
         rs = rec_ms_avg / 1e3
-        rflop = chunks_per_launch * w["rec_mfma"] * (3 if split else 1)
-        out["rec_kernel"] = {"kernel": rname, "avg_launch_ms": round(rec_ms_avg, 4),
-                             "mfma_frac": round(rflop / rs / 1e12 / ex_peak, 4),
+        rflop = chunks_per_launch * w["rec_mfma"]
+        out["rec_kernel"] = {"kernel": "rec_kernel", "avg_launch_ms": round(rec_ms_avg, 4),
+                             "mfma_frac": round(rflop / rs / 1e12 / PEAK_F32_TFLOPS, 4),
+                             "single_pipe_floor_note": "per step and SIMD 256 MFMAs (8 192 cycles) + the two waves' ~1 600 VALU cycles "
+                                                       "add on one issue pipe (profiles/r03a_issue_pipes2.md): mfma_frac <= 0.84",
                              "gx_read_GBps": round(chunks_per_launch * GX_BYTES / rs / 1e9, 1),
                              "hbm_frac": round(chunks_per_launch * GX_BYTES / rs / 1e9 / PEAK_HBM_GBPS, 4)}
     return out
 
 
-def base_line(args, world, metric_sr, value, elapsed, steps, precision):
+def base_line(args, world, metric_sr, value, elapsed, steps):
     return {"metric": f"audio-chunks/sec (32 ms @ {metric_sr // 1000} kHz)", "value": round(value, 1),
             "unit": "chunks/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if precision == "fp32" else "f16x3 (NOT fp32: 3-term fp16 split products, fp32 sums)",
-            "precision": precision, "data": "synthetic"}
+            "dtype": "f32", "data": "synthetic"}
 
 
 # ---- c2 / 8k: HBM-resident batch ------------------------------------------------------------------------
-def time_batch(eng, precision, step, probs, world, dist, dev, steps, warmup):
-    """One arithmetic on one workload: clock ramp, warm-up, `steps` timed calls with the engine's hipEvents on."""
+def time_batch(eng, step, probs, world, dist, dev, steps, warmup):
+    """Clock ramp, warm-up, `steps` timed calls with the engine's hipEvents on."""
     import torch
-    eng.set_precision(precision)
-    if os.environ.get("VAD_BENCH_ENC0"):           # tools/slow_box_hunt.sh: time an A/B form of the fp32 frontend (the
-        eng.set_option("enc0", os.environ["VAD_BENCH_ENC0"])   # roofline block of the line then does not apply)
     # the GPU takes some tens of milliseconds of load to reach its sustained clocks (measured: +4 % between the
     # 4th and the 40th step): a fixed untimed ramp precedes the W warm-up steps so that K steps time steady state
     for _ in range(max(0, CLOCK_RAMP_STEPS - warmup)):
@@ -292,7 +287,7 @@ def time_batch(eng, precision, step, probs, world, dist, dev, steps, warmup):
     return elapsed, front_ms / c, rec_ms / c, ok
 
 
-def run_batch(args, sr, rank, world, local, dist, steps, with_other):
+def run_batch(args, sr, rank, world, local, dist, steps):
     import torch
     from silero_vad_amd import Engine
     dev = torch.device("cuda", local)
@@ -310,24 +305,12 @@ def run_batch(args, sr, rank, world, local, dist, steps, with_other):
         state.zero_()
         eng.forward_audio(pcm, sr, ctx, state, probs)
 
-    elapsed, front_ms, rec_ms, ok = time_batch(eng, args.precision, step, probs, world, dist, dev, steps, args.warmup)
-    other = None
-    if with_other and world == 1:                      # the other arithmetic, same data, same protocol, for the record
-        alt = "fp32" if args.precision == "f16x3" else "f16x3"
-        p_main = probs.clone()
-        e2, f2, r2, ok2 = time_batch(eng, alt, step, probs, world, dist, dev, steps, args.warmup)
-        other = {"precision": alt, "dtype": base_line(args, 1, sr, 0, 1, 1, alt)["dtype"],
-                 "value": round(B * T * steps / e2, 1), "unit": "chunks/s", "steps": steps,
-                 "ms_per_step": round(e2 / steps * 1e3, 4), "kernel_ms": {"front": round(f2, 4), "rec": round(r2, 4)},
-                 "outputs_finite": ok2,
-                 "max_abs_prob_diff_vs_main": float((probs - p_main).abs().max().item()),
-                 "roofline": roofline(sr, B * T, f2, r2, B, T, alt)}
-        eng.set_precision(args.precision)
+    elapsed, front_ms, rec_ms, ok = time_batch(eng, step, probs, world, dist, dev, steps, args.warmup)
     if rank != 0:
         return None
     w = WORK[sr]
     value = B * T * world * steps / elapsed
-    out = base_line(args, world, sr, value, elapsed, steps, args.precision)
+    out = base_line(args, world, sr, value, elapsed, steps)
     cfg = "configs[1]" if sr == 16000 else "configs[2]"
     out["config"] = {"workload": f"{cfg}: synthetic {sr // 1000} kHz PCM resident in HBM, {n}-sample chunks, "
                                  f"{B} streams/GPU x {T} chunks/stream per step, zero initial state",
@@ -342,9 +325,7 @@ def run_batch(args, sr, rank, world, local, dist, steps, with_other):
                             "flop_per_chunk": w["flop"], "bytes_per_chunk": w["bytes"],
                             "note": "useful reference work (dense flops, SURVEY 8d) per second per GPU; informational"}
     out["kernel_ms"] = {"front": round(front_ms, 4), "rec": round(rec_ms, 4)}
-    out["roofline"] = roofline(sr, B * T, front_ms, rec_ms, B, T, args.precision)
-    if other:
-        out["other_precision"] = other
+    out["roofline"] = roofline(sr, B * T, front_ms, rec_ms, B, T)
     return out
 
 
@@ -355,7 +336,6 @@ def run_stream(args, rank, world, local, dist, steps):
     sr = 16000
     dev = torch.device("cuda", local)
     eng = Engine(device=local)
-    eng.set_precision(args.precision)
     n = WORK[sr]["chunk"]
     cap = args.live
     pool = StreamPool(eng, sr, capacity=cap, graph=True)
@@ -391,7 +371,7 @@ def run_stream(args, rank, world, local, dist, steps):
     if rank != 0:
         return None
     value = cap * world * steps / elapsed
-    out = base_line(args, world, sr, value, elapsed, steps, args.precision)
+    out = base_line(args, world, sr, value, elapsed, steps)
     out["config"] = {"workload": f"configs[4]: {cap} live 16 kHz streams/GPU ({cap * 8} per 8-GPU node), one "
                                  f"hipGraph-captured vad_step per 32 ms tick, (h,c)+context persistent in HBM",
                      "streams_per_gpu": cap, "sample_rate": sr, "step": "one tick (one chunk per stream)",
@@ -402,86 +382,287 @@ def run_stream(args, rank, world, local, dist, steps):
                               "budget_ms": 32.0}
     c = max(calls, 1)
     out["kernel_ms"] = {"front": round(front_ms / c, 4), "rec": round(rec_ms / c, 4)}
-    out["roofline"] = roofline(sr, cap, front_ms / c, rec_ms / c, cap, 1, args.precision)
+    out["roofline"] = roofline(sr, cap, front_ms / c, rec_ms / c, cap, 1)
     return out
 
 
-# ---- corpus: ragged recordings from host memory -------------------------------------------------------------
-def run_corpus(args, rank, world, local, dist, steps):
+# ---- corpus: a full per-GPU shard of the 10 000 h corpus, from pinned host memory -----------------------------
+CORPUS_HOURS_PER_GPU = 10_000.0 / 8          # BASELINE configs[3]: 10 000 h over the 8 GPUs of a node
+CORPUS_PASS = 4096                           # recordings per pass and rank (one ragged_speech_segments call)
+
+
+def corpus_shard(rank, world, passes, per_pass, sr, base_len, seed=101):
+    """The corpus as (length, offset) of every recording, pass by pass: each pass holds world x per_pass recordings of
+    20-40 s, dealt to the ranks by total duration (sharding.shard_by_duration: deterministic, every rank computes the
+    same partition without communicating).  Returns this rank's [(global ids, lengths, offsets)] per pass."""
+    import numpy as np
+    from silero_vad_amd import shard_by_duration
+    out = []
+    for p in range(passes):
+        rng = np.random.default_rng(seed + p)               # the same corpus on every rank
+        lens = rng.integers(20 * sr, 40 * sr, size=world * per_pass)
+        offs = rng.integers(0, base_len - 40 * sr, size=world * per_pass) // 8 * 8     # 16-byte aligned int16 rows
+        mine = np.asarray(shard_by_duration(lens, world, rank) if world > 1 else np.arange(per_pass), dtype=np.int64)
+        out.append((mine + p * world * per_pass, lens[mine], offs[mine]))
+    return out
+
+
+def corpus_parity_sample(model, gids, lens, offs, base_page, counts, segs, sr, every=10_000):
+    """CHECKER, outside the timed region ("parity on a 1-in-10^4 stream sample"): every 10 000th recording
+    of the corpus is recomputed alone through `audio_forward` and through the CPU oracle; its probabilities must agree to
+    the contract and the segments the corpus run returned for it must equal the segments scanned from the oracle's
+    probabilities.  (oracle/ is test infrastructure: used here as the checker only, like `smoke()` does.)"""
     import numpy as np
     import torch
-    from silero_vad_amd import load_silero_vad, ragged_speech_segments, refill_speech_segments
+    from oracle import Oracle
+    from silero_vad_amd import segment_probs
+    orc = Oracle()
+    first = np.concatenate([[0], np.cumsum(counts)])
+    worst, checked, same = 0.0, 0, True
+    for j in np.flatnonzero(gids % every == 0):
+        a = base_page[int(offs[j]):int(offs[j]) + int(lens[j])]      # (the arena the corpus run read)
+        x = a.to(torch.float32) / 32768.0
+        got = model.audio_forward(x[None], sr)[0].numpy()
+        want = orc.audio_forward(x.numpy()[None], sr)[0]
+        worst = max(worst, float(np.abs(got - want).max()))
+        mine = [{"start": int(p), "end": int(q)} for p, q in segs[first[j]:first[j + 1]]]
+        same = same and mine == segment_probs(want, int(lens[j]), sr)
+        checked += 1
+    return {"recordings_checked": checked, "one_in": every, "parity_sample_max_abs_dp": worst,
+            "segments_identical_to_oracle_scan": bool(same), "tolerance": 1e-4}
+
+
+def run_corpus(args, rank, world, local, dist, passes):
+    import numpy as np
+    import torch
+    from silero_vad_amd import (PackedRecordings, _lib, gather_to_rank0, load_silero_vad, ragged_speech_segments,
+                                refill_speech_segments)
     from silero_vad_amd import streams as S
     sr = 16000
     dev = torch.device("cuda", local)
-    model = load_silero_vad(device=local, precision=args.precision)
+    node = _lib.lib().vad_bind_host_to_device(local)            # staging threads + pinned buffers on the GPU's NUMA node
+    host_threads = _lib.lib().vad_host_threads()
+    model = load_silero_vad(device=local)
     n = WORK[sr]["chunk"]
-    rng = np.random.default_rng(101 + rank)
+    rng = np.random.default_rng(7)
     base_len = 8 << 20
     tt = np.arange(base_len, dtype=np.float32) / sr
     base = (0.03 * rng.standard_normal(base_len).astype(np.float32)
             + 0.2 * np.sin(2 * np.pi * 170.0 * tt) * (np.sin(2 * np.pi * 0.7 * tt) > 0))
-    base_f = torch.from_numpy(base.astype(np.float32))
-    base_i = torch.from_numpy((base * 32767.0).clip(-32768, 32767).astype(np.int16))
+    base_i_page = torch.from_numpy((base * 32767.0).clip(-32768, 32767).astype(np.int16))
     R = args.recordings
-    lens = rng.integers(20 * sr, 40 * sr, size=R)              # 20-40 s recordings, ragged
-    offs = rng.integers(0, base_len - 40 * sr, size=R)
-    chunks = int(sum((m + n - 1) // n for m in lens))
+    shard = corpus_shard(rank, world, passes, R, sr, base_len)
+    gids = np.concatenate([g for g, _, _ in shard])
+    lens = np.concatenate([l for _, l, _ in shard])
+    offs_rand = np.concatenate([o for _, _, o in shard])        # views into the small pageable signal (the staged leg)
     hours = float(lens.sum()) / sr / 3600.0
-    legs = {}
-    for name, src, sched in (("int16", base_i, "buckets"), ("fp32", base_f, "buckets"), ("int16_refill", base_i, "refill")):
-        audios = [src[o:o + m] for o, m in zip(offs, lens)]    # views: the "files" already decoded in RAM
-        nseg = [0]
-        S.STATS.clear()
+    # The decoder's output arena: page-locked, refilled pass by pass (a ring the size of one pass); the recordings of a pass lie
+    # in it back to back, each starting on a 16-byte boundary.
+    offs = np.zeros(len(lens), dtype=np.int64)
+    span = 0
+    for p in range(passes):
+        sl = slice(sum(len(x[1]) for x in shard[:p]), sum(len(x[1]) for x in shard[:p + 1]))
+        l = lens[sl]
+        o = np.concatenate([[0], np.cumsum((l + 7) // 8 * 8)[:-1]])
+        offs[sl] = o
+        span = max(span, int(o[-1] + l[-1]))
+    arena_len = (span + base_len - 1) // base_len * base_len
+    arena = torch.empty(arena_len, dtype=torch.int16, pin_memory=True)
+    arena.view(-1, base_len)[:] = base_i_page
+    base_i = arena
 
-        def step():
+    def run_leg(src, sched, mode, nrec, keep):
+        """One call over the first `nrec` recordings of this rank's shard: the pipeline (upload of bucket k+1 beside the
+        kernels of bucket k, two compute lanes, scan on the device) fills once and drains once."""
+        os.environ["SILERO_VAD_AMD_UPLOAD"] = mode
+        res = {}
+
+        def one(m):
+            rec = PackedRecordings(src, (offs if src is base_i else offs_rand)[:m], lens[:m])
             if sched == "buckets":      # length-sorted buckets, one lock-step call each, device scan per bucket
-                segs = ragged_speech_segments(audios, model, sr, max_waste=0.1, max_bytes=1 << 30)
-            else:                       # persistent slots refilled at slab boundaries, one device scan at the end
-                segs = refill_speech_segments(audios, model, sr, slots=max(64, R // 2), slab_chunks=64)
-            nseg[0] = sum(len(s) for s in segs)
+                return ragged_speech_segments(rec, model, sr, max_waste=0.1, max_bytes=1 << 30, as_arrays=True)
+            segs = refill_speech_segments(rec, model, sr, slots=2048, slab_chunks=64)   # persistent slots, refilled at slab boundaries
+            return np.asarray([len(x) for x in segs]), None
 
-        step()                                                  # warm-up: pinned buffers, scratch
+        one(min(nrec, 2 * R))                                   # warm-up: pinned buffers, scratch, lanes
         S.STATS.clear()
-        elapsed = timed(world, dist, dev, steps, step, gpu_sync)
+        nseg = []
+
+        # the timed region also holds the host-side gather of the results to rank 0 (north_star: "only a host-side gather
+        # of timestamps"): two compact arrays per rank, one gather_object at the end of the shard
+        def whole():
+            counts, segs = one(nrec)
+            res["counts"], res["segs"] = counts, segs
+            nseg.append(int(counts.sum()))
+            if keep and world > 1:
+                gathered = gather_to_rank0((gids[:nrec], counts, segs))
+                if gathered is not None:
+                    nseg.append(sum(int(g[1].sum()) for g in gathered))
+
+        elapsed = timed(world, dist, dev, 1, whole, gpu_sync)
         st = dict(S.STATS)
-        bytes_in = float(lens.sum()) * (4 if name == "fp32" else 2) * steps
-        legs[name] = {"scheduler": sched, "value": round(chunks * world * steps / elapsed, 1), "unit": "chunks/s", "steps": steps,
-                      "s_per_step": round(elapsed / steps, 4), "segments_found_rank0": nseg[0],
-                      "ingest_GBps_per_gpu": round(bytes_in / elapsed / 1e9, 2),
-                      "h2d_GBps_while_copying": (round(st["h2d_bytes"] / st["h2d_s"] / 1e9, 2) if st.get("h2d_s") else None),
-                      "host_stage_ms_per_step": round(st.get("stage_s", 0) / steps * 1e3, 2),
-                      "host_segmenter_ms_per_step": round(st.get("scan_s", 0) / steps * 1e3, 2),
-                      "d2h_MB_per_step": round(st.get("d2h_bytes", 0) / steps / 1e6, 3),
-                      "buckets_per_step": int(st.get("buckets", 0) / steps),
-                      "padded_over_real_samples": round(st.get("padded", 0) / max(st.get("real", 1), 1), 4),
-                      "projected_10k_hours_s": round(10_000.0 / (hours * world * steps / elapsed), 1)}
-    # what the link allows: the H2D rate measured while copying / bytes per chunk of the leg's sample format -- the leg's
-    # value can approach it (fully overlapped pipeline), never exceed it
-    link = next((l["h2d_GBps_while_copying"] for l in legs.values() if l["h2d_GBps_while_copying"]), None)
-    for name, l in legs.items():
-        gbps = l["h2d_GBps_while_copying"] or link
-        l["pcie_ceiling_chunks_per_s"] = round(gbps * 1e9 / (n * (4 if name == "fp32" else 2)) * world, 1) if gbps else None
-        l["fraction_of_pcie_ceiling"] = round(l["value"] / l["pcie_ceiling_chunks_per_s"], 3) if gbps else None
+        leg_chunks = int(((lens[:nrec] + n - 1) // n).sum())
+        leg_bytes = float(lens[:nrec].sum()) * 2
+        d = {"scheduler": sched, "source": "pinned" if src is base_i else "pageable", "upload": mode,
+             "recordings_per_gpu": int(nrec), "audio_hours_per_gpu": round(float(lens[:nrec].sum()) / sr / 3600.0, 2),
+             "value": round(leg_chunks * world / elapsed, 1), "unit": "chunks/s", "wall_s": round(elapsed, 4),
+             "segments_found_rank0": nseg[0], "segments_gathered_all_ranks": nseg[1] if len(nseg) > 1 else None,
+             "ingest_GBps_per_gpu": round(leg_bytes / elapsed / 1e9, 2),
+             "h2d_GBps_while_copying": (round(st["h2d_bytes"] / st["h2d_s"] / 1e9, 2) if st.get("h2d_s") else None),
+             "host_stage_ms": round(st.get("stage_s", 0) * 1e3, 2),
+             "host_upload_call_ms": round(st.get("upload_call_s", 0) * 1e3, 2),
+             "host_segmenter_ms": round(st.get("scan_s", 0) * 1e3, 2),
+             "d2h_MB": round(st.get("d2h_bytes", 0) / 1e6, 3),
+             "buckets": int(st.get("buckets", 0)),
+             "padded_over_real_samples": round(st.get("padded", 0) / max(st.get("real", 1), 1), 4)}
+        return d, res
+
+    legs = {}
+    main_mode = os.environ.get("VAD_BENCH_CORPUS_UPLOAD", "window")
+    legs["main"], res = run_leg(base_i, "buckets", main_mode, len(lens), True)
+    parity = None
+    if not args.no_parity:
+        parity = corpus_parity_sample(model, gids, lens, offs, base_i, res["counts"], res["segs"], sr)
+    short = min(len(lens), 3 * R)
+    if not args.corpus_main_only:                               # the other ingest routes on 3 passes' worth, for comparison
+        for other in ("window", "gather", "dma"):
+            if other != main_mode:
+                legs[f"pinned_{other}"], _ = run_leg(base_i, "buckets", other, short, False)
+        legs["pageable_staged"], _ = run_leg(base_i_page, "buckets", "stage", short, False)
+        legs["pinned_refill_gather"], _ = run_leg(base_i, "refill", "gather", short, False)
+    os.environ.pop("SILERO_VAD_AMD_UPLOAD", None)
+    # what the link allows: the H2D rate measured while copying / bytes per chunk -- a leg's value can approach it (fully
+    # overlapped pipeline), never exceed it
+    link = max((l["h2d_GBps_while_copying"] or 0) for l in legs.values()) or None
+    for l in legs.values():
+        l["pcie_ceiling_chunks_per_s"] = round(link * 1e9 / (n * 2) * world, 1) if link else None
+        l["fraction_of_pcie_ceiling"] = round(l["value"] / l["pcie_ceiling_chunks_per_s"], 3) if link else None
     if rank != 0:
         return None
-    main = legs["int16"]
-    out = base_line(args, world, sr, main["value"], main["s_per_step"] * steps, steps, args.precision)
-    out["config"] = {"workload": f"configs[3] bounded sample: {R} ragged recordings/GPU (20-40 s, {hours:.2f} h) "
-                                 "in host RAM -> pinned staging -> H2D overlapped with compute -> probs -> "
-                                 "segmenter on the GPU -> segment lists to the host; PCIe- and host-inclusive; main leg int16 "
-                                 "PCM, bucket scheduler",
-                     "recordings_per_gpu": R, "audio_hours_per_gpu_per_step": round(hours, 3), "sample_rate": sr,
-                     "sharding": f"recordings x{world}, no collectives"}
+    main = legs["main"]
+    out = base_line(args, world, sr, main["value"], main["wall_s"], 1)
+    out["ms_per_step"] = round(main["wall_s"] * 1e3, 3)
+    full = abs(hours - CORPUS_HOURS_PER_GPU) / CORPUS_HOURS_PER_GPU < 0.05
+    out["config"] = {"workload": f"configs[3]: {'the full' if full else 'a PARTIAL'} per-GPU shard of the 10 000 h corpus -- "
+                                 f"{passes} x {R} ragged recordings/GPU (20-40 s, {hours:.1f} h of audio per GPU) back to back in a pinned "
+                                 "host arena -> one DMA per 2 GiB arena window -> padded batches cut on the GPU (no host copy) -> probs -> "
+                                 "segmenter on the GPU -> segment lists to the host -> gathered to rank 0; ONE step = the whole shard; "
+                                 "PCIe- and host-inclusive wall time; int16 PCM, bucket scheduler, two compute lanes",
+                     "recordings_per_gpu": int(len(lens)), "audio_hours_per_gpu": round(hours, 2), "sample_rate": sr,
+                     "sharding": f"recordings x{world} by duration (shard_by_duration), no collectives; results gathered to rank 0",
+                     "host_threads_per_rank": host_threads, "numa_node_bound": node}
     out["realtime_factor"] = round(main["value"] * 0.032, 1)
+    out["wall_s"] = main["wall_s"]
+    out["audio_hours_all_gpus"] = round(hours * world, 1)
+    out["ten_k_hours_at_this_rate_s"] = round(10_000.0 / (hours * world / main["wall_s"]), 1)
+    out["parity_sample"] = parity
+    if parity:
+        out["parity_sample_max_abs_dp"] = parity["parity_sample_max_abs_dp"]
     out["legs"] = legs
-    out["projected_10k_hours_s"] = main["projected_10k_hours_s"]
     return out
 
 
-# ---- dry: the launch / reduce / print plumbing without a GPU (tests/test_sharding.py) -------------------------
-def run_dry(args, rank, world, dist):
+# ---- plumbing: the reference's default usage, one chunk per call (configs[0], SURVEY 8d C1) -----------------------------
+def run_plumbing(args, local):
+    """B = 1: what an unmodified caller does -- `model(chunk, sr).item()` once per 32 ms chunk
+    (src/silero_vad/utils_vad.py:324-336, :528; the reference advertises "< 1 ms per chunk", README.md:103)."""
+    import numpy as np
     import torch
+    from silero_vad_amd import Engine, StreamPool, get_speech_timestamps, load_silero_vad
+    sr, n = 16000, 512
+    wav = torch.from_numpy(np.load(ROOT / "tests" / "golden" / "audio_16k.npz")["pcm"].astype(np.float32) / 32768.0)
+    model = load_silero_vad(device=local)
+
+    def med(xs):
+        xs = sorted(xs)
+        return round(xs[len(xs) // 2] * 1e3, 4)
+
+    # (a) eager per-call protocol, host chunk in, float out
+    model.reset_states()
+    lat = []
+    for i in range(60 + 400):
+        c = wav[i * n:(i + 1) * n]
+        t0 = time.perf_counter()
+        model(c, sr).item()
+        lat.append(time.perf_counter() - t0)
+    eager_ms = med(lat[60:])
+    # (b) the same step captured in a hipGraph (StreamPool with one slot), host chunk in, float out
+    pool = StreamPool(Engine(device=local), sr, capacity=1, graph=True)
+    pool.open()
+    lat = []
+    for i in range(60 + 400):
+        c = wav[i * n:(i + 1) * n][None]
+        t0 = time.perf_counter()
+        pool.tick(c).item()
+        lat.append(time.perf_counter() - t0)
+    graph_ms = med(lat[60:])
+    # (c) get_speech_timestamps on the 60 s fixture: the one-call fast path, and the unmodified per-chunk protocol
+    class PerChunk:                                            # hides audio_forward_device: the caller loops over chunks
+        def __init__(self, m):
+            self.m = m
+        def reset_states(self):
+            self.m.reset_states()
+        def __call__(self, x, sr):
+            return self.m(x, sr)
+    t0 = time.perf_counter(); ts_fast = get_speech_timestamps(wav, model, sampling_rate=sr); fast_s = time.perf_counter() - t0
+    t0 = time.perf_counter(); ts_fast = get_speech_timestamps(wav, model, sampling_rate=sr); fast_s = time.perf_counter() - t0
+    t0 = time.perf_counter(); ts_chunk = get_speech_timestamps(wav, PerChunk(model), sampling_rate=sr); chunk_s = time.perf_counter() - t0
+    if len(ts_fast) != 19 or ts_chunk != ts_fast:
+        raise RuntimeError(f"plumbing: expected the reference's 19 segments, got {len(ts_fast)} / {len(ts_chunk)}")
+    chunks = (len(wav) + n - 1) // n
+    return {"workload": "configs[0]: tests/data/test.wav (60 s, 16 kHz) through the reference's per-chunk protocol, B = 1",
+            "per_call_latency_ms": {"eager_model_call_item": eager_ms, "hipgraph_step_item": graph_ms,
+                                    "note": "host chunk in -> float out, median of 400 calls (H2D of the chunk, 2 kernels, D2H of the probability)"},
+            "get_speech_timestamps_60s": {"segments": len(ts_fast), "one_call_fast_path_ms": round(fast_s * 1e3, 2),
+                                          "per_chunk_protocol_ms": round(chunk_s * 1e3, 1), "chunks": chunks,
+                                          "per_chunk_protocol_ms_per_chunk": round(chunk_s * 1e3 / chunks, 4),
+                                          "identical_segments": True},
+            "reference_claim": "< 1 ms per chunk on one CPU thread (README.md:103); measured CPU R1 in cpu_baseline"}
+
+
+# ---- dry: the launch / shard / gather / reduce / print plumbing without a GPU (tests/test_sharding.py) --------------------
+class _DryModel:
+    """No GPU, no oracle: probabilities are a cheap deterministic function of the audio, enough to drive the sharding,
+    the ragged scheduler's CPU branch, the native host scanner and the gather."""
+    def audio_forward_device(self, x, sr):
+        import torch
+        n = 512 if sr == 16000 else 256
+        x = x.to(torch.float32)
+        T = (x.shape[1] + n - 1) // n
+        x = torch.nn.functional.pad(x, (0, T * n - x.shape[1]))
+        return torch.sigmoid(40.0 * x.view(x.shape[0], T, n).abs().mean(-1) - 2.0)
+
+
+def run_dry(args, rank, world, dist):
+    import numpy as np
+    import torch
+    if args.config == "corpus":
+        from silero_vad_amd import gather_to_rank0, ragged_speech_segments
+        sr, R, passes, base_len = 16000, 12, 2, 1 << 20
+        rng = np.random.default_rng(7)
+        base = torch.from_numpy((0.2 * rng.standard_normal(base_len) * (np.sin(np.arange(base_len) / 9000.0) > 0)).astype(np.float32))
+        shard = corpus_shard(rank, world, passes, R, sr, base_len)
+        res = []
+
+        def whole():
+            for _, lens, offs in shard:
+                res.append(ragged_speech_segments([base[o:o + m] for o, m in zip(offs.tolist(), lens.tolist())], _DryModel(), sr,
+                                                  threshold=0.4))
+        elapsed = timed(world, dist, torch.device("cpu"), 1, whole, lambda: None)
+        mine = {int(g): r for (gids, _, _), rr in zip(shard, res) for g, r in zip(gids, rr)}
+        parts = gather_to_rank0(mine)
+        if rank != 0:
+            return None
+        merged = {}
+        for part in parts:
+            merged.update(part)
+        out = base_line(args, world, sr, 0.0, elapsed, 1)
+        out.update({"dry": True, "metric": "dry run (no measurement)", "data": "none (dry run of the corpus sharding / gather plumbing; no GPU work)",
+                    "config": {"workload": "dry corpus", "sharding": f"recordings x{world} by duration, results gathered to rank 0"},
+                    "recordings_total": world * R * passes, "recordings_gathered": len(merged),
+                    "ids_complete": sorted(merged) == list(range(world * R * passes)),
+                    "segments_total": sum(len(v) for v in merged.values())})
+        return out
     acc = [0.0]
 
     def step():
@@ -490,7 +671,7 @@ def run_dry(args, rank, world, dist):
     elapsed = timed(world, dist, torch.device("cpu"), args.steps, step, lambda: None)
     if rank != 0:
         return None
-    out = base_line(args, world, 16000, 0.0, elapsed, args.steps, args.precision)
+    out = base_line(args, world, 16000, 0.0, elapsed, args.steps)
     out.update({"dry": True, "metric": "dry run (no measurement)", "data": "none (dry run of the launch/reduce plumbing; no GPU work, not a measurement)",
                 "config": {"workload": "dry", "sharding": f"streams x{world}, no collectives"}})
     return out
@@ -500,10 +681,14 @@ def small(d):
     """The part of a config's line that is kept when it is nested under other_configs."""
     if d is None:
         return None
-    keep = ("value", "unit", "steps", "ms_per_step", "dtype", "kernel_ms", "tick_latency_ms", "legs",
-            "projected_10k_hours_s", "outputs_finite", "realtime_factor", "timed_region_s")
+    keep = ("value", "unit", "steps", "ms_per_step", "dtype", "kernel_ms", "tick_latency_ms", "legs", "wall_s", "n_gpus",
+            "audio_hours_all_gpus", "ten_k_hours_at_this_rate_s", "parity_sample", "parity_sample_max_abs_dp",
+            "outputs_finite", "realtime_factor", "timed_region_s")
     out = {k: d[k] for k in keep if k in d}
     out["workload"] = d["config"]["workload"]
+    for k in ("sharding", "host_threads_per_rank", "numa_node_bound", "recordings_per_gpu", "audio_hours_per_gpu"):
+        if k in d["config"]:
+            out[k] = d["config"][k]
     if "roofline" in d:
         out["roofline"] = {k: d["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
     return out
@@ -514,19 +699,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["c2", "8k", "stream", "corpus"], default="c2")
-    ap.add_argument("--precision", choices=["fp32", "f16x3"], default="fp32",
-                    help="fp32 (default): exact v_mfma_f32_16x16x4_f32 chain, the reference's arithmetic; "
-                         "f16x3: opt-in fp16x3 split products on the f16 matrix cores (narrower than fp32)")
+    ap.add_argument("--config", choices=["c2", "8k", "stream", "corpus", "plumbing"], default="c2")
     ap.add_argument("--streams", type=int, default=STREAMS, help=argparse.SUPPRESS)
     ap.add_argument("--chunks", type=int, default=CHUNKS_PER_STREAM, help=argparse.SUPPRESS)
     ap.add_argument("--live", type=int, default=LIVE_STREAMS, help=argparse.SUPPRESS)
-    ap.add_argument("--recordings", type=int, default=4096, help=argparse.SUPPRESS)
+    ap.add_argument("--recordings", type=int, default=CORPUS_PASS, help=argparse.SUPPRESS)
+    ap.add_argument("--corpus-passes", type=int, default=37, help="corpus: passes of --recordings per GPU (37 x 4096 x 30 s = 1 250 h)")
+    ap.add_argument("--corpus-main-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-parity", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-extras", action="store_true", help="N=1: skip other_precision / other_configs")
-    ap.add_argument("--dry", action="store_true", help="no GPU: exercise launch/barrier/reduce/print only (gloo)")
+    ap.add_argument("--no-extras", action="store_true", help="skip other_configs")
+    ap.add_argument("--dry", action="store_true", help="no GPU: exercise launch/shard/gather/barrier/reduce/print only (gloo)")
     args = ap.parse_args()
-    default_steps = {"c2": 200, "8k": 200, "stream": 2000, "corpus": 2}
+    default_steps = {"c2": 200, "8k": 200, "stream": 2000, "corpus": 1, "plumbing": 1}   # corpus: one step = the whole shard
     if args.steps is None:
         args.steps = default_steps[args.config]
 
@@ -548,24 +733,37 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.set_device(torch.device("cuda", local))
-        extras = world == 1 and not args.no_extras
+        extras = not args.no_extras
         if args.config in ("c2", "8k"):
             sr = 16000 if args.config == "c2" else 8000
-            out = run_batch(args, sr, rank, world, local, dist, args.steps, with_other=extras)
+            out = run_batch(args, sr, rank, world, local, dist, args.steps)
         elif args.config == "stream":
             out = run_stream(args, rank, world, local, dist, args.steps)
+        elif args.config == "corpus":
+            out = run_corpus(args, rank, world, local, dist, args.corpus_passes)
         else:
-            out = run_corpus(args, rank, world, local, dist, max(1, min(args.steps, 3)))
-        if extras and args.config == "c2":              # the other BASELINE configs, short, for the record
+            out = {"metric": "per-call latency (plumbing, no throughput claim)", "value": None, "n_gpus": 1,
+                   "config": {"workload": "configs[0]"}, "plumbing": run_plumbing(args, local)}
+        if extras and args.config == "c2":              # the other BASELINE configs, for the record
             oc = {}
-            for name, fn in (("8k", lambda: run_batch(args, 8000, rank, world, local, dist, 100, with_other=False)),
-                             ("stream", lambda: run_stream(args, rank, world, local, dist, 1000)),
-                             ("corpus", lambda: run_corpus(args, rank, world, local, dist, 1))):
+            legs = [("stream", lambda: run_stream(args, rank, world, local, dist, 1000)),
+                    ("corpus", lambda: run_corpus(args, rank, world, local, dist, args.corpus_passes))]
+            if world == 1:
+                legs = [("8k", lambda: run_batch(args, 8000, rank, world, local, dist, 100))] + legs + \
+                       [("plumbing", lambda: {"config": {"workload": "configs[0]"}, **run_plumbing(args, local)})]
+            for name, fn in legs:
+                if world > 1:                           # every rank takes part in a leg's barriers: no swallowing of errors there
+                    r = fn()
+                    if rank == 0:
+                        oc[name] = small(r)
+                    continue
                 try:
-                    oc[name] = small(fn())
+                    r = fn()
+                    oc[name] = r if name == "plumbing" else small(r)
                 except Exception as e:                  # an extra must never cost the headline line
                     oc[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            out["other_configs"] = oc
+            if rank == 0:
+                out["other_configs"] = oc
 
     if rank == 0:
         if cpu is not None:

@@ -198,6 +198,9 @@ int  vad_stage_rows(const void *const *rows, const long *lens, long n, long widt
  *   how = 0  copy engines: one H2D DMA per row (any alignment, no CU time) behind one fill of the batch
  *   how = 1  one gather kernel that reads the rows over PCIe and writes the padded batch (kernel_ingest.hip): a single
  *            launch for any number of rows -- what the continuous-refill scheduler needs (thousands of short rows per slab)
+ *   how = 2  rows[] are DEVICE addresses: the recordings were brought over packed, by one large DMA of the arena range
+ *            that holds them, and are scattered into the padded batch at HBM speed (the route streams.py takes for a
+ *            PackedRecordings whose recordings lie back to back: PCIe carries exactly the live bytes, in big copies)
  * For pageable sources use vad_stage_rows + one copy instead.                                                          */
 int  vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, long n, long width, size_t elem_size,
                      void *dst, int how, void *stream);

@@ -78,7 +78,7 @@ struct RowDesc {
     const void *ptr;
     long len;
 };
-hipError_t launch_gather_rows(const RowDesc *rows, long n, long width, int esz, void *dst, hipStream_t s);
+hipError_t launch_gather_rows(const RowDesc *rows, long n, long width, int esz, void *dst, bool rows_on_device, hipStream_t s);
 
 // Segmenter on the device (kernel_scan.hip): lane i scans probs[i * ldp ...] (or probs[row_off[i] ...] if row_off is
 // not null), n_chunks[i] entries (or n_chunks_all if n_chunks is null), writes its segments to out[i * cap ...] and

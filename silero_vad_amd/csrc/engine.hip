@@ -692,7 +692,7 @@ int vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, lo
                     void *dst, int how, void *stream_v) {
     if (!e) return VAD_ERR_ARG;
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
-    if (n < 0 || width < 0 || (elem_size != 2 && elem_size != 4) || (how != 0 && how != 1))
+    if (n < 0 || width < 0 || (elem_size != 2 && elem_size != 4) || how < 0 || how > 2)
         return fail(e, VAD_ERR_ARG, "bad argument");
     if (n == 0 || width == 0) return VAD_OK;
     if (!rows || !lens || !dst) return fail(e, VAD_ERR_ARG, "null pointer");
@@ -728,7 +728,7 @@ int vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, lo
     }
     if (!e->tab_ev[slot]) HIP_TRY(e, hipEventCreateWithFlags(&e->tab_ev[slot], hipEventDisableTiming));
     for (long i = 0; i < n; ++i) e->h_tab[slot][i] = vad::RowDesc{lens[i] ? device_view(rows[i]) : nullptr, lens[i]};
-    HIP_TRY(e, vad::launch_gather_rows(e->h_tab[slot], n, width, (int)elem_size, dst, stream));
+    HIP_TRY(e, vad::launch_gather_rows(e->h_tab[slot], n, width, (int)elem_size, dst, how == 2, stream));
     HIP_TRY(e, hipEventRecord(e->tab_ev[slot], stream));
     e->tab_busy[slot] = true;
     return VAD_OK;

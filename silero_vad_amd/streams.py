@@ -146,12 +146,93 @@ def _compute_lanes(model, want):
     return lanes
 
 
+class PackedRecordings:
+    """Many recordings inside ONE host tensor -- a decoder's output arena, a memory-mapped shard: recording i is
+    `base[offsets[i] : offsets[i] + lengths[i]]`.  Accepted wherever the corpus functions take a list of recordings; it
+    spares the per-recording Python work (150 000 tensor views cost more host time than their audio costs GPU time) and,
+    when `base` is pinned, the whole set is one page-locked source for `vad_upload_rows`."""
+
+    def __init__(self, base: torch.Tensor, offsets, lengths):
+        if base.dim() != 1 or base.is_cuda or not base.is_contiguous() or base.dtype not in (torch.int16, torch.float32):
+            raise ValueError("base must be a contiguous 1-D CPU tensor of int16 or float32 samples")
+        self.base = base
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+        if self.offsets.shape != self.lengths.shape or self.offsets.ndim != 1:
+            raise ValueError("offsets and lengths need one entry per recording")
+        if len(self.offsets) and (self.offsets.min() < 0 or self.lengths.min() < 0
+                                  or int((self.offsets + self.lengths).max()) > base.numel()):
+            raise ValueError("a recording lies outside base")
+
+    def __len__(self):
+        return len(self.offsets)
+
+    def __getitem__(self, i):
+        o, m = int(self.offsets[i]), int(self.lengths[i])
+        return self.base[o:o + m]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def windows(self, max_bytes: int):
+        """Index ranges [lo, hi) of recordings that lie in arena order without overlap and whose span (first sample of the
+        first .. last sample of the last) is at most `max_bytes`: each can be brought to the GPU by ONE copy."""
+        esz = self.base.element_size()
+        out, n = [], len(self)
+        lo = 0
+        end = self.offsets + self.lengths
+        while lo < n:
+            hi = lo + 1
+            while hi < n and self.offsets[hi] >= end[hi - 1] and (end[hi] - self.offsets[lo]) * esz <= max_bytes:
+                hi += 1
+            out.append((lo, hi))
+            lo = hi
+        return out
+
+
+class WindowedPlan:
+    """RaggedPlan per arena window: the recordings of a window (PackedRecordings.windows) are bucketed among themselves, so
+    that a bucket's rows all come from one contiguous arena range that a single DMA has brought to the GPU."""
+
+    def __init__(self, rec: PackedRecordings, max_waste, max_bytes, itemsize, window_bytes):
+        self.lengths = rec.lengths.tolist()
+        self.windows = rec.windows(window_bytes)
+        self.buckets, self.window_of = [], []
+        self.empty = [i for i, m in enumerate(self.lengths) if m <= 0]
+        for w, (lo, hi) in enumerate(self.windows):
+            sub = RaggedPlan(self.lengths[lo:hi], max_waste, max_bytes, itemsize)
+            for b in sub.buckets:
+                self.buckets.append([lo + i for i in b])
+                self.window_of.append(w)
+        self.span = [(int(rec.offsets[lo]), int(rec.offsets[hi - 1] + rec.lengths[hi - 1])) for lo, hi in self.windows]
+
+    def mean_window_fill(self):
+        return float(np.mean([hi - lo for lo, hi in self.windows])) if self.windows else 0.0
+
+
+def _describe(audios):
+    """(is int16, lengths as a list of ints) of a list of recordings or a PackedRecordings."""
+    if isinstance(audios, PackedRecordings):
+        return audios.base.dtype == torch.int16, audios.lengths.tolist()
+    as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
+    return as_i16, [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
+
+
 class _Sources:
     """The recordings of one call as flat arrays: host address and length of each, made contiguous / of one dtype once,
     and whether ALL of them sit in page-locked memory (then no host-side copy is needed at all)."""
 
     def __init__(self, audios, dtype, check_pinned):
         n = len(audios)
+        if isinstance(audios, PackedRecordings):
+            if audios.base.dtype != dtype:
+                raise TypeError("mixed int16 / float recordings in one call")
+            self.keep = [audios.base]
+            self.len = audios.lengths
+            self.ptr = (audios.base.data_ptr() + audios.offsets * audios.base.element_size()).astype(np.uint64)
+            self.ptr[self.len == 0] = 0
+            self.pinned = bool(check_pinned and n > 0 and audios.base.is_pinned())
+            return
         self.keep = []
         self.ptr = np.zeros(n, dtype=np.uint64)
         self.len = np.zeros(n, dtype=np.int64)
@@ -184,8 +265,9 @@ class _Sources:
 
 
 def _upload_mode():
-    """How pinned recordings reach the GPU: "dma" (copy engines, one per row), "gather" (one kernel that reads host
-    memory), "stage" (force the pageable path).  SILERO_VAD_AMD_UPLOAD overrides the per-scheduler default."""
+    """How pinned recordings reach the GPU: "window" (a PackedRecordings whose recordings lie back to back: one DMA per arena
+    window, batches cut on the device; the default where it applies), "gather" (one kernel that reads host memory; the default
+    otherwise), "dma" (copy engines, one copy per row), "stage" (force the pageable path).  SILERO_VAD_AMD_UPLOAD overrides."""
     import os
     return os.environ.get("SILERO_VAD_AMD_UPLOAD", "")
 
@@ -214,15 +296,21 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     Ingest: recordings in pinned host memory go straight to the device batch (vad_upload_rows: no host copy);
     pageable ones are packed into pinned staging by the native threaded copy and copied from there."""
     n = chunk_size(sampling_rate)
-    as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
+    as_i16, lengths = _describe(audios)
     dtype = torch.int16 if as_i16 else torch.float32
     esz = 2 if as_i16 else 4
-    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
-    plan = plan or RaggedPlan(lengths, max_waste, max_bytes, esz)
     fast = model.audio_forward_device
     dev = getattr(model, "device", None)
     on_gpu = dev is not None and torch.device(dev).type == "cuda"
     mode = _upload_mode()
+    if plan is None and on_gpu and mode in ("", "window") and isinstance(audios, PackedRecordings) and audios.base.is_pinned() \
+            and hasattr(getattr(model, "engine", None), "upload_rows"):
+        import os
+        wbytes = int(os.environ.get("SILERO_VAD_AMD_WINDOW_BYTES", 0)) or max(2 * max_bytes, 1 << 30)
+        wp = WindowedPlan(audios, max_waste, max_bytes, esz, window_bytes=wbytes)
+        if mode == "window" or wp.mean_window_fill() >= 64:   # the recordings really lie back to back: one DMA per window
+            plan = wp
+    plan = plan or RaggedPlan(lengths, max_waste, max_bytes, esz)
     src = _Sources(audios, dtype, check_pinned=on_gpu and mode != "stage" and hasattr(getattr(model, "engine", None), "upload_rows"))
     if not on_gpu:                                        # CPU stand-in models (tests)
         for idxs in plan.buckets:
@@ -237,7 +325,41 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         pool = model._stage_pool = _StagePool(dev, len(lane_list) + 1)
     cur = torch.cuda.current_stream(dev)
     direct = src.pinned
-    how = 1 if mode == "gather" else 0
+    how = 0 if mode == "dma" else 1
+    windowed = direct and isinstance(plan, WindowedPlan)
+    if windowed:
+        # One large H2D DMA per arena window (copy engines: no CU time, no host time, exactly the live bytes), two windows
+        # ahead of the kernels; the padded [rows][pitch] batches are then cut out of the window's device copy at HBM speed.
+        win = {"buf": [None, None, None], "free": [None, None, None], "ev": {}, "next": 0,
+               "stream": getattr(pool, "copy_stream", None) or torch.cuda.Stream(dev)}
+        pool.copy_stream = win["stream"]
+        last_bucket_of = {}
+        for k, w in enumerate(plan.window_of):
+            last_bucket_of[w] = k
+        base_t = audios.base
+
+        def ensure_window(w):
+            while win["next"] <= w and win["next"] < len(plan.span):
+                v = win["next"]
+                a, b = plan.span[v]
+                j = v % 3
+                nb = (b - a) * esz
+                if win["buf"][j] is None or win["buf"][j].numel() < nb:
+                    with torch.cuda.stream(win["stream"]):
+                        win["buf"][j] = torch.empty(max(nb, 1 << 20), dtype=torch.uint8, device=dev)
+                    win["free"][j] = None
+                if win["free"][j] is not None:                # every bucket cut from the buffer's previous window is done
+                    win["stream"].wait_event(win["free"][j])
+                with torch.cuda.stream(win["stream"]):
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(win["stream"])
+                    win["buf"][j][:nb].view(dtype).copy_(base_t[a:b], non_blocking=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(win["stream"])
+                copies.append((e0, e1))
+                STATS["h2d_bytes"] += nb
+                win["ev"][v] = e1
+                win["next"] += 1
     align = 16 // esz                                      # device rows are 16-byte aligned: the kernels' vector loads
     # every lane's scratch is sized up front for the largest bucket it can meet: a growth inside the loop would
     # synchronise the device and stall all lanes (vad_reserve)
@@ -259,7 +381,8 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         width = (L + align - 1) // align * align          # row pitch
         nbytes = len(idxs) * width * esz
         i = pool.get(k, nbytes if not direct else 0, nbytes)
-        STATS["h2d_bytes"] += nbytes
+        if not windowed:
+            STATS["h2d_bytes"] += nbytes
         STATS["buckets"] += 1
         STATS["padded"] += len(idxs) * L
         STATS["real"] += sum(plan.lengths[j] for j in idxs)
@@ -276,10 +399,24 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             host = pool.host[i][:nbytes].view(dtype).view(len(idxs), width)
             _stage_into(src, idxs, width, host)
             STATS["stage_s"] += time.perf_counter() - t0
+        if windowed:
+            w = plan.window_of[k]
+            ensure_window(w + 2)                          # this bucket's window and the two after it are on their way
+            pool.stream.wait_event(win["ev"][w])
+            a0 = plan.span[w][0]
+            rows = np.ascontiguousarray(win["buf"][w % 3].data_ptr() + (audios.offsets[idxs] - a0) * esz, dtype=np.uint64)
+            lens = np.ascontiguousarray(src.len[idxs])
         with torch.cuda.stream(pool.stream):
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record(pool.stream)
-            if direct:
+            if windowed:
+                model.engine.upload_rows(rows.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p)),
+                                         lens.ctypes.data_as(ctypes.POINTER(ctypes.c_long)), len(idxs), width, esz, d, 2)
+                if last_bucket_of[w] == k:                # the window's buffer may take another window once this cut is done
+                    win["free"][w % 3] = torch.cuda.Event()
+                    win["free"][w % 3].record(pool.stream)
+                STATS["upload_call_s"] += time.perf_counter() - t0
+            elif direct:
                 tabs = src.tables(idxs)
                 model.engine.upload_rows(tabs[2], tabs[3], len(idxs), width, esz, d, how)
                 STATS["upload_call_s"] += time.perf_counter() - t0
@@ -288,7 +425,8 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             m_dev = m_host.to(dev, non_blocking=True) if m_host is not None else None
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(pool.stream)
-        copies.append((ev0, ev))
+        if not windowed:
+            copies.append((ev0, ev))
         pool.done[i] = ev
         return d[:, :L], ev, i, m_dev, m_host
 
@@ -350,7 +488,7 @@ def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste:
     tensors in [-1, 1] or int16 PCM (all of one kind).  `model` needs ``audio_forward_device``
     (HipSileroVAD); staging + H2D of bucket k+1 overlap the kernels of bucket k."""
     n = chunk_size(sampling_rate)
-    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
+    lengths = _describe(audios)[1]
     out: List[torch.Tensor] = [torch.empty(0)] * len(audios)
     for idxs, probs in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes, plan):
         for row, i in enumerate(idxs):
@@ -360,27 +498,32 @@ def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste:
 
 def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
                            max_bytes: int = 256 << 20, threads: int = 0, device_scan: bool = None,
-                           **scan_kw) -> List[list]:
+                           as_arrays: bool = False, **scan_kw) -> List[list]:
     """Speech segments (sample indices) of many recordings: bucketed GPU batches, then the segmenter.
-    scan_kw: the threshold/duration arguments of get_speech_timestamps.
+    scan_kw: the threshold/duration arguments of get_speech_timestamps.  `audios`: a list of 1-D tensors or a
+    PackedRecordings.  as_arrays: return (counts int64[n], segments int64[sum(counts), 2]) -- recording i owns rows
+    cumsum(counts)[i-1] .. -- instead of a list of lists of dicts (for corpora of 10^5+ recordings the dicts cost more
+    host time than the GPU work; the arrays are also what a host-side gather to rank 0 wants).
 
     device_scan (default: on for a GPU model backed by the native engine): the scan runs on the GPU right behind the
     kernels of its bucket (vad_segment_probs_device, one lane per recording) and only counts + segment lists come
     back over PCIe; otherwise the probabilities are copied to the host and scanned by the native threaded scanner.
     Both give the same segments (one source, csrc/scanner.hpp)."""
     n = chunk_size(sampling_rate)
-    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
-    out: List[list] = [[] for _ in audios]
+    lengths = _describe(audios)[1]
     dev = getattr(model, "device", None)
     on_gpu = dev is not None and torch.device(dev).type == "cuda"
     if device_scan is None:
         device_scan = on_gpu and hasattr(getattr(model, "engine", None), "_h")
+    counts_all = np.zeros(len(lengths), dtype=np.int64)
+    parts = []                                                 # (indices, counts, segs[rows, cap, 2]) per bucket
     if device_scan:
         params = _segment_params(sampling_rate, **scan_kw)
         cap0 = 24                                              # segments per recording copied back optimistically
+        lens_t = torch.as_tensor(lengths, dtype=torch.int64)
 
         def meta(idxs):                                        # [2, n]: chunks and samples of each recording of the bucket
-            lens = torch.tensor([lengths[i] for i in idxs], dtype=torch.int64)
+            lens = lens_t[idxs]
             return torch.stack([(lens + n - 1) // n, lens])
 
         def post(probs_dev, idxs, both):
@@ -392,24 +535,40 @@ def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
             t0 = time.perf_counter()
             cnt = counts.numpy()
             if len(cnt) and int(cnt.max()) > cap0:             # rare: rescan this bucket with room for all
-                lens = torch.tensor([lengths[i] for i in idxs], dtype=torch.int64)
-                both = torch.stack([(lens + n - 1) // n, lens]).to(probs_dev.device)
+                both = meta(idxs).to(probs_dev.device)
                 c2, s2 = _device_scan(model.engine, probs_dev, both[0], both[1], params, int(cnt.max()))
                 cnt, segs = c2.cpu().numpy(), s2.cpu()
-            sg = segs.numpy()
-            for row, i in enumerate(idxs):
-                out[i] = [{"start": int(a), "end": int(b)} for a, b in sg[row, : cnt[row]]]
+            parts.append((np.asarray(idxs, dtype=np.int64), cnt.copy(), segs.numpy()))
             STATS["scan_s"] += time.perf_counter() - t0
-        return out
-    for idxs, probs in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes):
-        lens = [lengths[i] for i in idxs]
-        t0 = time.perf_counter()
-        segs = segment_probs_batch(probs, [(m + n - 1) // n for m in lens], lens, sampling_rate,
-                                   threads=threads, **scan_kw)
-        STATS["scan_s"] += time.perf_counter() - t0
-        for row, i in enumerate(idxs):
-            out[i] = segs[row]
-    return out
+    else:
+        for idxs, probs in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes):
+            lens = [lengths[i] for i in idxs]
+            t0 = time.perf_counter()
+            segs = segment_probs_batch(probs, [(m + n - 1) // n for m in lens], lens, sampling_rate,
+                                       threads=threads, **scan_kw)
+            cnt = np.asarray([len(sg) for sg in segs], dtype=np.int64)
+            arr = np.zeros((len(segs), max(1, int(cnt.max()) if len(cnt) else 1), 2), dtype=np.int64)
+            for r, sg in enumerate(segs):
+                for k, d in enumerate(sg):
+                    arr[r, k] = (d["start"], d["end"])
+            parts.append((np.asarray(idxs, dtype=np.int64), cnt, arr))
+            STATS["scan_s"] += time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for idxs, cnt, _ in parts:
+        counts_all[idxs] = cnt
+    first = np.concatenate([[0], np.cumsum(counts_all)])
+    flat = np.zeros((int(first[-1]), 2), dtype=np.int64)
+    for idxs, cnt, sg in parts:                                # scatter every bucket's segments to their recording's rows
+        if not len(idxs) or not cnt.any():
+            continue
+        k = np.arange(sg.shape[1])[None, :]
+        mask = k < cnt[:, None]
+        flat[(first[idxs][:, None] + k)[mask]] = sg[mask]
+    STATS["scan_s"] += time.perf_counter() - t0
+    if as_arrays:
+        return counts_all, flat
+    fl = flat.tolist()
+    return [[{"start": a, "end": b} for a, b in fl[first[i]:first[i + 1]]] for i in range(len(lengths))]
 
 
 def _segment_params(sampling_rate=16000, threshold=0.5, neg_threshold=None, min_speech_duration_ms=250,
@@ -575,9 +734,8 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
     eng = model.engine
     dev = torch.device(getattr(eng, "torch_device", None) or torch.device("cuda", eng.device))
     on_gpu = dev.type == "cuda"
-    as_i16 = len(audios) > 0 and all(torch.is_tensor(a) and a.dtype == torch.int16 for a in audios)
+    as_i16, lengths = _describe(audios)
     dtype, esz = (torch.int16, 2) if as_i16 else (torch.float32, 4)
-    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
     slots = max(1, min(int(slots), sum(1 for m in lengths if m > 0)))
     plan = plan or RefillPlan(lengths, slots, slab_chunks, n)
     B, S, width = plan.slots, plan.slab_chunks, plan.slab_chunks * n
@@ -686,7 +844,7 @@ def refill_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
     slab is done one device scan (vad_segment_probs_device with per-recording row offsets) turns them into segment
     lists, which is all that crosses PCIe on the way back."""
     n = chunk_size(sampling_rate)
-    lengths = [int(a.shape[0]) if hasattr(a, "shape") else len(a) for a in audios]
+    lengths = _describe(audios)[1]
     flat, base, plan = refill_probs(audios, model, sampling_rate, slots, slab_chunks, _keep_on_device=True)
     if flat.device.type != "cuda":                                        # CPU stand-in engines (tests)
         probs = [flat[base[i]:base[i + 1]] for i in range(len(audios))]
