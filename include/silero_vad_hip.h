@@ -78,6 +78,10 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *                 (csrc/kernel_front_f43.hip).  The test build libsilero_vad_hip_ab.so (__graft_entry__.build, -DVAD_AB=1)
  *                 also accepts "winograd2" (two F(2,3) tiles, csrc/kernel_front_wino.hip) and "direct" (tap by tap,
  *                 csrc/kernel_front.hip: bitwise the plain fmaf chain over the taps) as A/B forms for the parity tests
+ *   "front"     = "auto" (default) | "throughput" | "latency": the frontend has two forms with bit-identical results --
+ *                 one wave per 16-chunk tile (csrc/kernel_front_f43.hip: tens of thousands of tiles per launch) and one
+ *                 4-wave workgroup per tile (csrc/kernel_front_lat.hip: a stream pool's step, a B = 1 call); "auto" takes
+ *                 the latency form for launches of at most 768 tiles.  The other two values force one form (tests)
  *   "fused_decimation" = "1" (default) | "0": for sr = 32000 and 48000 the fp32 frontend reads every 2nd / 3rd sample
  *                 itself; "0" forces the separate decimation pass that the higher multiples of 16000 use (A/B for tests)
  *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)

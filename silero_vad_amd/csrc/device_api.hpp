@@ -54,6 +54,10 @@ hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s);
 // `wfront` points to the F(4,3) image (layout.hpp w4_* units).  The product's fp32 frontend.
 template <typename PcmT>
 hipError_t launch_front_f43(int sr, const FrontArgs &a, hipStream_t s);
+// The LATENCY form of the same kernel (kernel_front_lat.hip): one workgroup = 4 waves = ONE tile, every layer's output rows
+// split over the waves; bit-identical results.  For launches of a few hundred tiles (one step of a stream pool, a B = 1 call).
+template <typename PcmT>
+hipError_t launch_front_lat(int sr, const FrontArgs &a, hipStream_t s);
 // Same function, encoder 0 as two Winograd F(2,3) tiles over the frame pairs, straight-line code (kernel_front_wino.hip);
 // `wfront` points to the F(2,3) image (layout.hpp w_* units).  A/B form, test builds only (VAD_AB; option enc0=winograd2).
 template <typename PcmT>

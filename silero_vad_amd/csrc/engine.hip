@@ -60,6 +60,8 @@ struct vad_engine {
     int enc0 = 2;                                   // fp32 frontend, encoder 0: 2 Winograd F(4,3) (the product); test builds: 0 direct, 1 F(2,3)
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the frontend's loads (option "fused_decimation")
+    long lat_tiles = 768;                           // launches of at most this many 16-chunk tiles take the latency form of the frontend
+                                                    // (option "front": auto | throughput | latency -> 768 | 0 | LONG_MAX)
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
 
     // scratch (per engine: a clone has its own, so that an engine and its clones may be in flight on different streams)
@@ -259,7 +261,8 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         else if (e->enc0 == 0) HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
         else
 #endif
-        HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
+        if ((long)((B + 15) / 16) * nt <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<PcmT>(sr, fa, stream));
+        else HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
         HIP_TRY(e, vad::launch_rec(sr, ra, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[2], stream));
@@ -444,6 +447,7 @@ int vad_clone(const vad_engine *src, vad_engine **out) {
     e->impl_reference = src->impl_reference;
     e->enc0 = src->enc0;
     e->fused_decimation = src->fused_decimation;
+    e->lat_tiles = src->lat_tiles;
     e->gx_cap = src->gx_cap;
     e->trace = src->trace;
     *out = e;
@@ -473,6 +477,13 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         else return fail(e, VAD_ERR_OPTION, "enc0 must be winograd (the A/B forms winograd2|direct exist only in the test build, "
                                             "libsilero_vad_hip_ab.so)");
 #endif
+        return VAD_OK;
+    }
+    if (n == "front") {                              // which form of the frontend a launch takes (A/B for tests; results are bit-identical)
+        if (v == "auto") e->lat_tiles = 768;
+        else if (v == "throughput") e->lat_tiles = 0;
+        else if (v == "latency") e->lat_tiles = 0x7fffffffL;
+        else return fail(e, VAD_ERR_OPTION, "front must be auto|throughput|latency");
         return VAD_OK;
     }
     if (n == "fused_decimation") {                   // "0": always decimate into scratch first (A/B for tests)
@@ -639,7 +650,8 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     else if (e->enc0 == 0) HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
     else
 #endif
-    HIP_TRY(e, vad::launch_front_f43<float>(sr, fa, stream));
+    if ((long)((B + 15) / 16) * T <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<float>(sr, fa, stream));
+    else HIP_TRY(e, vad::launch_front_f43<float>(sr, fa, stream));
     HIP_TRY(e, vad::launch_unpack_gx(e->d_gx, gx, B, T, stream));
     return VAD_OK;
 }

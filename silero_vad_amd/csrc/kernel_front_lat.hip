@@ -1,0 +1,342 @@
+// kernel_front_lat.hip -- the LATENCY form of the fp32 frontend: the same function as kernel_front_f43.hip
+//   PCM -> framing + right reflect pad -> Hann window -> 4 x real FFT magnitude -> 4 x ReLU(Conv1d k=3)
+//       -> W_ih * feat + (b_ih + b_hh)  => gx
+// and the same arithmetic, bit for bit, for launches that are too small to fill the chip the throughput way.
+// (reference: JIT!/vad/model/vad_annotator.py:58-67 framing, JIT!/vad/utils/pytorch_stft.py:17-34 STFT,
+//  JIT!/vad/utils/model_utils.py:19-25 encoder, the W_ih half of aten::lstm_cell JIT!/torch/nn/modules/rnn.py:69.)
+//
+// Why.  kernel_front_f43.hip gives one 16-chunk tile to ONE wave, which walks the whole 54-unit weight program on its own:
+// 3 456 MFMAs x 32 cycles + the FFT = 135 k cycles = 56 us at best, 90 us in practice with one wave per SIMD.  With tens
+// of thousands of tiles that is the right shape (two waves per SIMD interleave, four tiles share one weight stream).  One
+// step of 8 192 live streams (BASELINE configs[4]) is 512 tiles, a `model(chunk, sr)` call of an unmodified caller is ONE
+// (src/silero_vad/utils_vad.py:328, :528): three quarters of the chip's SIMDs idle while the rest take 90 us.
+//
+// How.  One workgroup = 4 waves = ONE tile; the output rows of every layer are split over the 4 waves (encoder 0: 32 of its
+// 128 rows each -- a "row part" of the F(4,3) program at 16 kHz --, encoder 1 and 2: one 16-row block each, encoder 3: two,
+// W_ih: one LSTM gate each), so a wave issues 864 MFMAs instead of 3 456.  Between layers the activations (the next layer's
+// B operand) are exchanged through LDS in MFMA D-fragment order -- which IS the B-operand order of the chain layout
+// (layout.hpp), so a lane reads back exactly the 16 bytes another lane of the same (g, j) wrote -- and each wave sums over
+// ALL input channels in the order the one-wave program does: same products, same order per accumulator, identical bits
+// (tests/test_gpu_parity.py::test_latency_frontend_is_bit_identical).  The 4 STFT frames are split the same way: wave v
+// transforms frame v, the magnitudes are exchanged through LDS.
+//   One workgroup per CU (launch bound 256 x 1): with a single wave per SIMD there is nobody to hide latency, so the A
+// fragments do not go through an LDS ring and its barriers; each wave streams exactly the blocks it needs from the L2-resident
+// image straight into registers, kD = 8 blocks (32 MFMAs, ~1 000 cycles) ahead -- there are 512 VGPRs per lane to do it in.
+#include <hip/hip_runtime.h>
+
+#include "front_common.hpp"
+
+namespace vad {
+namespace {
+
+constexpr int kD = 8;                    // A-fragment prefetch distance, in 1 KiB blocks (one block = 4 MFMAs)
+#define IC(x) (decltype(x)::value)      // the value of an integral_constant argument, as a constant expression
+
+struct Pipe {
+    f32x4 q[kD];
+};
+
+__device__ __forceinline__ f32x4 ld_blk(const float *lane_base, long blk) {      // lane_base already holds lane * 4
+    return *reinterpret_cast<const f32x4 *>(lane_base + blk * 256);
+}
+
+// One segment of a wave's program: NB blocks consumed in order, NBS consecutive blocks form a step that shares its four
+// B operands (bvec(step)); block i accumulates into acc(i).  load(i) requests this segment's block i, next(j) the first kD
+// blocks of the segment that follows, so that the stream never restarts cold.
+template <int NB, int NBS, class AccF, class BF, class LoadF, class NextF>
+__device__ __forceinline__ void run_segment(Pipe &pp, AccF acc, BF bvec, LoadF load, NextF next) {
+    static_assert(NB % kD == 0 && NB % NBS == 0, "segments are whole FIFO turns");
+    static_for<0, NB / NBS>([&](auto sc) VAD_INLINE {
+        constexpr int st = decltype(sc)::value;
+        f32x4 a[NBS];
+        static_for<0, NBS>([&](auto bc) VAD_INLINE {
+            constexpr int b = decltype(bc)::value, i = st * NBS + b;
+            a[b] = pp.q[i % kD];
+            if constexpr (i + kD < NB) pp.q[i % kD] = load(std::integral_constant<int, i + kD>{});
+            else pp.q[i % kD] = next(std::integral_constant<int, i + kD - NB>{});
+        });
+        const f32x4 bv = bvec(std::integral_constant<int, st>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            static_for<0, NBS>([&](auto bc) VAD_INLINE {
+                constexpr int b = decltype(bc)::value;
+                f32x4 &c = acc(std::integral_constant<int, st * NBS + b>{});
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][ks], bv[ks], c, 0, 0, 0);
+            });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// ---- encoder 1's program for one output row block: 40 blocks = 10 units x 4 k-groups, in the order the one-wave program
+// accumulates them (kernel_front_f43.hip, "encoder 1 fed part by part"; layout.hpp w4_e1) -------------------------------------
+struct E1Blk {
+    int unit, kg, acc, frame, rbg;       // image unit, k-group, 0: out 0 (Z0) 1: out 1 (Z1), STFT frame and global row block of the B operand
+};
+constexpr E1Blk e1_blk(int Q, int idx) {
+    const int n = idx / 4, kg = idx % 4;
+    if (Q == 32) {
+        // per part: [tap1 <- y0 | tap2 <- y1] -> out 0, [tap0 <- y1 | tap1 <- y2] -> out 1, and after every odd part
+        // [tap2 <- y3 of part p-1 | tap2 <- y3 of part p] -> out 1; k-groups 0, 1 carry the first tensor's two row blocks
+        const int parts[10] = {0, 0, 1, 1, 1, 2, 2, 3, 3, 3}, us[10] = {0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
+        const int p = parts[n], u = us[n], first = kg < 2;
+        const int frame = u == 0 ? (first ? 0 : 1) : u == 1 ? (first ? 1 : 2) : 3;
+        const int src = u == 2 ? (first ? p - 1 : p) : p;
+        return E1Blk{vadl::w4_e1(p, u, 32), kg, u == 0 ? 0 : 1, frame, 2 * src + (kg & 1)};
+    }
+    // 8 kHz: per part tap1 <- y0, tap2 <- y1 (out 0); tap0 <- y1, tap1 <- y2, tap2 <- y3 (out 1); k-group = the part's row block
+    const int p = n / 5, u = n % 5;
+    const int fr[5] = {0, 1, 1, 2, 3}, ac[5] = {0, 0, 1, 1, 1};
+    return E1Blk{vadl::w4_e1(p, u, 16), kg, ac[u], fr[u], 4 * p + kg};
+}
+
+template <int Q, typename PcmT, int DEC>
+__global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
+    using namespace vadl;
+    constexpr Tab tb = make_tab(8 * Q, Q);
+    constexpr int TABF = (tb.total + 3) / 4 * 4;
+    constexpr int RB = w_rb(Q), KG0 = Q / 4, T0 = w4_tail0(Q);
+    constexpr int NB0 = 2 * KG0;                                 // blocks of one encoder-0 matrix for one wave (2 row blocks)
+    static_assert(NB0 % kD == 0, "encoder-0 segments are whole FIFO turns");
+    __shared__ __attribute__((aligned(16))) float tab[TABF];
+    __shared__ float xs[4][Q + 1][64];                           // STFT magnitudes, frame v by wave v
+    __shared__ __attribute__((aligned(16))) float ybuf[4][8][256];   // encoder 0: [frame][row block][lane][4]
+    __shared__ __attribute__((aligned(16))) float zbuf[2][4][256];   // encoder 1: [out][row block][lane][4]
+    __shared__ __attribute__((aligned(16))) float vbuf[4][256];      // encoder 2
+    __shared__ __attribute__((aligned(16))) float febuf[8][256];     // encoder 3
+
+    Lane ln;
+    ln.lane = threadIdx.x & 63;
+    ln.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    ln.g = ln.lane >> 4;
+    ln.j = ln.lane & 15;
+    const int w = ln.wave;
+    const long wt = blockIdx.x;                                  // one tile per workgroup (grid = tiles)
+    ln.tile_valid = true;
+    ln.tl = wt % a.nt;
+    ln.st = wt / a.nt;
+    ln.t = a.t0 + ln.tl;
+    const long bb = ln.st * 16 + ln.j;
+    ln.b = (int)(bb < a.B ? bb : a.B - 1);
+    ln.from_tail = a.tail != nullptr && ln.t == a.T - 1;
+    ln.sgnA = ln.g < 2 ? 1.f : -1.f;
+    ln.sgnB = (ln.g & 1) ? -1.f : 1.f;
+
+    // this wave's slice of encoder 0: rows 32 w .. 32 w + 31 = row blocks rb0, rb0 + 1 of row part `part`
+    const int part = Q == 32 ? w : (w >> 1), rb0 = Q == 32 ? 0 : 2 * (w & 1);
+    const int u_e0 = part == 0 ? w4_part0(0, Q) : part == 1 ? w4_part0(1, Q) : part == 2 ? w4_part0(2, Q) : w4_part0(3, Q);
+    const float *lane_w = a.wfront + ln.lane * 4;
+    const float *e0 = lane_w + (size_t)u_e0 * 4096 + rb0 * 256;              // + j * 4096 + (kg * RB + r) * 256
+    auto e0_load = [&](int j, int i) VAD_INLINE { return ld_blk(e0, (long)j * 16 + (i >> 1) * RB + (i & 1)); };
+
+    Pipe pp;
+#pragma unroll
+    for (int i = 0; i < kD; ++i) pp.q[i] = e0_load(0, i);        // the stream starts while the FFT runs
+
+    {   // tables -> LDS: all loads of a thread are issued before the first is stored
+        static_assert(tb.total % 4 == 0, "tables are copied as 16-byte vectors");
+        constexpr int NV = tb.total / 4, PER = (NV + 255) / 256;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.tables);
+        f32x4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            v[k] = src[i < NV ? i : NV - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < NV) reinterpret_cast<f32x4 *>(tab)[i] = v[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- STFT: wave v transforms frame v; everybody reads all four ------------------------------------------------------------
+    float X0[Q + 1], X1[Q + 1], X2[Q + 1], X3[Q + 1];
+    {
+        float Xm[Q + 1];
+        fft_frame<Q, PcmT, DEC>(Xm, w, a, tab, ln);
+#pragma unroll
+        for (int k = 0; k <= Q; ++k) xs[w][k][ln.lane] = Xm[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k <= Q; ++k) {
+        X0[k] = xs[0][k][ln.lane];
+        X1[k] = xs[1][k][ln.lane];
+        X2[k] = xs[2][k][ln.lane];
+        X3[k] = xs[3][k][ln.lane];
+    }
+    // |Y_nyq| of chunk j lives in lane group 0 (X[Q]); every lane of the chunk needs it
+    const float xn0 = __shfl(X0[Q], ln.j), xn1 = __shfl(X1[Q], ln.j), xn2 = __shfl(X2[Q], ln.j), xn3 = __shfl(X3[Q], ln.j);
+    // the F(4,3) input transform reads the frames through E = x3 - x1 and F = x2 - x0 (kept in place of x3 and x0)
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        X3[k] = X3[k] - X1[k];
+        X0[k] = X2[k] - X0[k];
+    }
+
+    // ---- encoder 0, this wave's 32 rows: one F(4,3) tile (kernel_front_f43.hip has the algebra) -------------------------------
+    {
+        const int row0 = 32 * w;
+        const float *wn = tab + tb.w_nyq + row0;                 // [tap][row]
+        f32x4 Y0[2], Y1[2], Y2[2], Y3[2];
+        init_bias<2>(Y0, tab + tb.b_e0 + row0, ln);
+        zero<2>(Y1);
+        zero<2>(Y2);
+        zero<2>(Y3);
+        auto seg0 = [&](auto jc, f32x4 (&Y)[2], auto bfun) VAD_INLINE {
+            constexpr int j = decltype(jc)::value;
+            run_segment<NB0, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Y[IC(i) & 1]; },
+                                [&](auto kg) VAD_INLINE {
+                                    return f32x4{bfun(4 * IC(kg)), bfun(4 * IC(kg) + 1), bfun(4 * IC(kg) + 2), bfun(4 * IC(kg) + 3)}; },
+                                [&](auto i) VAD_INLINE { return e0_load(j, IC(i)); },
+                                [&](auto i) VAD_INLINE { return e0_load(j + 1, IC(i)); });
+        };
+        {   const Coef k = opaque_coef<kF4, kFm3>();
+            seg0(std::integral_constant<int, 0>{}, Y0, [&](int s) VAD_INLINE {
+                return fmaf(fmaf(X2[s], k.p1, X1[s]), k.b, fmaf(X0[s], k.a, X3[s])); });                  // (E + 4F) - 3(x1 + x2)
+            const Coef k2 = opaque_coef<kFm4, kF3>();
+            seg0(std::integral_constant<int, 1>{}, Y1, [&](int s) VAD_INLINE {
+                return fmaf(fmaf(X1[s], k2.m1, X2[s]), k2.b, fmaf(X0[s], k2.a, X3[s])); });               // (E - 4F) + 3(x2 - x1)
+        }
+        {   const Coef k = opaque_coef<kF2, kFm2>();
+            seg0(std::integral_constant<int, 2>{}, Y2, [&](int s) VAD_INLINE { return fmaf(X0[s], k.a, X3[s]); });   // E + 2F
+            seg0(std::integral_constant<int, 3>{}, Y3, [&](int s) VAD_INLINE { return fmaf(X0[s], k.b, X3[s]); });   // E - 2F
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sm = Y0[m][r] + Y1[m][r], df = Y0[m][r] - Y1[m][r];
+                const float s2 = Y2[m][r] + Y3[m][r], d2 = Y2[m][r] - Y3[m][r];
+                Y0[m][r] = sm + s2;
+                Y1[m][r] = fmaf(2.f, d2, df);
+                Y2[m][r] = fmaf(4.f, s2, sm);
+                Y3[m][r] = fmaf(8.f, d2, df);
+            }
+        {   const Coef k = opaque_coef<kFm4, kFm025>();
+            seg0(std::integral_constant<int, 4>{}, Y0, [&](int s) VAD_INLINE { return fmaf(X1[s], k.a, X3[s]); });   // x3 - 5 x1 = E - 4 x1
+            // the last matrix: what follows in this wave's stream is encoder 1's first blocks
+            run_segment<NB0, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Y3[IC(i) & 1]; },
+                                [&](auto kgc) VAD_INLINE {
+                                    constexpr int kg = IC(kgc);
+                                    return f32x4{fmaf(X2[4 * kg], k.b, -X0[4 * kg]), fmaf(X2[4 * kg + 1], k.b, -X0[4 * kg + 1]),
+                                                 fmaf(X2[4 * kg + 2], k.b, -X0[4 * kg + 2]), fmaf(X2[4 * kg + 3], k.b, -X0[4 * kg + 3])}; },   // -F - x2/4
+                                [&](auto i) VAD_INLINE { return e0_load(5, IC(i)); },
+                                [&](auto i) VAD_INLINE {
+                                    constexpr E1Blk eb = e1_blk(Q, IC(i));
+                                    return ld_blk(lane_w, (long)eb.unit * 16 + eb.kg * 4 + w); });
+        }
+        nyq_update<2>(Y0, xn0, wn + 128, ln);
+        nyq_update<2>(Y0, xn1, wn + 256, ln);
+        nyq_update<2>(Y1, xn0, wn, ln);
+        nyq_update<2>(Y1, xn1, wn + 128, ln);
+        nyq_update<2>(Y1, xn2, wn + 256, ln);
+        nyq_update<2>(Y2, xn1, wn, ln);
+        nyq_update<2>(Y2, xn2, wn + 128, ln);
+        nyq_update<2>(Y2, xn3, wn + 256, ln);
+        nyq_update<2>(Y3, xn2, wn, ln);
+        nyq_update<2>(Y3, xn3, wn + 128, ln);
+        relu<2>(Y0);
+        relu<2>(Y1);
+        relu<2>(Y2);
+        relu<2>(Y3);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            *reinterpret_cast<f32x4 *>(&ybuf[0][2 * w + m][ln.lane * 4]) = Y0[m];
+            *reinterpret_cast<f32x4 *>(&ybuf[1][2 * w + m][ln.lane * 4]) = Y1[m];
+            *reinterpret_cast<f32x4 *>(&ybuf[2][2 * w + m][ln.lane * 4]) = Y2[m];
+            *reinterpret_cast<f32x4 *>(&ybuf[3][2 * w + m][ln.lane * 4]) = Y3[m];
+        }
+    }
+    auto lds_barrier = [&]() VAD_INLINE {                       // (not __syncthreads: that would drain the A-fragment stream too)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    lds_barrier();
+
+    // ---- encoder 1: output row block w of both outputs, over all 128 input channels in the one-wave program's order ----------
+    f32x4 Z[2];
+    Z[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e1 + 16 * w + 4 * ln.g);
+    Z[1] = Z[0];
+    run_segment<40, 1>(pp, [&](auto i) VAD_INLINE -> f32x4 & { constexpr E1Blk eb = e1_blk(Q, IC(i)); return Z[eb.acc]; },
+                       [&](auto i) VAD_INLINE {
+                           constexpr E1Blk eb = e1_blk(Q, IC(i));
+                           return *reinterpret_cast<const f32x4 *>(&ybuf[eb.frame][eb.rbg][ln.lane * 4]); },
+                       [&](auto i) VAD_INLINE {
+                           constexpr E1Blk eb = e1_blk(Q, IC(i));
+                           return ld_blk(lane_w, (long)eb.unit * 16 + eb.kg * 4 + w); },
+                       [&](auto i) VAD_INLINE { return ld_blk(lane_w, (long)(T0 + IC(i) / 4) * 16 + (IC(i) % 4) * 4 + w); });    // encoder 2: 2 units x 4 k-groups
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[o][r] = fmaxf(Z[o][r], 0.f);
+        *reinterpret_cast<f32x4 *>(&zbuf[o][w][ln.lane * 4]) = Z[o];
+    }
+    lds_barrier();
+
+    // ---- encoder 2 (T 2 -> 1, stride 2: taps 1, 2 see encoder-1 outputs 0, 1): output row block w --------------------------------
+    f32x4 V1[1];
+    V1[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e2 + 16 * w + 4 * ln.g);
+    const float *e3 = lane_w + (size_t)(T0 + 2) * 4096 + (2 * w) * 256;     // encoder 3: [kg 4][rb 8], this wave's row blocks 2w, 2w + 1
+    run_segment<8, 1>(pp, [&](auto) VAD_INLINE -> f32x4 & { return V1[0]; },
+                      [&](auto i) VAD_INLINE { return *reinterpret_cast<const f32x4 *>(&zbuf[IC(i) / 4][IC(i) % 4][ln.lane * 4]); },
+                      [&](auto i) VAD_INLINE { return ld_blk(lane_w, (long)(T0 + IC(i) / 4) * 16 + (IC(i) % 4) * 4 + w); },
+                      [&](auto i) VAD_INLINE { return ld_blk(e3, (long)(IC(i) >> 1) * 8 + (IC(i) & 1)); });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V1[0][r] = fmaxf(V1[0][r], 0.f);
+    *reinterpret_cast<f32x4 *>(&vbuf[w][ln.lane * 4]) = V1[0];
+    lds_barrier();
+
+    // ---- encoder 3 (T = 1: centre tap only): output row blocks 2w, 2w + 1 ---------------------------------------------------------------
+    f32x4 Fw[2];
+    Fw[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e3 + 32 * w + 4 * ln.g);
+    Fw[1] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e3 + 32 * w + 16 + 4 * ln.g);
+    const float *ih = lane_w + (size_t)(T0 + 4 + 4 * w) * 4096;             // W_ih, gate w: [kg 8][rb 8], 64 consecutive blocks
+    run_segment<8, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Fw[IC(i) & 1]; },
+                      [&](auto kg) VAD_INLINE { return *reinterpret_cast<const f32x4 *>(&vbuf[IC(kg)][ln.lane * 4]); },
+                      [&](auto i) VAD_INLINE { return ld_blk(e3, (long)(IC(i) >> 1) * 8 + (IC(i) & 1)); },
+                      [&](auto i) VAD_INLINE { return ld_blk(ih, IC(i)); });
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Fw[m][r] = fmaxf(Fw[m][r], 0.f);
+        *reinterpret_cast<f32x4 *>(&febuf[2 * w + m][ln.lane * 4]) = Fw[m];
+    }
+    lds_barrier();
+
+    // ---- LSTM input-gate pre-activations of gate w (8 row blocks), stored in D-fragment order ------------------------------------------
+    f32x4 Fe[8], G[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) Fe[m] = *reinterpret_cast<const f32x4 *>(&febuf[m][ln.lane * 4]);
+    init_bias<8>(G, tab + tb.b_g + 128 * w, ln);
+    run_segment<64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
+                       [&](auto kg) VAD_INLINE { return Fe[IC(kg)]; },
+                       [&](auto i) VAD_INLINE { return ld_blk(ih, IC(i)); },
+                       [&](auto) VAD_INLINE { return f32x4{0.f, 0.f, 0.f, 0.f}; });
+    float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32 + 8 * w) * 256 + ln.lane * 4;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) *reinterpret_cast<f32x4 *>(gxt + (size_t)m * 256) = G[m];
+}
+
+}  // namespace
+
+template <typename PcmT>
+hipError_t launch_front_lat(int sr, const FrontArgs &a, hipStream_t s) {
+    if (a.B <= 0 || a.nt <= 0) return hipSuccess;
+    const long nst = (a.B + 15) / 16, total = nst * a.nt;
+    if (total > 0x7fffffffL) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)total;
+    if (a.dec > 1 && (sr != 16000 || a.dec > 3)) return hipErrorInvalidValue;
+    if (a.dec == 3) hipLaunchKernelGGL((front_lat_kernel<32, PcmT, 3>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.dec == 2) hipLaunchKernelGGL((front_lat_kernel<32, PcmT, 2>), dim3(grid), dim3(256), 0, s, a);
+    else if (sr == 16000) hipLaunchKernelGGL((front_lat_kernel<32, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((front_lat_kernel<16, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+template hipError_t launch_front_lat<float>(int, const FrontArgs &, hipStream_t);
+template hipError_t launch_front_lat<int16_t>(int, const FrontArgs &, hipStream_t);
+
+}  // namespace vad

@@ -1176,3 +1176,85 @@ def test_ragged_corpus_from_pinned_memory(model, golden, monkeypatch, mode):
     monkeypatch.setenv("SILERO_VAD_AMD_WINDOW_BYTES", "400000")              # a handful of recordings per window
     got_w = ragged_probs(seq, model, sr, max_waste=0.2, max_bytes=150_000)
     assert all(torch.equal(g, want[j]) for g, j in zip(got_w, order))
+
+
+# ---- (14) the latency form of the frontend -----------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_latency_frontend_is_bit_identical(model, oracle, golden, tag):
+    """kernel_front_lat.hip (one 4-wave workgroup per 16-chunk tile, every layer's rows split over the waves, activations
+    exchanged through LDS) against kernel_front_f43.hip (one wave per tile): the same products summed in the same order --
+    probabilities, final state, context and the gate pre-activations must be IDENTICAL bits, for float and int16 PCM,
+    ragged tails, carried state, the 32 / 48 kHz front door, and also against the oracle."""
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    eng = model.engine
+    rng = np.random.default_rng(31)
+
+    def both(fn):
+        out = []
+        for form in ("throughput", "latency"):
+            eng.set_option("front", form)
+            try:
+                out.append(fn())
+            finally:
+                eng.set_option("front", "auto")
+        return out
+
+    for B, T, extra in ((1, 1, 0), (1, 7, 100), (17, 5, 0), (33, 12, n - 1), (70, 3, 1)):
+        rows = rolled_rows(g["wav"], B, T * n + extra, 4001)
+        st0 = (0.3 * rng.standard_normal((2, B, 128))).astype(np.float32)
+        ctx0 = (0.1 * rng.standard_normal((B, n // 8))).astype(np.float32)
+        (p1, c1, s1), (p2, c2, s2) = both(lambda: run_engine(model, rows, sr, state=st0, ctx=ctx0))
+        assert np.array_equal(p1, p2) and np.array_equal(c1, c2) and np.array_equal(s1, s2), (B, T, extra)
+        want, wctx, wst = oracle.forward_audio(rows, sr, state=st0, ctx=ctx0)
+        assert np.abs(p2 - want).max() < TIGHT and np.array_equal(c2, wctx)
+        x16 = torch.from_numpy((rows * 32768.0).clip(-32768, 32767).astype(np.int16))
+        (q1, _, _), (q2, _, _) = both(lambda: run_engine(model, x16, sr))
+        assert np.array_equal(q1, q2)
+    rows = rolled_rows(g["wav"], 19, 5 * n, 997)
+    x = torch.from_numpy(rows).to(model.device)
+    gx1, gx2 = both(lambda: eng.debug_frontend(x, sr, torch.zeros((19, n // 8), device=model.device)).cpu().numpy())
+    assert np.array_equal(gx1, gx2)
+    if sr == 16000:
+        for k in (2, 3):
+            L16 = 3 * 512 + 77
+            raw = np.zeros((5, L16 * k - (k - 1)), np.float32)
+            raw[:, ::k] = rolled_rows(g["wav"], 5, L16, 313)
+            xr = torch.from_numpy(raw).to(model.device)
+
+            def run_raw():
+                ctx = torch.zeros((5, 64), device=model.device)
+                st = torch.zeros((2, 5, 128), device=model.device)
+                return eng.forward_audio(xr, 16000 * k, ctx, st).cpu().numpy(), ctx.cpu().numpy(), st.cpu().numpy()
+            (a1, c1, s1), (a2, c2, s2) = both(run_raw)
+            assert np.array_equal(a1, a2) and np.array_equal(c1, c2) and np.array_equal(s1, s2), k
+
+
+def test_latency_frontend_serves_small_launches(model, golden):
+    """`front=auto`: a stream pool's step and a B = 1 call take the latency form, a corpus-sized call the throughput form --
+    visible in the kernel times the engine records (the latency form must be several times faster on 512 tiles)."""
+    eng = model.engine
+    sr, n, B = 16000, 512, 8192
+    x = torch.from_numpy(rolled_rows(golden["16k"]["wav"], 64, n, 4001)).repeat(B // 64, 1).to(model.device)
+    ctx = torch.zeros((B, 64), device=model.device)
+    st = torch.zeros((2, B, 128), device=model.device)
+    out = torch.zeros((B, 1), device=model.device)
+    times = {}
+    for form in ("throughput", "latency", "auto"):
+        eng.set_option("front", form)
+        try:
+            for _ in range(30):
+                eng.step(x, sr, ctx, st, out)
+            eng.set_option("profile", "1")
+            for _ in range(30):
+                eng.step(x, sr, ctx, st, out)
+            f, r, c = eng.kernel_times()
+            eng.set_option("profile", "0")
+            times[form] = f / c
+        finally:
+            eng.set_option("front", "auto")
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"front_ms_8192_streams_one_step": times}, open("gpurun_out/latency_frontend.json", "w"), indent=1)
+    assert times["latency"] < 0.75 * times["throughput"], times
+    assert times["auto"] < 0.75 * times["throughput"], times

@@ -18,13 +18,12 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
-HIP = ["engine.hip", "kernel_front.hip", "kernel_front_wino.hip", "kernel_front_f43.hip", "kernel_rec.hip", "kernel_front_split.hip", "kernel_rec_split.hip",
-       "kernels_ref.hip", "kernel_scan.hip"]
+HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_rec.hip", "kernels_ref.hip", "kernel_scan.hip", "kernel_ingest.hip"]
 CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
 VARIANTS = {
     "base": [],
-    "xbasis": ["-DVAD_F43_EF=0"],                       # F(4,3) input transform from x0..x3 instead of (E, F, x1, x2)
+    "xbasis": ["-DVAD_F43_EF=0"],                       # F(4,3) input transform from x0..x3 instead of (E, F, x1, x2) (f43 form only)
     "shfl": ["-DVAD_XLANE_SWAP=0"],                     # cross-lane FFT stages through ds_bpermute (round-2a form)
     "nyq0": ["-DVAD_NYQ_VALU=0"],                       # Nyquist bin as a 9th MFMA k-group (round-1 form)
     "nyq0_slot24": ["-DVAD_NYQ_VALU=0", "-DVAD_SLOT_BLOCKS=24"],
@@ -88,7 +87,7 @@ def build(names):
     shared.mkdir(exist_ok=True)
     procs = []
     # translation units without knobs are compiled once
-    knob_units = {"kernel_front.hip", "kernel_front_wino.hip", "kernel_front_f43.hip", "kernel_rec.hip", "kernel_front_split.hip", "kernel_rec_split.hip"}
+    knob_units = {"kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_rec.hip"}
     for src in HIP + CPP:
         if src in knob_units:
             continue
@@ -101,7 +100,7 @@ def build(names):
         d = OUT / ("obj_" + name)
         d.mkdir(exist_ok=True)
         for src in knob_units:
-            extra = nopk if (("split" in src and not name.startswith("pk")) or name.startswith("nopk")) else []   # product flags (see __graft_entry__)
+            extra = nopk if name.startswith("nopk") else []
             procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950"] + common + extra + VARIANTS[name]
                                           + ["-c", str(CSRC / src), "-o", str(d / (src + ".o"))]))
     for p in procs:
