@@ -244,12 +244,16 @@ __device__ __forceinline__ void fft_inlane(f32x2 (&z)[Q]) {
     }
 }
 
-// One frame (V) of 16 chunks: X[s] (s < Q): |Y[4s + P[g]]|;  X[Q]: |Y[4Q]| in group 0, 0 elsewhere.
+// The math of one frame of 16 chunks from the lanes' PCM slices s[] (load_slice): X[s] (s < Q): |Y[4s + P[g]]|;  X[Q]: |Y[4Q]| in
+// group 0, 0 elsewhere.
+template <int Q>
+__device__ __forceinline__ void fft_math(float (&X)[Q + 1], const float (&s)[2 * Q], const float *tab_lds, const Lane &ln);
+
+// One frame (V) of 16 chunks: load the slices, then fft_math.
 template <int Q, typename PcmT, int DEC = 1>
 __device__ __forceinline__ void fft_frame(float (&X)[Q + 1], const int V, const FrontArgs &a, const float *tab_lds,
                                           const Lane &ln) {
     constexpr int SL = 2 * Q;
-    constexpr vadl::Tab tb = vadl::make_tab(8 * Q, Q);
     __builtin_amdgcn_sched_barrier(0);     // keep each pass's loads inside the pass (register budget)
     float s[SL];
     if (VAD_ABLATE & 4) {
@@ -264,6 +268,13 @@ __device__ __forceinline__ void fft_frame(float (&X)[Q + 1], const int V, const 
         X[Q] = s[0];
         return;
     }
+    fft_math<Q>(X, s, tab_lds, ln);
+}
+
+template <int Q>
+__device__ __forceinline__ void fft_math(float (&X)[Q + 1], const float (&s)[2 * Q], const float *tab_lds, const Lane &ln) {
+    constexpr int SL = 2 * Q;
+    constexpr vadl::Tab tb = vadl::make_tab(8 * Q, Q);
 
     f32x2 z[Q];
     {   // window (same taps for every frame: the lane's slice always sits at 2Q g inside the frame)

@@ -19,9 +19,14 @@
 // ALL input channels in the order the one-wave program does: same products, same order per accumulator, identical bits
 // (tests/test_gpu_parity.py::test_latency_frontend_is_bit_identical).  The 4 STFT frames are split the same way: wave v
 // transforms frame v, the magnitudes are exchanged through LDS.
+// Measured (one MI355X, tools/lat_time.py): one step of 8 192 streams 84 -> 54 us, of <= 4 096 streams 84 -> 30 us, a B = 1..16 call
+// 80 -> 27 us.  Of the 27 us of one tile ~6 are the wave's STFT frame (PCM latency + a VALU-bound FFT nobody overlaps), ~3 A-fragment
+// waits, ~18 the MFMA + VALU issue time itself (timing-only ablations: variants lat_nofft / lat_noload / lat_neither); two workgroups
+// per CU (variant lat_wg2) do not help, because all workgroups of a step run in phase.
 //   One workgroup per CU (launch bound 256 x 1): with a single wave per SIMD there is nobody to hide latency, so the A
 // fragments do not go through an LDS ring and its barriers; each wave streams exactly the blocks it needs from the L2-resident
-// image straight into registers, kD = 8 blocks (32 MFMAs, ~1 000 cycles) ahead -- there are 512 VGPRs per lane to do it in.
+// image straight into registers, kD = 8 blocks (32 MFMAs, ~1 000 cycles) ahead (deeper measured no faster: tools/variants.py lat_d*),
+// and everything a wave waits for first (its PCM slice, the head of its stream, the tables) is requested before anything else.
 #include <hip/hip_runtime.h>
 
 #include "front_common.hpp"
@@ -29,31 +34,38 @@
 namespace vad {
 namespace {
 
-constexpr int kD = 8;                    // A-fragment prefetch distance, in 1 KiB blocks (one block = 4 MFMAs)
+#ifndef VAD_LAT_DEPTH
+#define VAD_LAT_DEPTH 8
+#endif
+constexpr int kD = VAD_LAT_DEPTH;        // A-fragment prefetch distance, in 1 KiB blocks (one block = 4 MFMAs = 128 pipe cycles)
 #define IC(x) (decltype(x)::value)      // the value of an integral_constant argument, as a constant expression
 
 struct Pipe {
     f32x4 q[kD];
 };
 
+#ifndef VAD_LAT_ABLATE
+#define VAD_LAT_ABLATE 0                 // timing experiments only (wrong results): 1 no A-fragment loads, 2 no FFT
+#endif
 __device__ __forceinline__ f32x4 ld_blk(const float *lane_base, long blk) {      // lane_base already holds lane * 4
+    if (VAD_LAT_ABLATE & 1) return f32x4{1e-3f, 2e-3f, -1e-3f, 5e-4f};
     return *reinterpret_cast<const f32x4 *>(lane_base + blk * 256);
 }
 
-// One segment of a wave's program: NB blocks consumed in order, NBS consecutive blocks form a step that shares its four
-// B operands (bvec(step)); block i accumulates into acc(i).  load(i) requests this segment's block i, next(j) the first kD
-// blocks of the segment that follows, so that the stream never restarts cold.
-template <int NB, int NBS, class AccF, class BF, class LoadF, class NextF>
-__device__ __forceinline__ void run_segment(Pipe &pp, AccF acc, BF bvec, LoadF load, NextF next) {
-    static_assert(NB % kD == 0 && NB % NBS == 0, "segments are whole FIFO turns");
+// One segment of a wave's program: blocks START .. START + NB - 1 of the wave's block stream, consumed in order; NBS
+// consecutive blocks form a step that shares its four B operands (bvec(step)); block i of the segment accumulates into
+// acc(i).  load(g) requests block g of the STREAM (any g, also beyond the segment: the FIFO runs kD blocks ahead, across
+// segment boundaries, and never restarts cold).
+template <int START, int NB, int NBS, class AccF, class BF, class LoadF>
+__device__ __forceinline__ void run_segment(Pipe &pp, AccF acc, BF bvec, LoadF load) {
+    static_assert(NB % NBS == 0, "segments are whole steps");
     static_for<0, NB / NBS>([&](auto sc) VAD_INLINE {
         constexpr int st = decltype(sc)::value;
         f32x4 a[NBS];
         static_for<0, NBS>([&](auto bc) VAD_INLINE {
-            constexpr int b = decltype(bc)::value, i = st * NBS + b;
-            a[b] = pp.q[i % kD];
-            if constexpr (i + kD < NB) pp.q[i % kD] = load(std::integral_constant<int, i + kD>{});
-            else pp.q[i % kD] = next(std::integral_constant<int, i + kD - NB>{});
+            constexpr int b = decltype(bc)::value, gi = START + st * NBS + b;
+            a[b] = pp.q[gi % kD];
+            pp.q[gi % kD] = load(std::integral_constant<int, gi + kD>{});
         });
         const f32x4 bv = bvec(std::integral_constant<int, st>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -90,17 +102,24 @@ constexpr E1Blk e1_blk(int Q, int idx) {
     return E1Blk{vadl::w4_e1(p, u, 16), kg, ac[u], fr[u], 4 * p + kg};
 }
 
+#ifndef VAD_LAT_WG_PER_CU
+#define VAD_LAT_WG_PER_CU 1
+#endif
 template <int Q, typename PcmT, int DEC>
-__global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
+__global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const FrontArgs a) {
     using namespace vadl;
     constexpr Tab tb = make_tab(8 * Q, Q);
     constexpr int TABF = (tb.total + 3) / 4 * 4;
     constexpr int RB = w_rb(Q), KG0 = Q / 4, T0 = w4_tail0(Q);
     constexpr int NB0 = 2 * KG0;                                 // blocks of one encoder-0 matrix for one wave (2 row blocks)
-    static_assert(NB0 % kD == 0, "encoder-0 segments are whole FIFO turns");
+    // the wave's block stream: encoder 0 (6 matrices), encoder 1 (40 blocks), encoder 2 (8), encoder 3 (8), W_ih (64)
+    constexpr int S_E1 = 6 * NB0, S_E2 = S_E1 + 40, S_E3 = S_E2 + 8, S_IH = S_E3 + 8, S_END = S_IH + 64;
     __shared__ __attribute__((aligned(16))) float tab[TABF];
-    __shared__ float xs[4][Q + 1][64];                           // STFT magnitudes, frame v by wave v
-    __shared__ __attribute__((aligned(16))) float ybuf[4][8][256];   // encoder 0: [frame][row block][lane][4]
+    // (the STFT magnitudes are dead once every wave has them in registers: encoder 0's output takes their place)
+    constexpr int XSF = 4 * (Q + 1) * 64, YBF = 4 * 8 * 256;
+    __shared__ __attribute__((aligned(16))) float xy[XSF > YBF ? XSF : YBF];
+    float (*xs)[Q + 1][64] = reinterpret_cast<float (*)[Q + 1][64]>(xy);          // [frame][k][lane], frame v by wave v
+    float (*ybuf)[8][256] = reinterpret_cast<float (*)[8][256]>(xy);              // encoder 0: [frame][row block][lane][4]
     __shared__ __attribute__((aligned(16))) float zbuf[2][4][256];   // encoder 1: [out][row block][lane][4]
     __shared__ __attribute__((aligned(16))) float vbuf[4][256];      // encoder 2
     __shared__ __attribute__((aligned(16))) float febuf[8][256];     // encoder 3
@@ -127,12 +146,35 @@ __global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
     const int u_e0 = part == 0 ? w4_part0(0, Q) : part == 1 ? w4_part0(1, Q) : part == 2 ? w4_part0(2, Q) : w4_part0(3, Q);
     const float *lane_w = a.wfront + ln.lane * 4;
     const float *e0 = lane_w + (size_t)u_e0 * 4096 + rb0 * 256;              // + j * 4096 + (kg * RB + r) * 256
-    auto e0_load = [&](int j, int i) VAD_INLINE { return ld_blk(e0, (long)j * 16 + (i >> 1) * RB + (i & 1)); };
+    const float *e3 = lane_w + (size_t)(T0 + 2) * 4096 + (2 * w) * 256;      // encoder 3: [kg 4][rb 8], this wave's row blocks 2w, 2w + 1
+    const float *ih = lane_w + (size_t)(T0 + 4 + 4 * w) * 4096;              // W_ih, gate w: [kg 8][rb 8], 64 consecutive blocks
+    // block g of this wave's stream (g is a compile-time constant at every call site)
+    auto gload = [&](auto gc) VAD_INLINE -> f32x4 {
+        constexpr int g = IC(gc);
+        if constexpr (g < S_E1) {
+            constexpr int j = g / NB0, i = g % NB0;
+            return ld_blk(e0, (long)j * 16 + (i >> 1) * RB + (i & 1));
+        } else if constexpr (g < S_E2) {
+            constexpr E1Blk eb = e1_blk(Q, g - S_E1);
+            return ld_blk(lane_w, (long)eb.unit * 16 + eb.kg * 4 + w);
+        } else if constexpr (g < S_E3) {
+            constexpr int i = g - S_E2;                           // encoder 2: 2 units x 4 k-groups, row block w
+            return ld_blk(lane_w, (long)(T0 + i / 4) * 16 + (i % 4) * 4 + w);
+        } else if constexpr (g < S_IH) {
+            constexpr int i = g - S_E3;
+            return ld_blk(e3, (long)(i >> 1) * 8 + (i & 1));
+        } else if constexpr (g < S_END) {
+            return ld_blk(ih, g - S_IH);
+        } else {
+            return f32x4{0.f, 0.f, 0.f, 0.f};                     // past the end of the program
+        }
+    };
 
+    // ---- everything this wave will wait for first is requested first: its PCM slice, the head of its weight stream, the tables
+    float pcm_s[2 * Q];
+    if (!(VAD_LAT_ABLATE & 2)) load_slice<Q, PcmT, DEC>(pcm_s, a, ln, w);          // wave v owns STFT frame v
     Pipe pp;
-#pragma unroll
-    for (int i = 0; i < kD; ++i) pp.q[i] = e0_load(0, i);        // the stream starts while the FFT runs
-
+    static_for<0, kD>([&](auto ic) VAD_INLINE { pp.q[IC(ic)] = gload(ic); });
     {   // tables -> LDS: all loads of a thread are issued before the first is stored
         static_assert(tb.total % 4 == 0, "tables are copied as 16-byte vectors");
         constexpr int NV = tb.total / 4, PER = (NV + 255) / 256;
@@ -155,11 +197,21 @@ __global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
     float X0[Q + 1], X1[Q + 1], X2[Q + 1], X3[Q + 1];
     {
         float Xm[Q + 1];
-        fft_frame<Q, PcmT, DEC>(Xm, w, a, tab, ln);
+        if (VAD_LAT_ABLATE & 2) {
+#pragma unroll
+            for (int k = 0; k <= Q; ++k) Xm[k] = (float)(ln.lane + k) * 1e-3f;
+        } else {
+            fft_math<Q>(Xm, pcm_s, tab, ln);
+        }
 #pragma unroll
         for (int k = 0; k <= Q; ++k) xs[w][k][ln.lane] = Xm[k];
     }
-    __syncthreads();
+    auto lds_barrier = [&]() VAD_INLINE {                       // (not __syncthreads: that would drain the A-fragment stream too)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k <= Q; ++k) {
         X0[k] = xs[0][k][ln.lane];
@@ -167,6 +219,7 @@ __global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
         X2[k] = xs[2][k][ln.lane];
         X3[k] = xs[3][k][ln.lane];
     }
+    lds_barrier();                                               // everybody has read xs: its memory becomes ybuf
     // |Y_nyq| of chunk j lives in lane group 0 (X[Q]); every lane of the chunk needs it
     const float xn0 = __shfl(X0[Q], ln.j), xn1 = __shfl(X1[Q], ln.j), xn2 = __shfl(X2[Q], ln.j), xn3 = __shfl(X3[Q], ln.j);
     // the F(4,3) input transform reads the frames through E = x3 - x1 and F = x2 - x0 (kept in place of x3 and x0)
@@ -186,12 +239,10 @@ __global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
         zero<2>(Y2);
         zero<2>(Y3);
         auto seg0 = [&](auto jc, f32x4 (&Y)[2], auto bfun) VAD_INLINE {
-            constexpr int j = decltype(jc)::value;
-            run_segment<NB0, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Y[IC(i) & 1]; },
-                                [&](auto kg) VAD_INLINE {
-                                    return f32x4{bfun(4 * IC(kg)), bfun(4 * IC(kg) + 1), bfun(4 * IC(kg) + 2), bfun(4 * IC(kg) + 3)}; },
-                                [&](auto i) VAD_INLINE { return e0_load(j, IC(i)); },
-                                [&](auto i) VAD_INLINE { return e0_load(j + 1, IC(i)); });
+            run_segment<IC(jc) * NB0, NB0, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Y[IC(i) & 1]; },
+                                              [&](auto kg) VAD_INLINE {
+                                                  return f32x4{bfun(4 * IC(kg)), bfun(4 * IC(kg) + 1), bfun(4 * IC(kg) + 2), bfun(4 * IC(kg) + 3)}; },
+                                              gload);
         };
         {   const Coef k = opaque_coef<kF4, kFm3>();
             seg0(std::integral_constant<int, 0>{}, Y0, [&](int s) VAD_INLINE {
@@ -217,16 +268,7 @@ __global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
             }
         {   const Coef k = opaque_coef<kFm4, kFm025>();
             seg0(std::integral_constant<int, 4>{}, Y0, [&](int s) VAD_INLINE { return fmaf(X1[s], k.a, X3[s]); });   // x3 - 5 x1 = E - 4 x1
-            // the last matrix: what follows in this wave's stream is encoder 1's first blocks
-            run_segment<NB0, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Y3[IC(i) & 1]; },
-                                [&](auto kgc) VAD_INLINE {
-                                    constexpr int kg = IC(kgc);
-                                    return f32x4{fmaf(X2[4 * kg], k.b, -X0[4 * kg]), fmaf(X2[4 * kg + 1], k.b, -X0[4 * kg + 1]),
-                                                 fmaf(X2[4 * kg + 2], k.b, -X0[4 * kg + 2]), fmaf(X2[4 * kg + 3], k.b, -X0[4 * kg + 3])}; },   // -F - x2/4
-                                [&](auto i) VAD_INLINE { return e0_load(5, IC(i)); },
-                                [&](auto i) VAD_INLINE {
-                                    constexpr E1Blk eb = e1_blk(Q, IC(i));
-                                    return ld_blk(lane_w, (long)eb.unit * 16 + eb.kg * 4 + w); });
+            seg0(std::integral_constant<int, 5>{}, Y3, [&](int s) VAD_INLINE { return fmaf(X2[s], k.b, -X0[s]); });  // x0 - 1.25 x2 = -F - x2/4
         }
         nyq_update<2>(Y0, xn0, wn + 128, ln);
         nyq_update<2>(Y0, xn1, wn + 256, ln);
@@ -250,25 +292,22 @@ __global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
             *reinterpret_cast<f32x4 *>(&ybuf[3][2 * w + m][ln.lane * 4]) = Y3[m];
         }
     }
-    auto lds_barrier = [&]() VAD_INLINE {                       // (not __syncthreads: that would drain the A-fragment stream too)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
     lds_barrier();
 
     // ---- encoder 1: output row block w of both outputs, over all 128 input channels in the one-wave program's order ----------
+    // (all of encoder 0's output first: 32 registers' worth of LDS reads in one go instead of one exposed LDS latency per block --
+    //  the 132 registers of the magnitudes are free by now)
+    f32x4 Yall[4][8];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) Yall[f][m] = *reinterpret_cast<const f32x4 *>(&ybuf[f][m][ln.lane * 4]);
     f32x4 Z[2];
     Z[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e1 + 16 * w + 4 * ln.g);
     Z[1] = Z[0];
-    run_segment<40, 1>(pp, [&](auto i) VAD_INLINE -> f32x4 & { constexpr E1Blk eb = e1_blk(Q, IC(i)); return Z[eb.acc]; },
-                       [&](auto i) VAD_INLINE {
-                           constexpr E1Blk eb = e1_blk(Q, IC(i));
-                           return *reinterpret_cast<const f32x4 *>(&ybuf[eb.frame][eb.rbg][ln.lane * 4]); },
-                       [&](auto i) VAD_INLINE {
-                           constexpr E1Blk eb = e1_blk(Q, IC(i));
-                           return ld_blk(lane_w, (long)eb.unit * 16 + eb.kg * 4 + w); },
-                       [&](auto i) VAD_INLINE { return ld_blk(lane_w, (long)(T0 + IC(i) / 4) * 16 + (IC(i) % 4) * 4 + w); });    // encoder 2: 2 units x 4 k-groups
+    run_segment<S_E1, 40, 1>(pp, [&](auto i) VAD_INLINE -> f32x4 & { constexpr E1Blk eb = e1_blk(Q, IC(i)); return Z[eb.acc]; },
+                             [&](auto i) VAD_INLINE { constexpr E1Blk eb = e1_blk(Q, IC(i)); return Yall[eb.frame][eb.rbg]; },
+                             gload);
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
 #pragma unroll
@@ -278,27 +317,29 @@ __global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
     lds_barrier();
 
     // ---- encoder 2 (T 2 -> 1, stride 2: taps 1, 2 see encoder-1 outputs 0, 1): output row block w --------------------------------
+    f32x4 Zall[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) Zall[o][m] = *reinterpret_cast<const f32x4 *>(&zbuf[o][m][ln.lane * 4]);
     f32x4 V1[1];
     V1[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e2 + 16 * w + 4 * ln.g);
-    const float *e3 = lane_w + (size_t)(T0 + 2) * 4096 + (2 * w) * 256;     // encoder 3: [kg 4][rb 8], this wave's row blocks 2w, 2w + 1
-    run_segment<8, 1>(pp, [&](auto) VAD_INLINE -> f32x4 & { return V1[0]; },
-                      [&](auto i) VAD_INLINE { return *reinterpret_cast<const f32x4 *>(&zbuf[IC(i) / 4][IC(i) % 4][ln.lane * 4]); },
-                      [&](auto i) VAD_INLINE { return ld_blk(lane_w, (long)(T0 + IC(i) / 4) * 16 + (IC(i) % 4) * 4 + w); },
-                      [&](auto i) VAD_INLINE { return ld_blk(e3, (long)(IC(i) >> 1) * 8 + (IC(i) & 1)); });
+    run_segment<S_E2, 8, 1>(pp, [&](auto) VAD_INLINE -> f32x4 & { return V1[0]; },
+                            [&](auto i) VAD_INLINE { return Zall[IC(i) / 4][IC(i) % 4]; }, gload);
 #pragma unroll
     for (int r = 0; r < 4; ++r) V1[0][r] = fmaxf(V1[0][r], 0.f);
     *reinterpret_cast<f32x4 *>(&vbuf[w][ln.lane * 4]) = V1[0];
     lds_barrier();
 
     // ---- encoder 3 (T = 1: centre tap only): output row blocks 2w, 2w + 1 ---------------------------------------------------------------
+    f32x4 Vall[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) Vall[m] = *reinterpret_cast<const f32x4 *>(&vbuf[m][ln.lane * 4]);
     f32x4 Fw[2];
     Fw[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e3 + 32 * w + 4 * ln.g);
     Fw[1] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e3 + 32 * w + 16 + 4 * ln.g);
-    const float *ih = lane_w + (size_t)(T0 + 4 + 4 * w) * 4096;             // W_ih, gate w: [kg 8][rb 8], 64 consecutive blocks
-    run_segment<8, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Fw[IC(i) & 1]; },
-                      [&](auto kg) VAD_INLINE { return *reinterpret_cast<const f32x4 *>(&vbuf[IC(kg)][ln.lane * 4]); },
-                      [&](auto i) VAD_INLINE { return ld_blk(e3, (long)(IC(i) >> 1) * 8 + (IC(i) & 1)); },
-                      [&](auto i) VAD_INLINE { return ld_blk(ih, IC(i)); });
+    run_segment<S_E3, 8, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Fw[IC(i) & 1]; },
+                            [&](auto kg) VAD_INLINE { return Vall[IC(kg)]; }, gload);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -312,10 +353,8 @@ __global__ void __launch_bounds__(256, 1) front_lat_kernel(const FrontArgs a) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) Fe[m] = *reinterpret_cast<const f32x4 *>(&febuf[m][ln.lane * 4]);
     init_bias<8>(G, tab + tb.b_g + 128 * w, ln);
-    run_segment<64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
-                       [&](auto kg) VAD_INLINE { return Fe[IC(kg)]; },
-                       [&](auto i) VAD_INLINE { return ld_blk(ih, IC(i)); },
-                       [&](auto) VAD_INLINE { return f32x4{0.f, 0.f, 0.f, 0.f}; });
+    run_segment<S_IH, 64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
+                             [&](auto kg) VAD_INLINE { return Fe[IC(kg)]; }, gload);
     float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32 + 8 * w) * 256 + ln.lane * 4;
 #pragma unroll
     for (int m = 0; m < 8; ++m) *reinterpret_cast<f32x4 *>(gxt + (size_t)m * 256) = G[m];

@@ -23,6 +23,9 @@ CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
 VARIANTS = {
     "base": [],
+    "lat_wg2": ["-DVAD_LAT_WG_PER_CU=2", "-DVAD_LAT_DEPTH=8"], "lat_wg2_d4": ["-DVAD_LAT_WG_PER_CU=2", "-DVAD_LAT_DEPTH=4"],
+    "lat_d8": ["-DVAD_LAT_DEPTH=8"], "lat_d24": ["-DVAD_LAT_DEPTH=24"], "lat_d32": ["-DVAD_LAT_DEPTH=32"],
+    "lat_noload": ["-DVAD_LAT_ABLATE=1"], "lat_nofft": ["-DVAD_LAT_ABLATE=2"], "lat_neither": ["-DVAD_LAT_ABLATE=3"],
     "xbasis": ["-DVAD_F43_EF=0"],                       # F(4,3) input transform from x0..x3 instead of (E, F, x1, x2) (f43 form only)
     "shfl": ["-DVAD_XLANE_SWAP=0"],                     # cross-lane FFT stages through ds_bpermute (round-2a form)
     "nyq0": ["-DVAD_NYQ_VALU=0"],                       # Nyquist bin as a 9th MFMA k-group (round-1 form)
