@@ -16,7 +16,6 @@ if [ "$slow" = "1" ] || [ -n "${HUNT_FORCE_PMC:-}" ]; then
   [ "$slow" = "1" ] && echo SLOW BOX | tee -a $out/summary.txt
   python bench.py --no-cpu-baseline --no-extras --steps 100 --config 8k 2>/dev/null | kms | sed 's/^/8k product front_ms /' | tee -a $out/summary.txt
   VAD_BENCH_ENC0=winograd2 python bench.py --no-cpu-baseline --no-extras --steps 100 --config 8k 2>/dev/null | kms | sed 's/^/8k straight-line front_ms /' | tee -a $out/summary.txt
-  python bench.py --no-cpu-baseline --no-extras --steps 100 --precision f16x3 2>/dev/null | kms | sed 's/^/f16x3 front_ms /' | tee -a $out/summary.txt
   echo "== product" | tee -a $out/summary.txt
   bash tools/pmc_front.sh $out/pmc_product | tee -a $out/summary.txt
   echo "== straight-line" | tee -a $out/summary.txt
