@@ -1,6 +1,8 @@
 """Host logic of silero_vad_amd/streams.py on CPU: the ragged-corpus plan, the batch segmenter and
 the batched streaming iterator.  The GPU engine is replaced by a stand-in over the CPU oracle
 (tests may use the oracle; the product never does)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -240,3 +242,60 @@ def test_stage_rows_on_the_persistent_pool(built):
         assert _lib.lib().vad_stage_rows(rows, clens, n, width, 2, dst.ctypes.data, threads) == 0
         for i in range(n):
             assert np.array_equal(dst[i, :lens[i]], base[offs[i]:offs[i] + lens[i]]) and not dst[i, lens[i]:].any()
+
+
+def test_packed_recordings_windows_and_plan():
+    """PackedRecordings: arena-order runs become windows of bounded span; a recording that starts before its
+    predecessor ends (a ring that wrapped, overlapping views) starts a new window; WindowedPlan buckets every recording
+    exactly once, inside its own window."""
+    from silero_vad_amd import PackedRecordings
+    from silero_vad_amd.streams import WindowedPlan
+    rng = np.random.default_rng(2)
+    lens = rng.integers(1000, 9000, 500).astype(np.int64)
+    lens[17] = 0
+    offs = np.concatenate([[0], np.cumsum((lens + 7) // 8 * 8)[:-1]])
+    ring = int(offs[250])                                        # the arena is refilled from the start half way through
+    offs[250:] -= ring
+    base = torch.zeros(int(max(offs + lens)) + 8, dtype=torch.int16)
+    rec = PackedRecordings(base, offs, lens)
+    assert len(rec) == 500 and rec[3].shape[0] == lens[3] and rec[17].numel() == 0
+    wins = rec.windows(max_bytes=200_000)
+    assert wins[0][0] == 0 and wins[-1][1] == 500 and all(a[1] == b[0] for a, b in zip(wins, wins[1:]))
+    assert any(hi == 250 for _, hi in wins)                      # the wrap is a window boundary
+    for lo, hi in wins:
+        assert (offs[hi - 1] + lens[hi - 1] - offs[lo]) * 2 <= 200_000 or hi - lo == 1
+        assert np.all(offs[lo + 1:hi] >= offs[lo:hi - 1] + lens[lo:hi - 1])
+    plan = WindowedPlan(rec, max_waste=0.2, max_bytes=60_000, itemsize=2, window_bytes=200_000)
+    seen = sorted(i for b in plan.buckets for i in b)
+    assert seen == [i for i in range(500) if lens[i] > 0] and plan.empty == [17]
+    for b, w in zip(plan.buckets, plan.window_of):
+        lo, hi = plan.windows[w]
+        assert all(lo <= i < hi for i in b)
+        a0, a1 = plan.span[w]
+        assert all(a0 <= offs[i] and offs[i] + lens[i] <= a1 for i in b)
+    with pytest.raises(ValueError):
+        PackedRecordings(base, offs, lens + base.numel())
+    with pytest.raises(ValueError):
+        PackedRecordings(base.to(torch.float64), offs, lens)
+
+
+def test_packed_recordings_through_the_cpu_stand_in(oracle):
+    """The corpus functions take a PackedRecordings wherever they take a list; results as arrays or as lists of dicts."""
+    from replay_engine import ReplayEngine
+    from silero_vad_amd import PackedRecordings, ragged_probs, ragged_speech_segments
+    from silero_vad_amd.engine import HipSileroVAD
+    sr, n = 16000, 512
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "audio_16k.npz"))["pcm"]
+    lens = np.array([9 * n, 17 * n + 5, 30 * n, n, 0, 12 * n + 400])
+    offs = np.array([0, 20000, 90000, 300000, 0, 500000])
+    base = torch.from_numpy(gold.copy())
+    rec = PackedRecordings(base, offs, lens)
+    lst = [base[o:o + m] for o, m in zip(offs, lens)]
+    model = HipSileroVAD(engine=ReplayEngine(oracle))
+    a, b = ragged_probs(rec, model, sr), ragged_probs(lst, model, sr)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    segs = ragged_speech_segments(lst, model, sr, threshold=0.4)
+    counts, flat = ragged_speech_segments(rec, model, sr, threshold=0.4, as_arrays=True)
+    first = np.concatenate([[0], np.cumsum(counts)])
+    assert [[{"start": int(p), "end": int(q)} for p, q in flat[first[i]:first[i + 1]]] for i in range(len(lens))] == segs
+    assert sum(len(s) for s in segs) > 0 and counts[4] == 0
