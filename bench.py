@@ -25,6 +25,7 @@ The same JSON line also carries, for the record (none of them is the headline `v
                             with a 1-in-10^4 recording parity sample checked after the timed region          [any N]
                    plumbing configs[0]: the reference's default usage -- B = 1 `model(chunk, sr).item()` per-call
                             latency (eager and hipGraph) and get_speech_timestamps on the 60 s fixture       [N = 1]
+  other_arithmetic rec_bf16x9: the same C2 workload with the recurrence as exact bf16 x 9 products (opt-in; N = 1)
   roofline         dominant kernel (frontend: STFT + encoder + W_ih GEMM): EXECUTED fp32 MFMA flops per launch /
                    average launch duration (hipEvents recorded by the engine around that kernel on the launch
                    stream during the timed steps) against the dense fp32 MFMA peak; always <= 1
@@ -287,7 +288,7 @@ def time_batch(eng, step, probs, world, dist, dev, steps, warmup):
     return elapsed, front_ms / c, rec_ms / c, ok
 
 
-def run_batch(args, sr, rank, world, local, dist, steps):
+def run_batch(args, sr, rank, world, local, dist, steps, with_other=False):
     import torch
     from silero_vad_amd import Engine
     dev = torch.device("cuda", local)
@@ -306,6 +307,22 @@ def run_batch(args, sr, rank, world, local, dist, steps):
         eng.forward_audio(pcm, sr, ctx, state, probs)
 
     elapsed, front_ms, rec_ms, ok = time_batch(eng, step, probs, world, dist, dev, steps, args.warmup)
+    other = None
+    if with_other and world == 1:
+        # for the record, never the headline: the same workload with the recurrence's W_hh * h as exact bf16 x 9 piece products on
+        # the bf16 matrix pipe (option rec=bf16x9, csrc/kernel_rec_b9.hip) -- the frontend stays the fp32 MFMA chain
+        p_main = probs.clone()
+        eng.set_option("rec", "bf16x9")
+        try:
+            e2, f2, r2, ok2 = time_batch(eng, step, probs, world, dist, dev, steps, args.warmup)
+        finally:
+            eng.set_option("rec", "fp32")
+        other = {"rec_bf16x9": {"what": "recurrence only: three bf16 pieces per operand (exact), nine exact products, fp32 accumulation; "
+                                        "opt-in, a different summation than the fp32 MFMA chain -- not the headline arithmetic",
+                                "value": round(B * T * steps / e2, 1), "unit": "chunks/s", "ms_per_step": round(e2 / steps * 1e3, 4),
+                                "kernel_ms": {"front": round(f2, 4), "rec": round(r2, 4)}, "outputs_finite": ok2,
+                                "max_abs_prob_diff_vs_main": float((probs - p_main).abs().max().item()),
+                                "study": "profiles/r03g_rec_bf16x9_study.json: both recurrences against float64, 8 input sets"}}
     if rank != 0:
         return None
     w = WORK[sr]
@@ -326,6 +343,8 @@ def run_batch(args, sr, rank, world, local, dist, steps):
                             "note": "useful reference work (dense flops, SURVEY 8d) per second per GPU; informational"}
     out["kernel_ms"] = {"front": round(front_ms, 4), "rec": round(rec_ms, 4)}
     out["roofline"] = roofline(sr, B * T, front_ms, rec_ms, B, T)
+    if other:
+        out["other_arithmetic"] = other
     return out
 
 
@@ -736,7 +755,7 @@ def main():
         extras = not args.no_extras
         if args.config in ("c2", "8k"):
             sr = 16000 if args.config == "c2" else 8000
-            out = run_batch(args, sr, rank, world, local, dist, args.steps)
+            out = run_batch(args, sr, rank, world, local, dist, args.steps, with_other=extras and args.config == "c2")
         elif args.config == "stream":
             out = run_stream(args, rank, world, local, dist, args.steps)
         elif args.config == "corpus":

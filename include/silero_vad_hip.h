@@ -78,6 +78,10 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *                 (csrc/kernel_front_f43.hip).  The test build libsilero_vad_hip_ab.so (__graft_entry__.build, -DVAD_AB=1)
  *                 also accepts "winograd2" (two F(2,3) tiles, csrc/kernel_front_wino.hip) and "direct" (tap by tap,
  *                 csrc/kernel_front.hip: bitwise the plain fmaf chain over the taps) as A/B forms for the parity tests
+ *   "rec"       = "fp32" (default) | "bf16x9": how the recurrence evaluates W_hh * h -- as the fp32 MFMA chain, or as the nine
+ *                 exact products of three bf16 pieces per operand (x = p0 + p1 + p2 exactly) on the bf16 matrix pipe with fp32
+ *                 accumulation (csrc/kernel_rec_b9.hip).  Not narrower than fp32 (no operand bit is dropped, every product is
+ *                 exact), but a different summation: opt-in; measured against a float64 recurrence by the GPU suite
  *   "front"     = "auto" (default) | "throughput" | "latency": the frontend has two forms with bit-identical results --
  *                 one wave per 16-chunk tile (csrc/kernel_front_f43.hip: tens of thousands of tiles per launch) and one
  *                 4-wave workgroup per tile (csrc/kernel_front_lat.hip: a stream pool's step, a B = 1 call); "auto" takes
@@ -225,7 +229,8 @@ int  vad_bind_host_to_device(int device);
  * Host-only: size and contents of the packed weight images the kernels consume, so CPU tests can
  * check the fragment packing without a GPU.  which: 0 = frontend GEMM stream (enc0 "direct"), 1 = recurrent
  * W_hh image, 2 = small tables (biases, head, window, twiddles), 5 = frontend stream in Winograd F(2,3) form,
- * 6 = frontend stream in Winograd F(4,3) form (the product's).                                             */
+ * 6 = frontend stream in Winograd F(4,3) form (the product's), 7 = recurrent image as three bf16 pieces per weight
+ * (option rec=bf16x9), returned as raw 4-byte words holding two bf16 each.                                       */
 long vad_debug_packed_floats(const vad_engine *e, int sr, int which);
 int  vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n);
 /* Host-only engine for the hooks above (no device needed).                                       */

@@ -75,6 +75,9 @@ struct RecArgs {
     int B;
 };
 hipError_t launch_rec(int sr, const RecArgs &a, hipStream_t s);
+// The same recurrence with W_hh * h as exact bf16 x 9 piece products on the bf16 matrix pipe (kernel_rec_b9.hip); `whh` points
+// to the three-piece image (layout.hpp "bf16 x 9 recurrent image").  Option "rec" = "bf16x9".
+hipError_t launch_rec_b9(int sr, const RecArgs &a, hipStream_t s);
 
 // Ingest (kernel_ingest.hip): rows[i].len elements (esz bytes each) at rows[i].ptr -- PINNED host memory, or device memory --
 // -> dst[i][0 .. width), zero padded.  `rows` itself is read by the kernel (pinned or device memory).

@@ -31,6 +31,7 @@ struct vad_images {
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
     float *d_front4[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
+    uint16_t *d_whh_b9[2] = {};
 #if VAD_AB
     float *d_front[2] = {}, *d_front_wino[2] = {};
 #endif
@@ -40,6 +41,7 @@ struct vad_images {
         for (int ni = 0; ni < 2; ++ni) {
             if (d_front4[ni]) (void)hipFree(d_front4[ni]);
             if (d_whh[ni]) (void)hipFree(d_whh[ni]);
+            if (d_whh_b9[ni]) (void)hipFree(d_whh_b9[ni]);
             if (d_tables[ni]) (void)hipFree(d_tables[ni]);
 #if VAD_AB
             if (d_front[ni]) (void)hipFree(d_front[ni]);
@@ -58,6 +60,7 @@ struct vad_engine {
     std::string err;
     bool impl_reference = false;
     int enc0 = 2;                                   // fp32 frontend, encoder 0: 2 Winograd F(4,3) (the product); test builds: 0 direct, 1 F(2,3)
+    bool rec_b9 = false;                            // recurrence: fp32 MFMA chain (default) | exact bf16 x 9 products (option "rec")
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the frontend's loads (option "fused_decimation")
     long lat_tiles = 768;                           // launches of at most this many 16-chunk tiles take the latency form of the frontend
@@ -239,7 +242,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         fa.dec = dec;
         fa.trace = e->trace;
         vad::RecArgs ra{};
-        ra.whh = e->img->d_whh[ni];
+        ra.whh = e->rec_b9 ? reinterpret_cast<const float *>(e->img->d_whh_b9[ni]) : e->img->d_whh[ni];
         ra.tables = e->img->d_tables[ni];
         ra.gx = e->d_gx;
         ra.state = state;
@@ -264,7 +267,8 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         if ((long)((B + 15) / 16) * nt <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<PcmT>(sr, fa, stream));
         else HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
-        HIP_TRY(e, vad::launch_rec(sr, ra, stream));
+        if (e->rec_b9) HIP_TRY(e, vad::launch_rec_b9(sr, ra, stream));
+        else HIP_TRY(e, vad::launch_rec(sr, ra, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[2], stream));
     }
     HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -387,6 +391,7 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
         const vad::PackedNet &pk = e->weights->packed[ni];
         if (upload(e, &im.d_front4[ni], pk.front_wino4)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh[ni], pk.whh)) return bail(VAD_ERR_HIP);
+        if (upload(e, &im.d_whh_b9[ni], pk.whh_b9)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_tables[ni], pk.tables)) return bail(VAD_ERR_HIP);
 #if VAD_AB
         if (upload(e, &im.d_front[ni], pk.front)) return bail(VAD_ERR_HIP);
@@ -448,6 +453,7 @@ int vad_clone(const vad_engine *src, vad_engine **out) {
     e->enc0 = src->enc0;
     e->fused_decimation = src->fused_decimation;
     e->lat_tiles = src->lat_tiles;
+    e->rec_b9 = src->rec_b9;
     e->gx_cap = src->gx_cap;
     e->trace = src->trace;
     *out = e;
@@ -477,6 +483,12 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         else return fail(e, VAD_ERR_OPTION, "enc0 must be winograd (the A/B forms winograd2|direct exist only in the test build, "
                                             "libsilero_vad_hip_ab.so)");
 #endif
+        return VAD_OK;
+    }
+    if (n == "rec") {                                // the recurrence's arithmetic: fp32 MFMA chain | exact bf16 x 9 piece products
+        if (v == "fp32") e->rec_b9 = false;
+        else if (v == "bf16x9") e->rec_b9 = true;
+        else return fail(e, VAD_ERR_OPTION, "rec must be fp32|bf16x9");
         return VAD_OK;
     }
     if (n == "front") {                              // which form of the frontend a launch takes (A/B for tests; results are bit-identical)
@@ -585,13 +597,19 @@ long vad_debug_packed_floats(const vad_engine *e, int sr, int which) {
     if (!e || ni < 0) return -1;
     const vad::PackedNet &p = e->weights->packed[ni];
     return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size() : which == 2 ? (long)p.tables.size()
-         : which == 5 ? (long)p.front_wino.size() : which == 6 ? (long)p.front_wino4.size() : -1;
+         : which == 5 ? (long)p.front_wino.size() : which == 6 ? (long)p.front_wino4.size()
+         : which == 7 ? (long)p.whh_b9.size() / 2 : -1;
 }
 
 int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n) {
     const int ni = net_index(sr);
     if (!e || ni < 0 || !dst) return VAD_ERR_ARG;
     const vad::PackedNet &p = e->weights->packed[ni];
+    if (which == 7) {                               // three-piece bf16 image: raw 4-byte words holding two bf16 each
+        if (n != (long)p.whh_b9.size() / 2) return VAD_ERR_ARG;
+        std::memcpy(dst, p.whh_b9.data(), p.whh_b9.size() * sizeof(uint16_t));
+        return VAD_OK;
+    }
     const std::vector<float> *v = which == 0 ? &p.front : which == 1 ? &p.whh : which == 2 ? &p.tables
                                   : which == 5 ? &p.front_wino : which == 6 ? &p.front_wino4 : nullptr;
     if (!v || n != (long)v->size()) return VAD_ERR_ARG;

@@ -126,6 +126,14 @@ constexpr long front_wino4_floats(int Q) { return (long)w4_units(Q) * kWUnitFloa
 // ---- recurrent image: [wave 8][gate 4][kgroup 8][lane 64][4] ------------------------------------
 constexpr long whh_floats() { return 8L * 4 * 8 * 256; }
 
+// ---- bf16 x 9 recurrent image (kernel_rec_b9.hip) -----------------------------------------------------------------
+// Every fp32 weight w is stored as THREE bf16 pieces w = p0 + p1 + p2, exactly (p0 = bf16(w), p1 = bf16(w - p0),
+// p2 = w - p0 - p1: bf16 carries 8 significand bits and fp32's exponent range, so three pieces hold all 24 bits and none
+// underflows), for v_mfma_f32_16x16x32_bf16, whose A and B operands hold 8 bf16 per lane: lane (g, i | j) supplies k-slots
+// (g, e), e < 8.  K32 step u, slot (g, e) <-> hidden unit 32 u + 8 g + e (natural order: the B operand is 8 consecutive
+// h values of a stream).  Image: [wave 8][piece 3][gate 4][u 4][lane 64][8] bf16; wave w owns rows 128 q + 16 w + i.
+constexpr long whh_b9_halfs() { return 8L * 3 * 4 * 4 * 64 * 8; }
+
 // ---- small tables (floats) ----------------------------------------------------------------------
 struct Tab {
     int b_e0, b_e1, b_e2, b_e3, b_g, w_out, b_out, window, tw1, tw2, w_nyq, total;

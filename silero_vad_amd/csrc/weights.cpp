@@ -208,6 +208,34 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
                             t.w_hh[(size_t)(128 * q + 16 * w + i) * 128 + chain_chan(4 * kg + r, gg)];
                     }
 
+    // recurrent image as three bf16 pieces per weight: [wave][piece][gate][u][lane][8] (layout.hpp)
+    p.whh_b9.assign((size_t)whh_b9_halfs(), 0);
+    auto bf16_rne = [](float x) -> uint16_t {
+        uint32_t u;
+        std::memcpy(&u, &x, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);                   // round to nearest even (no NaN / Inf among the weights)
+        return (uint16_t)(u >> 16);
+    };
+    auto bf16_f32 = [](uint16_t h) -> float {
+        const uint32_t u = (uint32_t)h << 16;
+        float x;
+        std::memcpy(&x, &u, 4);
+        return x;
+    };
+    for (int w = 0; w < 8; ++w)
+        for (int q = 0; q < 4; ++q)
+            for (int u = 0; u < 4; ++u)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int gg = lane >> 4, i = lane & 15;
+                        float r = t.w_hh[(size_t)(128 * q + 16 * w + i) * 128 + 32 * u + 8 * gg + e];
+                        for (int piece = 0; piece < 3; ++piece) {
+                            const uint16_t h = bf16_rne(r);
+                            p.whh_b9[((((((size_t)w * 3 + piece) * 4 + q) * 4 + u) * 64 + lane) * 8) + e] = h;
+                            r -= bf16_f32(h);              // exact: the remainder has fewer significant bits than r
+                        }
+                    }
+
     // tables
     const Tab tb = make_tab(g.F, Q);
     p.tables.assign((size_t)tb.total, 0.f);

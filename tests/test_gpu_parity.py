@@ -1258,3 +1258,113 @@ def test_latency_frontend_serves_small_launches(model, golden):
     json.dump({"front_ms_8192_streams_one_step": times}, open("gpurun_out/latency_frontend.json", "w"), indent=1)
     assert times["latency"] < 0.75 * times["throughput"], times
     assert times["auto"] < 0.75 * times["throughput"], times
+
+
+# ---- (15) the recurrence as exact bf16 x 9 products ----------------------------------------------------------------------
+def _recurrence_f64(gx, W_hh, w_out, b_out):
+    """The LSTM cell + head over gx[B, T, 512] (= W_ih x + b_ih + b_hh, taken as exact input) in float64, zero initial state."""
+    B, T, _ = gx.shape
+    h = np.zeros((B, 128)); c = np.zeros((B, 128))
+    probs = np.zeros((B, T))
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    for t in range(T):
+        g = gx[:, t].astype(np.float64) + h @ W_hh.T
+        i, f, gg, o = sig(g[:, :128]), sig(g[:, 128:256]), np.tanh(g[:, 256:384]), sig(g[:, 384:])
+        c = f * c + i * gg
+        h = o * np.tanh(c)
+        probs[:, t] = sig(np.maximum(h, 0.0) @ w_out + b_out)
+    return probs, np.stack([h, c])
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_rec_bf16x9_against_float64(model, oracle, golden, tag):
+    """Option rec=bf16x9 (csrc/kernel_rec_b9.hip: three bf16 pieces per operand, nine exact products, fp32 accumulation on the
+    bf16 matrix pipe) against the fp32 MFMA recurrence, both measured against a FLOAT64 evaluation of the recurrence on the
+    frontend's own gate pre-activations: 64 streams x 256 steps (the C2 / C3 time depth) of full-level speech, quiet speech
+    (x 1e-3), the synthetic mix and the adversarial set.  The claim "not narrower than fp32" is held to numbers: both kernels
+    sit within a few 1e-6 of float64 (the activations' v_exp / v_rcp error, common to both, dominates), the bf16 x 9 kernel's
+    error -- probabilities and final (h, c) -- must stay within a factor of two of the fp32 chain's own (plus 3e-7) on every
+    set, and it must meet the oracle like everything else.  The measured pairs go to gpurun_out/rec_bf16x9_study.json."""
+    import json
+    import os
+    from oracle.weights import read_container
+    from silero_vad_amd import _lib
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    eng = model.engine
+    Wt = read_container(_lib.WEIGHTS_PATH.read_bytes())
+    pre = "_model" if sr == 16000 else "_model_8k"
+    W_hh = Wt[pre + ".decoder.rnn.weight_hh"].astype(np.float64)
+    w_out = Wt[pre + ".decoder.decoder.2.weight"].reshape(128).astype(np.float64)
+    b_out = float(Wt[pre + ".decoder.decoder.2.bias"].reshape(-1)[0])
+    T = 256
+    sets = {"speech": rolled_rows(g["wav"], 64, T * n, 7919),
+            "quiet_speech": (rolled_rows(g["wav"], 64, T * n, 4001) * 1e-3).astype(np.float32),
+            "synthetic": rolled_rows(synthetic_audio(sr, np.random.default_rng(42)), 64, T * n, 4001),
+            "adversarial": _adversarial(sr, T)[1]}
+    report = {}
+    for name, rows in sets.items():
+        x = torch.from_numpy(rows).to(model.device)
+        B = x.shape[0]
+        gx = eng.debug_frontend(x, sr, torch.zeros((B, n // 8), device=model.device)).cpu().numpy()
+        p64, s64 = _recurrence_f64(gx, W_hh, w_out, b_out)
+        want, _, wst = oracle.forward_audio(rows, sr)
+        err = {}
+        for arith in ("fp32", "bf16x9"):
+            eng.set_option("rec", arith)
+            try:
+                p, _, st = run_engine(model, rows, sr)
+            finally:
+                eng.set_option("rec", "fp32")
+            # (against the fp32 ORACLE the quiet and the adversarial sets sit higher than the rest whatever the kernel: over 256 steps
+            #  two valid fp32 evaluations of this network differ by up to 3.5e-5 / 1.5e-4 on quiet input, the tap-by-tap form
+            #  included -- profiles/r03g_quiet_levels.md)
+            loose = name in ("quiet_speech", "adversarial")
+            assert np.abs(p - want).max() < (TOL if loose else TIGHT), (name, arith)
+            assert state_err(st, wst) < (5e-4 if loose else TOL), (name, arith)
+            err[arith] = {"max_abs_dp_vs_f64": float(np.abs(p - p64).max()), "state_err_vs_f64": state_err(st, s64)}
+        report[name] = err
+        assert err["bf16x9"]["max_abs_dp_vs_f64"] <= 2.0 * err["fp32"]["max_abs_dp_vs_f64"] + 3e-7, (name, err)
+        assert err["bf16x9"]["state_err_vs_f64"] <= 2.0 * err["fp32"]["state_err_vs_f64"] + 3e-7, (name, err)
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = "gpurun_out/rec_bf16x9_study.json"
+    prev = json.load(open(path)) if os.path.exists(path) else {}
+    prev[tag] = report
+    json.dump(prev, open(path, "w"), indent=1)
+
+
+def test_rec_bf16x9_is_faster_and_bit_stable(model, golden):
+    """The point of the exercise: at the C2 shape the bf16 x 9 recurrence must be clearly faster than the fp32 one (its
+    matrix work is 0.56 of the cycles and the VALU runs beside it), and repeated launches must be bit-identical."""
+    import json
+    import os
+    eng = model.engine
+    sr, n, B, T = 16000, 512, 4096, 256
+    x = _strided_rows(torch.from_numpy(golden["16k"]["wav"]).to(model.device), B, T * n, 7919)
+    times, outs = {}, {}
+    for arith in ("fp32", "bf16x9"):
+        eng.set_option("rec", arith)
+        try:
+            def run():
+                ctx = torch.zeros((B, n // 8), device=model.device)
+                st = torch.zeros((2, B, 128), device=model.device)
+                p = eng.forward_audio(x, sr, ctx, st)
+                return p, st
+            for _ in range(3):
+                run()
+            eng.set_option("profile", "1")
+            p0, s0 = run()
+            for _ in range(4):
+                p, s = run()
+                assert torch.equal(p, p0) and torch.equal(s, s0), arith
+            f, r, c = eng.kernel_times()
+            eng.set_option("profile", "0")
+            times[arith] = r / c
+            outs[arith] = p0
+        finally:
+            eng.set_option("rec", "fp32")
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"rec_ms_c2": times, "max_abs_dp_between": float((outs["fp32"] - outs["bf16x9"]).abs().max())},
+              open("gpurun_out/rec_bf16x9_timing.json", "w"), indent=1)
+    assert float((outs["fp32"] - outs["bf16x9"]).abs().max()) < 5e-6
+    assert times["bf16x9"] < 0.8 * times["fp32"], times

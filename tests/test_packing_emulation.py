@@ -101,3 +101,29 @@ def test_mfma_emulation_is_transpose_detecting():
     for lane in range(64):
         for r in range(4):
             assert abs(acc[r, lane] - D[4 * (lane >> 4) + r, lane & 15]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_bf16x9_recurrent_image_is_exact(built, tag):
+    """The three-piece bf16 image of W_hh (option rec=bf16x9, csrc/kernel_rec_b9.hip): the pieces of every weight add up to
+    the fp32 weight EXACTLY, each piece is a bf16 (low 16 bits of its fp32 pattern are zero), and slot (g, e) of K32 step u
+    of wave w, gate q, row i holds W_hh[128 q + 16 w + i][32 u + 8 g + e]."""
+    from oracle.weights import read_container
+    from silero_vad_amd import _lib
+    sr = SRS[tag]
+    L = _lib.lib()
+    blob = _lib.WEIGHTS_PATH.read_bytes()
+    h = ctypes.c_void_p()
+    assert L.vad_create_host_only(blob, len(blob), ctypes.byref(h)) == 0
+    n = L.vad_debug_packed_floats(h, sr, 7)
+    raw = np.empty(n, np.float32)
+    assert L.vad_debug_packed_copy(h, sr, 7, raw.ctypes.data_as(_lib.f32p), n) == 0
+    L.vad_destroy(h)
+    img = raw.view(np.uint16).reshape(8, 3, 4, 4, 64, 8)                   # [wave][piece][gate][u][lane][e]
+    pieces = (img.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    W = read_container(blob)[("_model" if sr == 16000 else "_model_8k") + ".decoder.rnn.weight_hh"].astype(np.float64)
+    w, q, u, lane, e = np.meshgrid(np.arange(8), np.arange(4), np.arange(4), np.arange(64), np.arange(8), indexing="ij")
+    want = W[128 * q + 16 * w + (lane & 15), 32 * u + 8 * (lane >> 4) + e]
+    assert np.array_equal(pieces.sum(1), want)                              # exact: float64 holds the three pieces' sum
+    assert np.all(np.abs(pieces[:, 1]) <= np.abs(pieces[:, 0]) * 2.0 ** -8 + 1e-45)
+    assert np.all(np.abs(pieces[:, 2]) <= np.abs(pieces[:, 0]) * 2.0 ** -16 + 1e-45)

@@ -18,7 +18,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
-HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_rec.hip", "kernels_ref.hip", "kernel_scan.hip", "kernel_ingest.hip"]
+HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_rec.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
+       "kernel_ingest.hip"]
 CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
 VARIANTS = {
@@ -90,7 +91,7 @@ def build(names):
     shared.mkdir(exist_ok=True)
     procs = []
     # translation units without knobs are compiled once
-    knob_units = {"kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_rec.hip"}
+    knob_units = {"kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_rec.hip", "kernel_rec_b9.hip"}
     for src in HIP + CPP:
         if src in knob_units:
             continue
