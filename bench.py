@@ -400,8 +400,17 @@ def run_stream(args, rank, world, local, dist, steps):
     out["tick_latency_ms"] = {"median": round(lat[len(lat) // 2], 4), "p95": round(lat[int(len(lat) * 0.95)], 4),
                               "budget_ms": 32.0}
     c = max(calls, 1)
-    out["kernel_ms"] = {"front": round(front_ms / c, 4), "rec": round(rec_ms / c, 4)}
-    out["roofline"] = roofline(sr, cap, front_ms / c, rec_ms / c, cap, 1)
+    out["kernel_ms"] = {"front": round(front_ms / c, 4), "rec": round(rec_ms / c, 4),
+                        "note": "one step in ONE kernel (latency frontend + LSTM cell + head, csrc/kernel_front_lat.hip): `front` is that kernel, "
+                                "`rec` only the gap between the two event records"}
+    rl = roofline(sr, cap, front_ms / c, 0.0, cap, 1)
+    # the fused kernel executes the frontend's AND the recurrence's matrix flops
+    w = WORK[sr]
+    fl = cap * (w["front_mfma"] + w["rec_mfma"])
+    rl.update({"kernel": "front_lat_kernel<32, float, 1, true> (frontend + LSTM cell + head)", "flop_per_launch": fl,
+               "achieved": round(fl / (front_ms / c / 1e3) / 1e12, 3)})
+    rl["frac"] = round(rl["achieved"] / PEAK_F32_TFLOPS, 4)
+    out["roofline"] = rl
     return out
 
 

@@ -86,6 +86,9 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *                 one wave per 16-chunk tile (csrc/kernel_front_f43.hip: tens of thousands of tiles per launch) and one
  *                 4-wave workgroup per tile (csrc/kernel_front_lat.hip: a stream pool's step, a B = 1 call); "auto" takes
  *                 the latency form for launches of at most 768 tiles.  The other two values force one form (tests)
+ *   "fuse_step" = "1" (default) | "0": a ONE-step call that takes the latency form (vad_step of a stream pool, a B = 1 call)
+ *                 runs the LSTM cell and the head inside the frontend's kernel -- no second launch, no trip of the gate
+ *                 pre-activations through HBM; bit-identical to the two-kernel path ("0": force that, A/B for tests)
  *   "fused_decimation" = "1" (default) | "0": for sr = 32000 and 48000 the fp32 frontend reads every 2nd / 3rd sample
  *                 itself; "0" forces the separate decimation pass that the higher multiples of 16000 use (A/B for tests)
  *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)

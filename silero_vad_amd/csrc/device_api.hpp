@@ -58,6 +58,17 @@ hipError_t launch_front_f43(int sr, const FrontArgs &a, hipStream_t s);
 // split over the waves; bit-identical results.  For launches of a few hundred tiles (one step of a stream pool, a B = 1 call).
 template <typename PcmT>
 hipError_t launch_front_lat(int sr, const FrontArgs &a, hipStream_t s);
+// ONE step (nt == 1) with the LSTM cell and the head fused behind the latency frontend: no gx round trip, no second kernel.  The
+// workgroup of a tile applies W_hh (image `whh_lat`: gate by gate in W_ih's block order) to h_{t-1}, exchanges the four gates through
+// LDS, updates (h, c) in `state` in place and writes the tile's 16 probabilities.  Bit-identical to front + rec_kernel.
+struct CellArgs {
+    const float *whh_lat;    // [gate 4][kg 8][row block 8][lane 64][4]
+    float *state;            // [2][B][128] in/out
+    float *probs;            // [B][ldp], this step's column is t0
+    long ldp;
+};
+template <typename PcmT>
+hipError_t launch_step_lat(int sr, const FrontArgs &a, const CellArgs &c, hipStream_t s);
 // Same function, encoder 0 as two Winograd F(2,3) tiles over the frame pairs, straight-line code (kernel_front_wino.hip);
 // `wfront` points to the F(2,3) image (layout.hpp w_* units).  A/B form, test builds only (VAD_AB; option enc0=winograd2).
 template <typename PcmT>

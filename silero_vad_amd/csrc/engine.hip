@@ -30,7 +30,7 @@ struct vad_images {
     int device = -1;
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
-    float *d_front4[2] = {}, *d_whh[2] = {}, *d_tables[2] = {};
+    float *d_front4[2] = {}, *d_whh[2] = {}, *d_whh_lat[2] = {}, *d_tables[2] = {};
     uint16_t *d_whh_b9[2] = {};
 #if VAD_AB
     float *d_front[2] = {}, *d_front_wino[2] = {};
@@ -42,6 +42,7 @@ struct vad_images {
             if (d_front4[ni]) (void)hipFree(d_front4[ni]);
             if (d_whh[ni]) (void)hipFree(d_whh[ni]);
             if (d_whh_b9[ni]) (void)hipFree(d_whh_b9[ni]);
+            if (d_whh_lat[ni]) (void)hipFree(d_whh_lat[ni]);
             if (d_tables[ni]) (void)hipFree(d_tables[ni]);
 #if VAD_AB
             if (d_front[ni]) (void)hipFree(d_front[ni]);
@@ -60,6 +61,8 @@ struct vad_engine {
     std::string err;
     bool impl_reference = false;
     int enc0 = 2;                                   // fp32 frontend, encoder 0: 2 Winograd F(4,3) (the product); test builds: 0 direct, 1 F(2,3)
+    bool fuse_step = true;                          // a ONE-step call small enough for the latency frontend runs the LSTM cell and the head in
+                                                    // the same kernel (option "fuse_step")
     bool rec_b9 = false;                            // recurrence: fp32 MFMA chain (default) | exact bf16 x 9 products (option "rec")
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the frontend's loads (option "fused_decimation")
@@ -259,12 +262,27 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             e->ev_used += 3;
             HIP_TRY(e, hipEventRecord(ev[0], stream));
         }
+        const long tiles = (long)((B + 15) / 16) * nt;
+        if (T == 1 && e->fuse_step && !e->rec_b9 && e->enc0 == 2 && tiles <= e->lat_tiles) {
+            // one step, few tiles (a stream pool's tick, a B = 1 call): frontend, LSTM cell and head in ONE kernel, no gx round trip
+            vad::CellArgs ca{};
+            ca.whh_lat = e->img->d_whh_lat[ni];
+            ca.state = state;
+            ca.probs = probs;
+            ca.ldp = ldp;
+            HIP_TRY(e, vad::launch_step_lat<PcmT>(sr, fa, ca, stream));
+            if (prof) {
+                HIP_TRY(e, hipEventRecord(ev[1], stream));
+                HIP_TRY(e, hipEventRecord(ev[2], stream));
+            }
+            continue;
+        }
 #if VAD_AB
         if (e->enc0 == 1) HIP_TRY(e, vad::launch_front_wino<PcmT>(sr, fa, stream));
         else if (e->enc0 == 0) HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
         else
 #endif
-        if ((long)((B + 15) / 16) * nt <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<PcmT>(sr, fa, stream));
+        if (tiles <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<PcmT>(sr, fa, stream));
         else HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
         if (e->rec_b9) HIP_TRY(e, vad::launch_rec_b9(sr, ra, stream));
@@ -392,6 +410,7 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
         if (upload(e, &im.d_front4[ni], pk.front_wino4)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh[ni], pk.whh)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_b9[ni], pk.whh_b9)) return bail(VAD_ERR_HIP);
+        if (upload(e, &im.d_whh_lat[ni], pk.whh_lat)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_tables[ni], pk.tables)) return bail(VAD_ERR_HIP);
 #if VAD_AB
         if (upload(e, &im.d_front[ni], pk.front)) return bail(VAD_ERR_HIP);
@@ -454,6 +473,7 @@ int vad_clone(const vad_engine *src, vad_engine **out) {
     e->fused_decimation = src->fused_decimation;
     e->lat_tiles = src->lat_tiles;
     e->rec_b9 = src->rec_b9;
+    e->fuse_step = src->fuse_step;
     e->gx_cap = src->gx_cap;
     e->trace = src->trace;
     *out = e;
@@ -489,6 +509,10 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         if (v == "fp32") e->rec_b9 = false;
         else if (v == "bf16x9") e->rec_b9 = true;
         else return fail(e, VAD_ERR_OPTION, "rec must be fp32|bf16x9");
+        return VAD_OK;
+    }
+    if (n == "fuse_step") {                          // "0": a one-step call runs frontend and recurrence as two kernels (A/B for tests)
+        e->fuse_step = (v != "0");
         return VAD_OK;
     }
     if (n == "front") {                              // which form of the frontend a launch takes (A/B for tests; results are bit-identical)

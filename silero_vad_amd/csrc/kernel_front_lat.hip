@@ -29,6 +29,7 @@
 // and everything a wave waits for first (its PCM slice, the head of its stream, the tables) is requested before anything else.
 #include <hip/hip_runtime.h>
 
+#include "activations.hpp"
 #include "front_common.hpp"
 
 namespace vad {
@@ -105,15 +106,16 @@ constexpr E1Blk e1_blk(int Q, int idx) {
 #ifndef VAD_LAT_WG_PER_CU
 #define VAD_LAT_WG_PER_CU 1
 #endif
-template <int Q, typename PcmT, int DEC>
-__global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const FrontArgs a) {
+template <int Q, typename PcmT, int DEC, bool CELL>
+__global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const FrontArgs a, const CellArgs cell) {
     using namespace vadl;
     constexpr Tab tb = make_tab(8 * Q, Q);
     constexpr int TABF = (tb.total + 3) / 4 * 4;
     constexpr int RB = w_rb(Q), KG0 = Q / 4, T0 = w4_tail0(Q);
     constexpr int NB0 = 2 * KG0;                                 // blocks of one encoder-0 matrix for one wave (2 row blocks)
     // the wave's block stream: encoder 0 (6 matrices), encoder 1 (40 blocks), encoder 2 (8), encoder 3 (8), W_ih (64)
-    constexpr int S_E1 = 6 * NB0, S_E2 = S_E1 + 40, S_E3 = S_E2 + 8, S_IH = S_E3 + 8, S_END = S_IH + 64;
+    // and, in the fused single-step form (CELL), W_hh of the wave's gate (64)
+    constexpr int S_E1 = 6 * NB0, S_E2 = S_E1 + 40, S_E3 = S_E2 + 8, S_IH = S_E3 + 8, S_HH = S_IH + 64, S_END = S_HH + (CELL ? 64 : 0);
     __shared__ __attribute__((aligned(16))) float tab[TABF];
     // (the STFT magnitudes are dead once every wave has them in registers: encoder 0's output takes their place)
     constexpr int XSF = 4 * (Q + 1) * 64, YBF = 4 * 8 * 256;
@@ -148,6 +150,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     const float *e0 = lane_w + (size_t)u_e0 * 4096 + rb0 * 256;              // + j * 4096 + (kg * RB + r) * 256
     const float *e3 = lane_w + (size_t)(T0 + 2) * 4096 + (2 * w) * 256;      // encoder 3: [kg 4][rb 8], this wave's row blocks 2w, 2w + 1
     const float *ih = lane_w + (size_t)(T0 + 4 + 4 * w) * 4096;              // W_ih, gate w: [kg 8][rb 8], 64 consecutive blocks
+    const float *hh = CELL ? cell.whh_lat + ln.lane * 4 + (size_t)w * 64 * 256 : nullptr;   // W_hh, gate w, the same order
     // block g of this wave's stream (g is a compile-time constant at every call site)
     auto gload = [&](auto gc) VAD_INLINE -> f32x4 {
         constexpr int g = IC(gc);
@@ -163,8 +166,10 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
         } else if constexpr (g < S_IH) {
             constexpr int i = g - S_E3;
             return ld_blk(e3, (long)(i >> 1) * 8 + (i & 1));
-        } else if constexpr (g < S_END) {
+        } else if constexpr (g < S_HH) {
             return ld_blk(ih, g - S_IH);
+        } else if constexpr (g < S_END) {
+            return ld_blk(hh, g - S_HH);
         } else {
             return f32x4{0.f, 0.f, 0.f, 0.f};                     // past the end of the program
         }
@@ -173,6 +178,12 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     // ---- everything this wave will wait for first is requested first: its PCM slice, the head of its weight stream, the tables
     float pcm_s[2 * Q];
     if (!(VAD_LAT_ABLATE & 2)) load_slice<Q, PcmT, DEC>(pcm_s, a, ln, w);          // wave v owns STFT frame v
+    f32x4 Hp[CELL ? 8 : 1];                                      // fused step: h_{t-1}, units 16 m + 4 g + r of stream j
+    if constexpr (CELL) {
+        const float *hsrc = cell.state + (size_t)ln.b * 128 + 4 * ln.g;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) Hp[m] = *reinterpret_cast<const f32x4 *>(hsrc + 16 * m);
+    }
     Pipe pp;
     static_for<0, kD>([&](auto ic) VAD_INLINE { pp.q[IC(ic)] = gload(ic); });
     {   // tables -> LDS: all loads of a thread are issued before the first is stored
@@ -355,27 +366,88 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     init_bias<8>(G, tab + tb.b_g + 128 * w, ln);
     run_segment<S_IH, 64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
                              [&](auto kg) VAD_INLINE { return Fe[IC(kg)]; }, gload);
-    float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32 + 8 * w) * 256 + ln.lane * 4;
+    if constexpr (!CELL) {
+        float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32 + 8 * w) * 256 + ln.lane * 4;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) *reinterpret_cast<f32x4 *>(gxt + (size_t)m * 256) = G[m];
+        for (int m = 0; m < 8; ++m) *reinterpret_cast<f32x4 *>(gxt + (size_t)m * 256) = G[m];
+    } else {
+        // ---- the LSTM cell and the head, fused (one step: a.nt == 1).  Same sums in the same order as kernel_rec.hip: the gate
+        // accumulators continue from W_ih x + b into W_hh h_{t-1}, k-groups ascending; same pointwise formulas; the head's 8 partial
+        // sums (one per 16-unit row block) are added in the same order.  (reference: aten::lstm_cell, JIT!/torch/nn/modules/rnn.py:69)
+        __shared__ __attribute__((aligned(16))) float gbuf[4][8][256];          // gates: [gate][row block][lane][4]
+        __shared__ float pb[8 * 16];                                              // head partial sums: [row block][stream]
+        const bool valid = bb < a.B;
+        run_segment<S_HH, 64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
+                                 [&](auto kg) VAD_INLINE { return Hp[IC(kg)]; }, gload);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) *reinterpret_cast<f32x4 *>(&gbuf[w][m][ln.lane * 4]) = G[m];
+        lds_barrier();
+        // wave w finishes the 32 hidden units of row blocks 2w, 2w + 1
+        const float bo = tab[tb.b_out];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int rb = 2 * w + m;
+            const f32x4 gi = *reinterpret_cast<const f32x4 *>(&gbuf[0][rb][ln.lane * 4]);
+            const f32x4 gf = *reinterpret_cast<const f32x4 *>(&gbuf[1][rb][ln.lane * 4]);
+            const f32x4 gg = *reinterpret_cast<const f32x4 *>(&gbuf[2][rb][ln.lane * 4]);
+            const f32x4 go = *reinterpret_cast<const f32x4 *>(&gbuf[3][rb][ln.lane * 4]);
+            const size_t soff = (size_t)ln.b * 128 + 16 * rb + 4 * ln.g;
+            f32x4 c = *reinterpret_cast<const f32x4 *>(cell.state + (size_t)a.B * 128 + soff);
+            const f32x4 wo = *reinterpret_cast<const f32x4 *>(tab + tb.w_out + 16 * rb + 4 * ln.g);
+            f32x4 h;
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = sigmoid_f(gi[r]), fg = sigmoid_f(gf[r]), gt = tanh_f(gg[r]);
+                const float cn = fmaf(fg, c[r], ig * gt);
+                c[r] = cn;
+                h[r] = sigmoid_f(go[r]) * tanh_f(cn);
+                part = fmaf(wo[r], fmaxf(h[r], 0.f), part);
+            }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            if (ln.g == 0) pb[rb * 16 + ln.j] = part;
+            if (valid) {
+                *reinterpret_cast<f32x4 *>(cell.state + soff) = h;
+                *reinterpret_cast<f32x4 *>(cell.state + (size_t)a.B * 128 + soff) = c;
+            }
+        }
+        lds_barrier();
+        if (w == 0 && ln.g == 0 && valid) {
+            float p = bo;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) p += pb[ww * 16 + ln.j];
+            cell.probs[(size_t)bb * cell.ldp + a.t0] = sigmoid_f(p);
+        }
+    }
 }
 
 }  // namespace
 
-template <typename PcmT>
-hipError_t launch_front_lat(int sr, const FrontArgs &a, hipStream_t s) {
+template <typename PcmT, bool CELL>
+static hipError_t launch_lat(int sr, const FrontArgs &a, const CellArgs &c, hipStream_t s) {
     if (a.B <= 0 || a.nt <= 0) return hipSuccess;
     const long nst = (a.B + 15) / 16, total = nst * a.nt;
-    if (total > 0x7fffffffL) return hipErrorInvalidValue;
+    if (total > 0x7fffffffL || (CELL && a.nt != 1)) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)total;
     if (a.dec > 1 && (sr != 16000 || a.dec > 3)) return hipErrorInvalidValue;
-    if (a.dec == 3) hipLaunchKernelGGL((front_lat_kernel<32, PcmT, 3>), dim3(grid), dim3(256), 0, s, a);
-    else if (a.dec == 2) hipLaunchKernelGGL((front_lat_kernel<32, PcmT, 2>), dim3(grid), dim3(256), 0, s, a);
-    else if (sr == 16000) hipLaunchKernelGGL((front_lat_kernel<32, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((front_lat_kernel<16, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
+    if (a.dec == 3) hipLaunchKernelGGL((front_lat_kernel<32, PcmT, 3, CELL>), dim3(grid), dim3(256), 0, s, a, c);
+    else if (a.dec == 2) hipLaunchKernelGGL((front_lat_kernel<32, PcmT, 2, CELL>), dim3(grid), dim3(256), 0, s, a, c);
+    else if (sr == 16000) hipLaunchKernelGGL((front_lat_kernel<32, PcmT, 1, CELL>), dim3(grid), dim3(256), 0, s, a, c);
+    else hipLaunchKernelGGL((front_lat_kernel<16, PcmT, 1, CELL>), dim3(grid), dim3(256), 0, s, a, c);
     return hipGetLastError();
+}
+template <typename PcmT>
+hipError_t launch_front_lat(int sr, const FrontArgs &a, hipStream_t s) {
+    return launch_lat<PcmT, false>(sr, a, CellArgs{}, s);
+}
+template <typename PcmT>
+hipError_t launch_step_lat(int sr, const FrontArgs &a, const CellArgs &c, hipStream_t s) {
+    return launch_lat<PcmT, true>(sr, a, c, s);
 }
 template hipError_t launch_front_lat<float>(int, const FrontArgs &, hipStream_t);
 template hipError_t launch_front_lat<int16_t>(int, const FrontArgs &, hipStream_t);
+template hipError_t launch_step_lat<float>(int, const FrontArgs &, const CellArgs &, hipStream_t);
+template hipError_t launch_step_lat<int16_t>(int, const FrontArgs &, const CellArgs &, hipStream_t);
 
 }  // namespace vad

@@ -208,6 +208,14 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
                             t.w_hh[(size_t)(128 * q + 16 * w + i) * 128 + chain_chan(4 * kg + r, gg)];
                     }
 
+    // recurrent weights in W_ih's order, gate by gate: [gate][kg][row block][lane][4] -- the fused single-step kernel appends them to a
+    // wave's weight stream (kernel_front_lat.hip); same k order per row block as the recurrent image above, so the sums are the same
+    p.whh_lat.assign((size_t)4 * 64 * 256, 0.f);
+    for (int q = 0; q < 4; ++q)
+        pack_segment(p.whh_lat.data() + (size_t)q * 64 * 256, 8, 32, [&](int row, int s, int gg) {
+            return t.w_hh[((size_t)(128 * q + row)) * 128 + chain_chan(s, gg)];
+        });
+
     // recurrent image as three bf16 pieces per weight: [wave][piece][gate][u][lane][8] (layout.hpp)
     p.whh_b9.assign((size_t)whh_b9_halfs(), 0);
     auto bf16_rne = [](float x) -> uint16_t {

@@ -26,6 +26,7 @@ struct PackedNet {
     std::vector<float> front_wino;   // frontend stream with enc0 in Winograd F(2,3) form (layout.hpp w_* units)
     std::vector<float> front_wino4;  // the same with enc0 as one F(4,3) tile, units in program order (layout.hpp w4_*)
     std::vector<float> whh;      // recurrent image
+    std::vector<float> whh_lat;  // recurrent weights gate by gate in W_ih's block order [gate][kg 8][row block 8][lane][4] (kernel_front_lat.hip, fused step)
     std::vector<uint16_t> whh_b9;    // recurrent image as three bf16 pieces per weight (layout.hpp "bf16 x 9 recurrent image")
     std::vector<float> tables;   // biases, head, window, twiddles, Nyquist-bin weights
 };
