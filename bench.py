@@ -104,6 +104,12 @@ def setup_dist(args):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if args.dry:
             dist.init_process_group("gloo")
+        elif os.environ.get("VAD_BENCH_SHARE_GPU"):
+            # FUNCTIONAL test of the N > 1 legs on a box with ONE GPU (tests/test_gpu_parity.py): every rank drives device 0, the
+            # barrier / MAX-reduce / gather go through gloo (RCCL refuses two ranks on one device).  Not a measurement.
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -124,7 +130,7 @@ def timed(world, dist, dev, steps, fn, sync):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     return elapsed
@@ -796,6 +802,8 @@ def main():
     if rank == 0:
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if os.environ.get("VAD_BENCH_SHARE_GPU") and world > 1:
+            out["data"] = "synthetic; FUNCTIONAL run of the multi-rank legs with all ranks on ONE GPU (gloo) -- not a measurement"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1413,3 +1413,34 @@ def test_fused_step_is_bit_identical(model, oracle, golden, tag):
     wav = torch.from_numpy(g["wav"])
     got = [model(wav[s:s + n], sr).item() for s in range(0, 30 * n, n)]
     assert np.abs(np.array(got) - g["probs_wav"][:30]).max() < TIGHT
+
+
+# ---- (17) the multi-rank legs of bench.py, functionally, on the one GPU a test box has ----------------------------------------------
+def test_bench_multi_rank_legs_run_on_shared_gpu(built):
+    """`bench.py --gpus 2 --config corpus` and `--config stream` with both ranks on device 0 (VAD_BENCH_SHARE_GPU: gloo for the
+    barrier / MAX-reduce / gather, since RCCL refuses two ranks on one device): the N > 1 code of the legs -- rank-aware host
+    threads, sharding by duration, per-rank arenas, the gather of the result arrays to rank 0 inside the timed region, the parity
+    sample -- executes on real hardware end to end.  Throughput means nothing here (two processes share one GPU); what is asserted
+    is that the line comes out, names 2 ranks, gathered every rank's segments and kept parity."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VAD_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--config", "corpus", "--corpus-passes", "2",
+                        "--recordings", "1024", "--corpus-main-only", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    main = d["legs"]["main"]
+    assert d["n_gpus"] == 2 and d["config"]["host_threads_per_rank"] >= 1
+    assert main["segments_gathered_all_ranks"] is not None and main["segments_gathered_all_ranks"] >= main["segments_found_rank0"] > 0
+    assert d["parity_sample"]["segments_identical_to_oracle_scan"] and d["parity_sample_max_abs_dp"] < TOL
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--config", "stream", "--steps", "50", "--live", "1024",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert d["n_gpus"] == 2 and d["outputs_finite"] and d["value"] > 0
