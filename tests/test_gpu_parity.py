@@ -1270,7 +1270,7 @@ def _recurrence_f64(gx, W_hh, w_out, b_out):
     B, T, _ = gx.shape
     h = np.zeros((B, 128)); c = np.zeros((B, 128))
     probs = np.zeros((B, T))
-    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    sig = lambda v: 1.0 / (1.0 + np.exp(-np.clip(v, -700.0, 700.0)))
     for t in range(T):
         g = gx[:, t].astype(np.float64) + h @ W_hh.T
         i, f, gg, o = sig(g[:, :128]), sig(g[:, 128:256]), np.tanh(g[:, 256:384]), sig(g[:, 384:])
@@ -1444,3 +1444,82 @@ def test_bench_multi_rank_legs_run_on_shared_gpu(built):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
     assert d["n_gpus"] == 2 and d["outputs_finite"] and d["value"] > 0
+
+
+# ---- (18) edges of the new paths ----------------------------------------------------------------------------------------------------
+def test_corpus_edges_float_arena_empty_recordings_8k(model, oracle, golden):
+    """The window route with a FLOAT32 arena, recordings of length 0 and shorter than one chunk inside it, at 8 kHz: every
+    recording gets what a single `audio_forward` gives it; empty ones get nothing."""
+    from silero_vad_amd import PackedRecordings, ragged_probs, ragged_speech_segments
+    sr, n = 8000, 256
+    wav = golden["8k"]["wav"]
+    lens = np.array([5 * n, 0, 17, 40 * n + 3, n, 0, 23 * n, 9 * n + 100, 1])
+    offs = np.concatenate([[0], np.cumsum((lens + 3) // 4 * 4)[:-1]])
+    arena = torch.zeros(int(offs[-1] + lens[-1]) + 16, dtype=torch.float32).pin_memory()
+    for o, m in zip(offs, lens):
+        arena[o:o + m] = torch.from_numpy(wav[7 * o:7 * o + m].copy())
+    rec = PackedRecordings(arena, offs, lens)
+    got = ragged_probs(rec, model, sr, max_waste=0.5)
+    for o, m, p in zip(offs, lens, got):
+        if m == 0:
+            assert p.numel() == 0
+            continue
+        a = arena[o:o + m].numpy()
+        want = oracle.audio_forward(np.pad(a, (0, max(0, n - m)))[None], sr)[0]
+        assert p.shape == want.shape and np.abs(p.numpy() - want).max() < TIGHT
+    counts, segs = ragged_speech_segments(rec, model, sr, threshold=0.3, min_speech_duration_ms=64, as_arrays=True)
+    assert counts[1] == counts[5] == 0 and counts.sum() == len(segs) and counts.sum() > 0
+
+
+def test_step_paths_by_size(model, oracle, golden):
+    """`vad_step` picks its kernels by size -- the fused one-kernel step up to 768 tiles, the throughput frontend + recurrence
+    above -- and an engine with the bf16 x 9 recurrence keeps frontend and recurrence apart: all of them against the oracle,
+    the fp32 ones bit for bit against each other on the streams they share."""
+    eng = model.engine
+    sr, n = 16000, 512
+    base = rolled_rows(golden["16k"]["wav"], 64, 3 * n, 977)
+    want, _, _ = oracle.forward_audio(base, sr)
+    ref = None
+    for B in (64, 12288 + 16):                                  # 4 tiles (fused) / 769 tiles (throughput form + recurrence)
+        x = torch.from_numpy(base).repeat(B // 64 + 1, 1)[:B].contiguous().to(model.device)
+        ctx = torch.zeros((B, 64), device=model.device)
+        st = torch.zeros((2, B, 128), device=model.device)
+        ps = []
+        for t in range(3):
+            p = torch.empty((B, 1), device=model.device)
+            eng.step(x[:, t * n:(t + 1) * n].contiguous(), sr, ctx, st, p)
+            ps.append(p)
+        got = torch.cat(ps, 1)[:64].cpu().numpy()
+        assert np.abs(got - want).max() < TIGHT, B
+        ref = got if ref is None else ref
+        assert np.array_equal(got, ref), B
+    eng.set_option("rec", "bf16x9")
+    try:
+        x = torch.from_numpy(base).to(model.device)
+        ctx = torch.zeros((64, 64), device=model.device)
+        st = torch.zeros((2, 64, 128), device=model.device)
+        ps = []
+        for t in range(3):
+            p = torch.empty((64, 1), device=model.device)
+            eng.step(x[:, t * n:(t + 1) * n].contiguous(), sr, ctx, st, p)
+            ps.append(p)
+        assert np.abs(torch.cat(ps, 1).cpu().numpy() - want).max() < TIGHT
+    finally:
+        eng.set_option("rec", "fp32")
+
+
+def test_upload_rows_rejects_bad_arguments(model):
+    from silero_vad_amd import _lib
+    eng = model.engine
+    dst = torch.zeros((2, 64), dtype=torch.int16, device=model.device)
+    buf = torch.zeros(256, dtype=torch.int16).pin_memory()
+    rows = (ctypes.c_void_p * 2)(buf.data_ptr(), buf.data_ptr())
+    with pytest.raises(_lib.VadError):                         # a row longer than the batch is wide
+        eng.upload_rows(rows, (ctypes.c_long * 2)(65, 3), 2, 64, 2, dst, 1)
+    with pytest.raises(_lib.VadError):                         # pitch not a multiple of 16 bytes
+        eng.upload_rows(rows, (ctypes.c_long * 2)(3, 3), 2, 63, 2, dst, 1)
+    with pytest.raises(_lib.VadError):                         # unknown route
+        eng.upload_rows(rows, (ctypes.c_long * 2)(3, 3), 2, 64, 2, dst, 5)
+    eng.upload_rows(rows, (ctypes.c_long * 2)(0, 0), 2, 64, 2, dst, 1)      # all-empty rows: a zeroed batch
+    torch.cuda.synchronize()
+    assert not dst.any()
