@@ -1,5 +1,6 @@
 // fft_wave.hpp -- per-wave framing + in-wave real FFT magnitude shared by the frontend kernels
-// (kernel_front.hip: exact-fp32 MFMA chain; kernel_front_split.hip: fp16x3 split MFMA chain).
+// (kernel_front_f43.hip: one wave per tile; kernel_front_lat.hip: one frame per wave of a 4-wave tile; test build: kernel_front.hip,
+//  kernel_front_wino.hip).
 //
 // One wave owns 16 chunks; lane (g, j) = (l>>4, l&15); the 4 lanes g of a chunk cooperate on each
 // of its 4 STFT frames.  Output is "mag layout" (layout.hpp): X[s], s < Q, = |Y[4s + P[g]]|, and

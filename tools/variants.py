@@ -27,29 +27,12 @@ VARIANTS = {
     "lat_wg2": ["-DVAD_LAT_WG_PER_CU=2", "-DVAD_LAT_DEPTH=8"], "lat_wg2_d4": ["-DVAD_LAT_WG_PER_CU=2", "-DVAD_LAT_DEPTH=4"],
     "lat_d8": ["-DVAD_LAT_DEPTH=8"], "lat_d24": ["-DVAD_LAT_DEPTH=24"], "lat_d32": ["-DVAD_LAT_DEPTH=32"],
     "lat_noload": ["-DVAD_LAT_ABLATE=1"], "lat_nofft": ["-DVAD_LAT_ABLATE=2"], "lat_neither": ["-DVAD_LAT_ABLATE=3"],
+    "rec_skew": ["-DVAD_REC_SKEW=1"],                  # fp32 recurrence with the two waves of a SIMD half a step apart (slower: r03a)
+    "rec_skew_noprio": ["-DVAD_REC_SKEW=1", "-DVAD_REC_PRIO=0"],
+    "nobvbatch": ["-DVAD_BV_BATCH=0"],                 # frontend: B-operand transforms interleaved with the MFMAs (round-2 form)
     "xbasis": ["-DVAD_F43_EF=0"],                       # F(4,3) input transform from x0..x3 instead of (E, F, x1, x2) (f43 form only)
-    "shfl": ["-DVAD_XLANE_SWAP=0"],                     # cross-lane FFT stages through ds_bpermute (round-2a form)
-    "nyq0": ["-DVAD_NYQ_VALU=0"],                       # Nyquist bin as a 9th MFMA k-group (round-1 form)
-    "nyq0_slot24": ["-DVAD_NYQ_VALU=0", "-DVAD_SLOT_BLOCKS=24"],
-    "slot32": ["-DVAD_SLOT_BLOCKS=32"],
-    "slot32_nobar": ["-DVAD_SLOT_BLOCKS=32", "-DVAD_ABLATE=1"],
-    "nopk_front": [],                                  # fp32 frontends without packed-fp32 VALU (scalar FFT)
-    "wg8k2": ["-DVAD_WG_PER_CU_8K=2"],                  # 8 kHz frontend at two workgroups per CU (round-1 form)
-    "ring3": ["-DVAD_RING_SLOTS=3"],                   # 3-slot weight ring, two units ahead, counted vmcnt
-    "ring2": ["-DVAD_RING_SLOTS=2"],                   # round-1 two-slot ring (barrier + vmcnt(0) at every unit boundary)
-    "ring3_nofft": ["-DVAD_RING_SLOTS=3", "-DVAD_ABLATE=2"],
-    "ring3_noring": ["-DVAD_RING_SLOTS=3", "-DVAD_ABLATE=8"],
-    "ring3_nobar": ["-DVAD_RING_SLOTS=3", "-DVAD_ABLATE=1"],
-    "slot8": ["-DVAD_SLOT_BLOCKS=8"],
-    "slot16": ["-DVAD_SLOT_BLOCKS=16"],
-    "stag6": ["-DVAD_STAGGER=6"],
-    "stag11": ["-DVAD_STAGGER=11"],
-    "stag16": ["-DVAD_STAGGER=16"],
-    "slot8_stag11": ["-DVAD_SLOT_BLOCKS=8", "-DVAD_STAGGER=11"],
     "trace": ["-DVAD_TRACE=1"],
-    "trace_slot8": ["-DVAD_TRACE=1", "-DVAD_SLOT_BLOCKS=8"],
     "trace_noload": ["-DVAD_TRACE=1", "-DVAD_ABLATE=4"],
-    "trace_stag11": ["-DVAD_TRACE=1", "-DVAD_STAGGER=11"],
     "abl_nobar": ["-DVAD_ABLATE=1"],
     "abl_nofft": ["-DVAD_ABLATE=2"],
     "abl_noload": ["-DVAD_ABLATE=4"],
@@ -57,29 +40,6 @@ VARIANTS = {
     "abl_mfma_only": ["-DVAD_ABLATE=15"],
     "abl_coalesced": ["-DVAD_ABLATE=16"],
     "abl_seg64": ["-DVAD_ABLATE=32"],
-    "abl_coalesced_noring": ["-DVAD_ABLATE=24"],
-    "abl_noload_noring": ["-DVAD_ABLATE=12"],
-    "abl_nofft_noload": ["-DVAD_ABLATE=6"],
-    # f16x3 kernels (kernel_front_split.hip, kernel_rec_split.hip).  VAD_ABLATE bits there: 1 no barriers,
-    # 2 no FFT math, 4 no PCM loads, 8 no weight ring, 64 no matrix pipe, 128 one fragment read per unit.
-    "abl_nomfma": ["-DVAD_ABLATE=64"],
-    "abl_notab": ["-DVAD_ABLATE=256"],
-    "abl_nolds": ["-DVAD_ABLATE=128"],
-    "abl_nomfma_nolds": ["-DVAD_ABLATE=192"],
-    "abl_nofft_nomfma": ["-DVAD_ABLATE=66"],
-    "abl_mfma_lds_only": ["-DVAD_ABLATE=15"],
-    "slots2": ["-DVAD_SPLIT_SLOTS=2"], "slots3": ["-DVAD_SPLIT_SLOTS=3"],
-    "w8": ["-DVAD_SPLIT_WAVES=8"],
-    "prio1": ["-DVAD_SPLIT_PRIO=1"], "prio3": ["-DVAD_SPLIT_PRIO=3"],
-    "ntpcm": ["-DVAD_SPLIT_NT_PCM=1"], "ntgx": ["-DVAD_SPLIT_NT_GX=1"],
-    "rec_skew": ["-DVAD_REC_SKEW=1"],                  # recurrence with the two waves of a SIMD half a step apart (slower: r03a)
-    "rec_skew_noprio": ["-DVAD_REC_SKEW=1", "-DVAD_REC_PRIO=0"],
-    "bvbatch": ["-DVAD_BV_BATCH=1"],                   # frontend: a step's four B operands first, then its 8 MFMAs back to back
-    "nobvbatch": ["-DVAD_BV_BATCH=0"],
-    "recd1": ["-DVAD_REC_DEPTH=1"], "recd3": ["-DVAD_REC_DEPTH=3"],
-    # "pk*": the split translation units WITH packed-fp32 VALU instructions -- reproduces the corruption
-    # described in kernel_front_split.hip under two workgroups per CU (tools/split_stress.py)
-    "pk": [],
 }
 
 
