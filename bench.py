@@ -543,6 +543,9 @@ def run_corpus(args, rank, world, local, dist, passes):
              "segments_found_rank0": nseg[0], "segments_gathered_all_ranks": nseg[1] if len(nseg) > 1 else None,
              "ingest_GBps_per_gpu": round(leg_bytes / elapsed / 1e9, 2),
              "h2d_GBps_while_copying": (round(st["h2d_bytes"] / st["h2d_s"] / 1e9, 2) if st.get("h2d_s") else None),
+             # every recording's bytes cross the link at least once (the arena is a ring that is refilled: equal offsets in different
+             # passes are different audio): must be >= 1
+             "bytes_copied_over_live_bytes": round(st.get("h2d_bytes", 0) / max(leg_bytes, 1), 4),
              "host_stage_ms": round(st.get("stage_s", 0) * 1e3, 2),
              "host_upload_call_ms": round(st.get("upload_call_s", 0) * 1e3, 2),
              "host_segmenter_ms": round(st.get("scan_s", 0) * 1e3, 2),

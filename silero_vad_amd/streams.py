@@ -191,23 +191,74 @@ class PackedRecordings:
 
 
 class WindowedPlan:
-    """RaggedPlan per arena window: the recordings of a window (PackedRecordings.windows) are bucketed among themselves, so
-    that a bucket's rows all come from one contiguous arena range that a single DMA has brought to the GPU."""
+    """RaggedPlan per arena window.  A window is a set of recordings whose span -- first sample of the first .. last sample
+    of the last -- is at most `window_bytes` and which lie in it in arena order without overlap, so that ONE DMA of the span
+    brings exactly their bytes to the GPU; the recordings of a window are bucketed among themselves.
+      * recordings that do not overlap anywhere are walked in arena order (sorted by offset), whatever order they were handed
+        over in;
+      * a set with overlaps -- a ring buffer that was refilled: the same offsets mean DIFFERENT audio at different times -- is
+        walked in the order it was handed over, and a window ends where the order turns back (the wrap of the ring): a byte is
+        never copied once for two recordings.
+    `density` = live bytes / copied bytes: a sparse set (recordings scattered over a large arena) is better served by the
+    gather kernel (streams.ragged_buckets)."""
 
     def __init__(self, rec: PackedRecordings, max_waste, max_bytes, itemsize, window_bytes):
         self.lengths = rec.lengths.tolist()
-        self.windows = rec.windows(window_bytes)
-        self.buckets, self.window_of = [], []
         self.empty = [i for i, m in enumerate(self.lengths) if m <= 0]
-        for w, (lo, hi) in enumerate(self.windows):
-            sub = RaggedPlan(self.lengths[lo:hi], max_waste, max_bytes, itemsize)
+        offs, lens = rec.offsets, rec.lengths
+        live = np.flatnonzero(lens > 0)
+        by_offset = live[np.argsort(offs[live], kind="stable")]
+        ends = offs[by_offset] + lens[by_offset]
+        overlap_free = bool(np.all(offs[by_offset][1:] >= ends[:-1])) if len(by_offset) > 1 else True
+        order = by_offset if overlap_free else live
+        self.windows, self.span = [], []                   # recording indices of each window (arena order), (first, last + 1) sample
+        cur, a0, a1 = [], 0, 0
+        for i in order.tolist():
+            o, e = int(offs[i]), int(offs[i] + lens[i])
+            if cur and (o < a1 or (e - a0) * itemsize > window_bytes):
+                self.windows.append(cur)
+                self.span.append((a0, a1))
+                cur = []
+            if not cur:
+                a0 = o
+            cur.append(i)
+            a1 = e
+        if cur:
+            self.windows.append(cur)
+            self.span.append((a0, a1))
+        self.buckets, self.window_of = [], []
+        for w, idx in enumerate(self.windows):
+            sub = RaggedPlan([self.lengths[i] for i in idx], max_waste, max_bytes, itemsize)
             for b in sub.buckets:
-                self.buckets.append([lo + i for i in b])
+                self.buckets.append([idx[i] for i in b])
                 self.window_of.append(w)
-        self.span = [(int(rec.offsets[lo]), int(rec.offsets[hi - 1] + rec.lengths[hi - 1])) for lo, hi in self.windows]
+        copied = sum(b - a for a, b in self.span)
+        self.density = float(lens[live].sum()) / copied if copied else 0.0
 
     def mean_window_fill(self):
-        return float(np.mean([hi - lo for lo, hi in self.windows])) if self.windows else 0.0
+        return float(np.mean([len(w) for w in self.windows])) if self.windows else 0.0
+
+
+def _as_packed(audios):
+    """A list of recordings that are all contiguous views of ONE host storage (a decoder's output buffer, sliced) as a
+    PackedRecordings over that storage; None if they are not."""
+    if isinstance(audios, PackedRecordings) or len(audios) < 2:
+        return None
+    first = audios[0]
+    if not torch.is_tensor(first) or first.is_cuda or first.dtype not in (torch.int16, torch.float32):
+        return None
+    st = first.untyped_storage()
+    key, dtype, esz = st.data_ptr(), first.dtype, first.element_size()
+    offs = np.empty(len(audios), dtype=np.int64)
+    lens = np.empty(len(audios), dtype=np.int64)
+    for i, a in enumerate(audios):
+        if not torch.is_tensor(a) or a.dtype != dtype or a.dim() != 1 or a.is_cuda or (a.numel() > 1 and a.stride(0) != 1) \
+                or a.untyped_storage().data_ptr() != key:
+            return None
+        offs[i] = a.storage_offset()
+        lens[i] = a.shape[0]
+    base = torch.empty(0, dtype=dtype).set_(st, 0, (st.nbytes() // esz,))
+    return PackedRecordings(base, offs, lens)
 
 
 def _describe(audios):
@@ -303,13 +354,16 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     dev = getattr(model, "device", None)
     on_gpu = dev is not None and torch.device(dev).type == "cuda"
     mode = _upload_mode()
-    if plan is None and on_gpu and mode in ("", "window") and isinstance(audios, PackedRecordings) and audios.base.is_pinned() \
-            and hasattr(getattr(model, "engine", None), "upload_rows"):
-        import os
-        wbytes = int(os.environ.get("SILERO_VAD_AMD_WINDOW_BYTES", 0)) or max(2 * max_bytes, 1 << 30)
-        wp = WindowedPlan(audios, max_waste, max_bytes, esz, window_bytes=wbytes)
-        if mode == "window" or wp.mean_window_fill() >= 64:   # the recordings really lie back to back: one DMA per window
-            plan = wp
+    if plan is None and on_gpu and mode in ("", "window") and hasattr(getattr(model, "engine", None), "upload_rows"):
+        # recordings that lie in ONE pinned host buffer (a PackedRecordings, or a list of views of one pinned tensor) and cover
+        # most of the range they span: one DMA per arena window, batches cut on the device
+        packed = audios if isinstance(audios, PackedRecordings) else _as_packed(audios)
+        if packed is not None and packed.base.is_pinned():
+            import os
+            wbytes = int(os.environ.get("SILERO_VAD_AMD_WINDOW_BYTES", 0)) or max(2 * max_bytes, 1 << 30)
+            wp = WindowedPlan(packed, max_waste, max_bytes, esz, window_bytes=wbytes)
+            if mode == "window" or (wp.density >= 0.6 and wp.mean_window_fill() >= 16):
+                plan, audios = wp, packed
     plan = plan or RaggedPlan(lengths, max_waste, max_bytes, esz)
     src = _Sources(audios, dtype, check_pinned=on_gpu and mode != "stage" and hasattr(getattr(model, "engine", None), "upload_rows"))
     if not on_gpu:                                        # CPU stand-in models (tests)

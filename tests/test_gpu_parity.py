@@ -1176,6 +1176,11 @@ def test_ragged_corpus_from_pinned_memory(model, golden, monkeypatch, mode):
     monkeypatch.setenv("SILERO_VAD_AMD_WINDOW_BYTES", "400000")              # a handful of recordings per window
     got_w = ragged_probs(seq, model, sr, max_waste=0.2, max_bytes=150_000)
     assert all(torch.equal(g, want[j]) for g, j in zip(got_w, order))
+    # a plain LIST of views of one pinned tensor, in any order, takes the same route (streams._as_packed)
+    perm = np.random.default_rng(1).permutation(len(seq_lens))
+    views = [arena[seq_offs[i]:seq_offs[i] + seq_lens[i]] for i in perm]
+    got_v = ragged_probs(views, model, sr, max_waste=0.2, max_bytes=150_000)
+    assert all(torch.equal(g, want[order[i]]) for g, i in zip(got_v, perm))
 
 
 # ---- (14) the latency form of the frontend -----------------------------------------------------------------------------

@@ -268,11 +268,27 @@ def test_packed_recordings_windows_and_plan():
     plan = WindowedPlan(rec, max_waste=0.2, max_bytes=60_000, itemsize=2, window_bytes=200_000)
     seen = sorted(i for b in plan.buckets for i in b)
     assert seen == [i for i in range(500) if lens[i] > 0] and plan.empty == [17]
+    assert sorted(i for w in plan.windows for i in w) == seen
+    for w, (a0, a1) in zip(plan.windows, plan.span):                # arena order inside a window, bounded span, everything inside it
+        assert all(offs[i] <= offs[j] for i, j in zip(w, w[1:]))
+        assert (a1 - a0) * 2 <= 200_000 or len(w) == 1
+        assert all(a0 <= offs[i] and offs[i] + lens[i] <= a1 for i in w)
     for b, w in zip(plan.buckets, plan.window_of):
-        lo, hi = plan.windows[w]
-        assert all(lo <= i < hi for i in b)
-        a0, a1 = plan.span[w]
-        assert all(a0 <= offs[i] and offs[i] + lens[i] <= a1 for i in b)
+        assert set(b) <= set(plan.windows[w])
+    assert 0.9 < plan.density <= 1.0                                 # a refilled ring: no byte is copied once for two recordings
+    assert any(w[-1] == 249 for w in plan.windows)                  # ... so the wrap of the ring ends a window
+    # an overlap-free set handed over in any order is walked in arena order: the same windows
+    free = PackedRecordings(base, offs[:250], lens[:250])
+    planf = WindowedPlan(free, 0.2, 60_000, 2, 200_000)
+    perm = rng.permutation(250)
+    plan2 = WindowedPlan(PackedRecordings(base, offs[:250][perm], lens[:250][perm]), 0.2, 60_000, 2, 200_000)
+    assert sorted(tuple(sorted(perm[i] for i in w)) for w in plan2.windows) == sorted(tuple(sorted(w)) for w in planf.windows)
+    # a list of views of one tensor is recognised as a packed set
+    from silero_vad_amd.streams import _as_packed
+    views = [base[o:o + m] for o, m in zip(offs, lens)]
+    pk = _as_packed(views)
+    assert pk is not None and np.array_equal(pk.offsets, offs) and np.array_equal(pk.lengths, lens) and pk.base.data_ptr() == base.data_ptr()
+    assert _as_packed(views + [torch.zeros(5, dtype=torch.int16)]) is None and _as_packed([v.clone() for v in views]) is None
     with pytest.raises(ValueError):
         PackedRecordings(base, offs, lens + base.numel())
     with pytest.raises(ValueError):
