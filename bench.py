@@ -329,6 +329,19 @@ def run_batch(args, sr, rank, world, local, dist, steps, with_other=False):
                                 "kernel_ms": {"front": round(f2, 4), "rec": round(r2, 4)}, "outputs_finite": ok2,
                                 "max_abs_prob_diff_vs_main": float((probs - p_main).abs().max().item()),
                                 "study": "profiles/r03g_rec_bf16x9_study.json: both recurrences against float64, 8 input sets"}}
+        # ... and with the frontend's matrix products the same way too (option front_mma=bf16x9, csrc/kernel_front_b9.hip)
+        eng.set_option("rec", "bf16x9")
+        eng.set_option("front_mma", "bf16x9")
+        try:
+            e3, f3, r3, ok3 = time_batch(eng, step, probs, world, dist, dev, steps, args.warmup)
+        finally:
+            eng.set_option("rec", "fp32")
+            eng.set_option("front_mma", "fp32")
+        other["all_bf16x9"] = {"what": "frontend GEMMs AND recurrence as exact bf16 x 9 piece products (FFT, transforms, activations fp32 as "
+                                       "before); opt-in, not the headline arithmetic.  DESIGN.md 4.1c says why the frontend gains so little",
+                               "value": round(B * T * steps / e3, 1), "unit": "chunks/s", "ms_per_step": round(e3 / steps * 1e3, 4),
+                               "kernel_ms": {"front": round(f3, 4), "rec": round(r3, 4)}, "outputs_finite": ok3,
+                               "max_abs_prob_diff_vs_main": float((probs - p_main).abs().max().item())}
     if rank != 0:
         return None
     w = WORK[sr]

@@ -82,6 +82,11 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *                 exact products of three bf16 pieces per operand (x = p0 + p1 + p2 exactly) on the bf16 matrix pipe with fp32
  *                 accumulation (csrc/kernel_rec_b9.hip).  Not narrower than fp32 (no operand bit is dropped, every product is
  *                 exact), but a different summation: opt-in; measured against a float64 recurrence by the GPU suite
+ *   "front_mma" = "fp32" (default) | "bf16x9": the same for the frontend's matrix products (encoders 0-3 and W_ih): the fp32 MFMA
+ *                 chain, or exact bf16 x 9 piece products (csrc/kernel_front_b9.hip; FFT, Winograd transforms, Nyquist update,
+ *                 biases and ReLU stay the fp32 VALU code).  With "bf16x9" EVERY launch takes that kernel, whatever its size
+ *                 (no latency form, no fused step: the arithmetic of a result must not depend on the batch it came in).
+ *                 Opt-in; 10-20 % faster than the fp32 frontend, not more
  *   "front"     = "auto" (default) | "throughput" | "latency": the frontend has two forms with bit-identical results --
  *                 one wave per 16-chunk tile (csrc/kernel_front_f43.hip: tens of thousands of tiles per launch) and one
  *                 4-wave workgroup per tile (csrc/kernel_front_lat.hip: a stream pool's step, a B = 1 call); "auto" takes
@@ -233,7 +238,8 @@ int  vad_bind_host_to_device(int device);
  * check the fragment packing without a GPU.  which: 0 = frontend GEMM stream (enc0 "direct"), 1 = recurrent
  * W_hh image, 2 = small tables (biases, head, window, twiddles), 5 = frontend stream in Winograd F(2,3) form,
  * 6 = frontend stream in Winograd F(4,3) form (the product's), 7 = recurrent image as three bf16 pieces per weight
- * (option rec=bf16x9), returned as raw 4-byte words holding two bf16 each.                                       */
+ * (option rec=bf16x9), 8 = the F(4,3) frontend program as three bf16 pieces per weight (option front_mma=bf16x9); 7 and 8 are
+ * returned as raw 4-byte words holding two bf16 each.                                                              */
 long vad_debug_packed_floats(const vad_engine *e, int sr, int which);
 int  vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n);
 /* Host-only engine for the hooks above (no device needed).                                       */

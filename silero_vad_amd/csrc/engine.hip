@@ -31,7 +31,7 @@ struct vad_images {
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
     float *d_front4[2] = {}, *d_whh[2] = {}, *d_whh_lat[2] = {}, *d_tables[2] = {};
-    uint16_t *d_whh_b9[2] = {};
+    uint16_t *d_whh_b9[2] = {}, *d_front_b9[2] = {};
 #if VAD_AB
     float *d_front[2] = {}, *d_front_wino[2] = {};
 #endif
@@ -42,6 +42,7 @@ struct vad_images {
             if (d_front4[ni]) (void)hipFree(d_front4[ni]);
             if (d_whh[ni]) (void)hipFree(d_whh[ni]);
             if (d_whh_b9[ni]) (void)hipFree(d_whh_b9[ni]);
+            if (d_front_b9[ni]) (void)hipFree(d_front_b9[ni]);
             if (d_whh_lat[ni]) (void)hipFree(d_whh_lat[ni]);
             if (d_tables[ni]) (void)hipFree(d_tables[ni]);
 #if VAD_AB
@@ -63,6 +64,7 @@ struct vad_engine {
     int enc0 = 2;                                   // fp32 frontend, encoder 0: 2 Winograd F(4,3) (the product); test builds: 0 direct, 1 F(2,3)
     bool fuse_step = true;                          // a ONE-step call small enough for the latency frontend runs the LSTM cell and the head in
                                                     // the same kernel (option "fuse_step")
+    bool front_b9 = false;                          // frontend products: fp32 MFMA chain (default) | exact bf16 x 9 (option "front_mma")
     bool rec_b9 = false;                            // recurrence: fp32 MFMA chain (default) | exact bf16 x 9 products (option "rec")
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the frontend's loads (option "fused_decimation")
@@ -263,7 +265,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             HIP_TRY(e, hipEventRecord(ev[0], stream));
         }
         const long tiles = (long)((B + 15) / 16) * nt;
-        if (T == 1 && e->fuse_step && !e->rec_b9 && e->enc0 == 2 && tiles <= e->lat_tiles) {
+        if (T == 1 && e->fuse_step && !e->rec_b9 && !e->front_b9 && e->enc0 == 2 && tiles <= e->lat_tiles) {
             // one step, few tiles (a stream pool's tick, a B = 1 call): frontend, LSTM cell and head in ONE kernel, no gx round trip
             vad::CellArgs ca{};
             ca.whh_lat = e->img->d_whh_lat[ni];
@@ -277,6 +279,10 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             }
             continue;
         }
+        if (e->front_b9) {
+            fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
+            HIP_TRY(e, vad::launch_front_b9<PcmT>(sr, fa, stream));
+        } else
 #if VAD_AB
         if (e->enc0 == 1) HIP_TRY(e, vad::launch_front_wino<PcmT>(sr, fa, stream));
         else if (e->enc0 == 0) HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
@@ -410,6 +416,7 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
         if (upload(e, &im.d_front4[ni], pk.front_wino4)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh[ni], pk.whh)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_b9[ni], pk.whh_b9)) return bail(VAD_ERR_HIP);
+        if (upload(e, &im.d_front_b9[ni], pk.front_b9)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_lat[ni], pk.whh_lat)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_tables[ni], pk.tables)) return bail(VAD_ERR_HIP);
 #if VAD_AB
@@ -473,6 +480,7 @@ int vad_clone(const vad_engine *src, vad_engine **out) {
     e->fused_decimation = src->fused_decimation;
     e->lat_tiles = src->lat_tiles;
     e->rec_b9 = src->rec_b9;
+    e->front_b9 = src->front_b9;
     e->fuse_step = src->fuse_step;
     e->gx_cap = src->gx_cap;
     e->trace = src->trace;
@@ -509,6 +517,12 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         if (v == "fp32") e->rec_b9 = false;
         else if (v == "bf16x9") e->rec_b9 = true;
         else return fail(e, VAD_ERR_OPTION, "rec must be fp32|bf16x9");
+        return VAD_OK;
+    }
+    if (n == "front_mma") {                          // the frontend's matrix products: fp32 MFMA chain | exact bf16 x 9 piece products
+        if (v == "fp32") e->front_b9 = false;        // (bf16x9: every launch takes the throughput form, whatever its size -- the
+        else if (v == "bf16x9") e->front_b9 = true;  //  arithmetic of a result must not depend on the batch it came in)
+        else return fail(e, VAD_ERR_OPTION, "front_mma must be fp32|bf16x9");
         return VAD_OK;
     }
     if (n == "fuse_step") {                          // "0": a one-step call runs frontend and recurrence as two kernels (A/B for tests)
@@ -622,16 +636,17 @@ long vad_debug_packed_floats(const vad_engine *e, int sr, int which) {
     const vad::PackedNet &p = e->weights->packed[ni];
     return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size() : which == 2 ? (long)p.tables.size()
          : which == 5 ? (long)p.front_wino.size() : which == 6 ? (long)p.front_wino4.size()
-         : which == 7 ? (long)p.whh_b9.size() / 2 : -1;
+         : which == 7 ? (long)p.whh_b9.size() / 2 : which == 8 ? (long)p.front_b9.size() / 2 : -1;
 }
 
 int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n) {
     const int ni = net_index(sr);
     if (!e || ni < 0 || !dst) return VAD_ERR_ARG;
     const vad::PackedNet &p = e->weights->packed[ni];
-    if (which == 7) {                               // three-piece bf16 image: raw 4-byte words holding two bf16 each
-        if (n != (long)p.whh_b9.size() / 2) return VAD_ERR_ARG;
-        std::memcpy(dst, p.whh_b9.data(), p.whh_b9.size() * sizeof(uint16_t));
+    if (which == 7 || which == 8) {                 // three-piece bf16 images: raw 4-byte words holding two bf16 each
+        const std::vector<uint16_t> &h = which == 7 ? p.whh_b9 : p.front_b9;
+        if (n != (long)h.size() / 2) return VAD_ERR_ARG;
+        std::memcpy(dst, h.data(), h.size() * sizeof(uint16_t));
         return VAD_OK;
     }
     const std::vector<float> *v = which == 0 ? &p.front : which == 1 ? &p.whh : which == 2 ? &p.tables
@@ -687,6 +702,10 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.gx = e->d_gx;
     fa.B = B;
     fa.trace = e->trace;
+    if (e->front_b9) {
+        fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
+        HIP_TRY(e, vad::launch_front_b9<float>(sr, fa, stream));
+    } else
 #if VAD_AB
     if (e->enc0 == 1) HIP_TRY(e, vad::launch_front_wino<float>(sr, fa, stream));
     else if (e->enc0 == 0) HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));

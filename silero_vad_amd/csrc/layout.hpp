@@ -123,6 +123,22 @@ constexpr int w4_tail0(int Q) { return w4_part0(w_parts(Q), Q); }          // E2
 constexpr int w4_units(int Q) { return w4_tail0(Q) + 20; }                 // 54 | 42
 constexpr long front_wino4_floats(int Q) { return (long)w4_units(Q) * kWUnitFloats; }
 
+// ---- bf16 x 9 frontend image (kernel_front_b9.hip) ----------------------------------------------------------------
+// The F(4,3) program above, unit for unit, with every fp32 weight as three exact bf16 pieces (as the recurrent image below) for
+// v_mfma_f32_16x16x32_bf16.  One K32 step of that instruction carries the 8 B-operand values a lane holds for TWO fp32 k-groups:
+// slot (g, e) of K32 step kp <-> fp32 k-step 8 kp + e at k = g, so that the chain / mag layouts stay what they are.  A unit holds the
+// same rows and k range as its fp32 unit: [step 4][piece 3][row block 2][lane 64][8 bf16] = 24 KiB, step i of a unit of an M-row-block
+// segment = (K32 step i / (M/2), row blocks 2 (i % (M/2)), +1).
+constexpr int w4_unit_m(int u, int Q) {               // row blocks of the segment unit u belongs to
+    const int T0 = w4_tail0(Q);
+    if (u >= T0) return u < T0 + 2 ? 4 : 8;
+    int p = 0;
+    while (p + 1 < w_parts(Q) && w4_part0(p + 1, Q) <= u) ++p;
+    return u - w4_part0(p, Q) < 6 ? w_rb(Q) : 4;
+}
+constexpr long kW9UnitHalfs = 4L * 3 * 2 * 64 * 8;   // 12 288 bf16 = 24 KiB
+constexpr long front_b9_halfs(int Q) { return (long)w4_units(Q) * kW9UnitHalfs; }
+
 // ---- recurrent image: [wave 8][gate 4][kgroup 8][lane 64][4] ------------------------------------
 constexpr long whh_floats() { return 8L * 4 * 8 * 256; }
 

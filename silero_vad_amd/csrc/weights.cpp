@@ -245,6 +245,26 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
                     }
 
     // tables
+    pack_net_wino4(t, g, p);
+    // the F(4,3) program as bf16 pieces: a re-indexing of the fp32 image (layout.hpp "bf16 x 9 frontend image")
+    p.front_b9.assign((size_t)front_b9_halfs(Q), 0);
+    for (int u = 0; u < w4_units(Q); ++u) {
+        const int H = w4_unit_m(u, Q) / 2;
+        const float *src = p.front_wino4.data() + (size_t)u * kWUnitFloats;
+        uint16_t *dst = p.front_b9.data() + (size_t)u * kW9UnitHalfs;
+        for (int ib = 0; ib < 4; ++ib)
+            for (int rb = 0; rb < 2; ++rb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int kp = ib / H, mh = ib % H, kg = 2 * kp + e / 4, i_f = kg * H + mh;
+                        float r = src[((size_t)(i_f * 2 + rb) * 64 + lane) * 4 + (e & 3)];
+                        for (int piece = 0; piece < 3; ++piece) {
+                            const uint16_t h = bf16_rne(r);
+                            dst[((((size_t)ib * 3 + piece) * 2 + rb) * 64 + lane) * 8 + e] = h;
+                            r -= bf16_f32(h);
+                        }
+                    }
+    }
     const Tab tb = make_tab(g.F, Q);
     p.tables.assign((size_t)tb.total, 0.f);
     float *T = p.tables.data();
@@ -272,7 +292,6 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
         for (int row = 0; row < 128; ++row)
             T[tb.w_nyq + tau * 128 + row] = t.ew[0][((size_t)row * K + 4 * Q) * 3 + tau];
     pack_net_wino(t, g, p);
-    pack_net_wino4(t, g, p);
 }
 
 }  // namespace

@@ -127,3 +127,44 @@ def test_bf16x9_recurrent_image_is_exact(built, tag):
     assert np.array_equal(pieces.sum(1), want)                              # exact: float64 holds the three pieces' sum
     assert np.all(np.abs(pieces[:, 1]) <= np.abs(pieces[:, 0]) * 2.0 ** -8 + 1e-45)
     assert np.all(np.abs(pieces[:, 2]) <= np.abs(pieces[:, 0]) * 2.0 ** -16 + 1e-45)
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_bf16x9_frontend_image_is_the_f43_program_exactly(packed, built, tag):
+    """The three-piece bf16 image of the frontend (option front_mma=bf16x9, csrc/kernel_front_b9.hip) is the F(4,3) program
+    unit for unit: the pieces of every weight add up to the fp32 weight EXACTLY, and slot (g, e) of K32 step kp of a unit
+    holds what the fp32 unit holds for k-step 8 kp + e at k = g (same rows) -- so the wave program the emulator validates
+    on the fp32 image (test_f43_wave_program_matches_reference_activations) is the program of the bf16 x 9 kernel too."""
+    from silero_vad_amd import _lib
+    sr = SRS[tag]
+    Q = 32 if sr == 16000 else 16
+    L = _lib.lib()
+    blob = _lib.WEIGHTS_PATH.read_bytes()
+    h = ctypes.c_void_p()
+    assert L.vad_create_host_only(blob, len(blob), ctypes.byref(h)) == 0
+    n = L.vad_debug_packed_floats(h, sr, 8)
+    raw = np.empty(n, np.float32)
+    assert L.vad_debug_packed_copy(h, sr, 8, raw.ctypes.data_as(_lib.f32p), n) == 0
+    L.vad_destroy(h)
+    f32 = packed[sr, 6].reshape(-1, 8, 2, 64, 4)                            # [unit][fp32 step][rb][lane][ks]
+    NU = f32.shape[0]
+    img = raw.view(np.uint16).reshape(NU, 4, 3, 2, 64, 8)                   # [unit][step][piece][rb][lane][e]
+    pieces = (img.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    RB, P = 64 // Q, 8 // (64 // Q)
+    per_part = [6 + ((2 + (p & 1)) if Q == 32 else 5) for p in range(P)]
+    unit_m = []
+    for p in range(P):
+        unit_m += [RB] * 6 + [4] * (per_part[p] - 6)
+    unit_m += [4, 4] + [8] * 18
+    assert len(unit_m) == NU == (54 if Q == 32 else 42)
+    for u in range(NU):
+        H = unit_m[u] // 2
+        for ib in range(4):
+            kp, mh = ib // H, ib % H
+            for e in range(8):
+                i_f = (2 * kp + e // 4) * H + mh
+                want = f32[u, i_f, :, :, e % 4].astype(np.float64)           # [rb][lane]
+                got = pieces[u, ib, :, :, :, e]                             # [piece][rb][lane]
+                assert np.array_equal(got.sum(0), want)
+                assert np.all(np.abs(got[1]) <= np.abs(got[0]) * 2.0 ** -8 + 1e-45)
+                assert np.all(np.abs(got[2]) <= np.abs(got[0]) * 2.0 ** -16 + 1e-45)

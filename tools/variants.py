@@ -18,7 +18,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
-HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_rec.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
+HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_rec.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
        "kernel_ingest.hip"]
 CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
@@ -40,6 +40,11 @@ VARIANTS = {
     "abl_mfma_only": ["-DVAD_ABLATE=15"],
     "abl_coalesced": ["-DVAD_ABLATE=16"],
     "abl_seg64": ["-DVAD_ABLATE=32"],
+    # bf16 x 9 frontend (tools/b9_time.py): timing-only ablations
+    "abl_b9_nosplit": ["-DVAD_ABLATE=64"], "abl_b9_nofrag": ["-DVAD_ABLATE=128"], "abl_b9_mfma3": ["-DVAD_ABLATE=256"],
+    "abl_b9_nosplit_nofft": ["-DVAD_ABLATE=66"], "abl_b9_valu_none": ["-DVAD_ABLATE=70"], "abl_b9_noring_nobar": ["-DVAD_ABLATE=9"],
+    "abl_b9_mfma_only": ["-DVAD_ABLATE=207"],
+    "pk_b9": [],                                        # bf16 x 9 frontend WITH packed fp32 VALU instructions (the product builds it without)
 }
 
 
@@ -51,7 +56,7 @@ def build(names):
     shared.mkdir(exist_ok=True)
     procs = []
     # translation units without knobs are compiled once
-    knob_units = {"kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_rec.hip", "kernel_rec_b9.hip"}
+    knob_units = {"kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_rec.hip", "kernel_rec_b9.hip"}
     for src in HIP + CPP:
         if src in knob_units:
             continue
@@ -64,7 +69,7 @@ def build(names):
         d = OUT / ("obj_" + name)
         d.mkdir(exist_ok=True)
         for src in knob_units:
-            extra = nopk if name.startswith("nopk") else []
+            extra = nopk if (name.startswith("nopk") or (src == "kernel_front_b9.hip" and not name.startswith("pk_"))) else []
             procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950"] + common + extra + VARIANTS[name]
                                           + ["-c", str(CSRC / src), "-o", str(d / (src + ".o"))]))
     for p in procs:
