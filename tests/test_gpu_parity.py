@@ -1661,3 +1661,117 @@ def test_front_bf16x9_at_the_c2_shape(model, golden):
     json.dump({"c2": times, "max_abs_dp_between": dp, "max_abs_dstate_between": ds}, open("gpurun_out/front_bf16x9_timing.json", "w"), indent=1)
     assert dp < 1e-5 and ds < TOL, (dp, ds)
     assert times["bf16x9"]["front_ms"] < 1.02 * times["fp32"]["front_ms"], times
+
+
+# ---- (20) the whole path against float64, both arithmetics, at the exact bench shape ---------------------------------------------------
+class _F64Net:
+    """The network in float64 on the device (plain torch matmuls; TEST infrastructure): STFT magnitude from the reference's basis,
+    four ReLU(conv k = 3), LSTM cell, head -- JIT!/vad/utils/pytorch_stft.py:17-34, JIT!/vad/utils/model_utils.py:19-25,
+    JIT!/torch/nn/modules/rnn.py:69, JIT!/torch/nn/modules/container/___torch_mangle_7.py:10-19."""
+
+    def __init__(self, sr, device):
+        from oracle.weights import read_container
+        from silero_vad_amd import _lib
+        w = read_container(_lib.WEIGHTS_PATH.read_bytes())
+        pre = "_model" if sr == 16000 else "_model_8k"
+        t = lambda k: torch.from_numpy(w[pre + "." + k].astype(np.float64)).to(device)
+        self.basis = t("stft.forward_basis_buffer").squeeze(1)                 # [2K, F]
+        self.F = self.basis.shape[-1]
+        self.K = self.basis.shape[0] // 2
+        self.enc = [(t(f"encoder.{i}.reparam_conv.weight"), t(f"encoder.{i}.reparam_conv.bias"), s) for i, s in enumerate((1, 2, 2, 1))]
+        self.w_ih, self.w_hh = t("decoder.rnn.weight_ih"), t("decoder.rnn.weight_hh")
+        self.b = t("decoder.rnn.bias_ih") + t("decoder.rnn.bias_hh")
+        self.w_out, self.b_out = t("decoder.decoder.2.weight").reshape(128), t("decoder.decoder.2.bias").reshape(())
+        self.n = 512 if sr == 16000 else 256
+
+    def features(self, x1):
+        """x1 [N, C + n] float64 -> gate pre-activations W_ih feat + b [N, 512]"""
+        F_ = self.F
+        x = torch.cat([x1, x1[:, -(F_ // 4) - 1:-1].flip(1)], 1)                # right reflect pad by F/4
+        fr = x.unfold(1, F_, F_ // 2)                                           # [N, 4, F]
+        y = fr @ self.basis.T                                                   # [N, 4, 2K]
+        a = torch.sqrt(y[..., :self.K] ** 2 + y[..., self.K:] ** 2).transpose(1, 2)   # [N, K, 4]
+        for wt, bs, s in self.enc:
+            ap = torch.nn.functional.pad(a, (1, 1))
+            u = ap.unfold(2, 3, s)                                              # [N, Cin, Tout, 3]
+            N, Cin, To, _ = u.shape
+            a = torch.relu(u.permute(0, 2, 1, 3).reshape(N, To, Cin * 3) @ wt.reshape(wt.shape[0], Cin * 3).T + bs).transpose(1, 2)
+        return a[:, :, 0] @ self.w_ih.T + self.b
+
+    def audio_forward(self, rows, slab=16):
+        """rows [B, T n] float32 on the device -> (probs [B, T], state [2, B, 128]) in float64, zero initial state / context"""
+        B, L = rows.shape
+        n, C = self.n, self.n // 8
+        T = L // n
+        x = torch.cat([torch.zeros((B, C), dtype=torch.float64, device=rows.device), rows.double()], 1)
+        h = torch.zeros((B, 128), dtype=torch.float64, device=rows.device)
+        c = torch.zeros_like(h)
+        probs = torch.empty((B, T), dtype=torch.float64, device=rows.device)
+        for t0 in range(0, T, slab):
+            nt = min(slab, T - t0)
+            x1 = x[:, t0 * n: (t0 + nt) * n + C].unfold(1, n + C, n).reshape(B * nt, n + C)
+            gx = self.features(x1).reshape(B, nt, 512)
+            for k in range(nt):
+                g = gx[:, k] + h @ self.w_hh.T
+                i, f, gg, o = torch.sigmoid(g[:, :128]), torch.sigmoid(g[:, 128:256]), torch.tanh(g[:, 256:384]), torch.sigmoid(g[:, 384:])
+                c = f * c + i * gg
+                h = o * torch.tanh(c)
+                probs[:, t0 + k] = torch.sigmoid(torch.relu(h) @ self.w_out + self.b_out)
+        return probs, torch.stack([h, c])
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_whole_path_both_arithmetics_against_float64(model, oracle, golden, tag):
+    """The study VERDICT r02 item 9 asks for before any arithmetic but the fp32 MFMA chain may carry the headline: the WHOLE path --
+    fp32 (default) and bf16 x 9 (front_mma + rec) -- against a float64 evaluation of the network, at the exact C2 / C3 shape
+    (4 096 streams x 256 chunks of speech), on quiet speech (x 1e-3), the synthetic mix and the adversarial set, 256 steps each,
+    probabilities AND final (h, c).  Asserted: the float64 evaluation itself agrees with the oracle (a second, independent
+    statement of the network); both arithmetics sit within 2e-5 (probabilities) of float64 on full-level input and inside the
+    contract everywhere.  Recorded (gpurun_out/whole_path_f64_study_<tag>.json): every pair of figures and whether bf16 x 9 is
+    no worse than fp32 on it."""
+    import json
+    import os
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    eng = model.engine
+    dev = model.device
+    f64 = _F64Net(sr, dev)
+    T = 256
+    wav_dev = torch.from_numpy(g["wav"]).to(dev)
+    sets = {"c2_speech_4096x256": _strided_rows(wav_dev, 4096, T * n, 7919),
+            "quiet_speech_x1e-3": _strided_rows(wav_dev, 64, T * n, 4001) * 1e-3,
+            "synthetic": torch.from_numpy(rolled_rows(synthetic_audio(sr, np.random.default_rng(42)), 64, T * n, 4001)).to(dev),
+            "adversarial": torch.from_numpy(_adversarial(sr, T)[1]).to(dev)}
+    # the float64 network is the oracle's network: a few steps of speech, fp32 round-off apart
+    chk = sets["c2_speech_4096x256"][:8, :6 * n].contiguous()
+    p64, _ = f64.audio_forward(chk)
+    want, _, _ = oracle.forward_audio(chk.cpu().numpy(), sr)
+    assert np.abs(p64.cpu().numpy() - want).max() < 5e-6
+    report = {}
+    for name, x in sets.items():
+        x = x.contiguous()
+        B = x.shape[0]
+        p64, s64 = f64.audio_forward(x)
+        fig = {}
+        for arith in ("fp32", "bf16x9"):
+            eng.set_option("front_mma", arith)
+            eng.set_option("rec", arith)
+            try:
+                ctx = torch.zeros((B, n // 8), device=dev)
+                st = torch.zeros((2, B, 128), device=dev)
+                p = eng.forward_audio(x, sr, ctx, st)
+            finally:
+                eng.set_option("front_mma", "fp32")
+                eng.set_option("rec", "fp32")
+            dp = (p.double() - p64).abs()
+            ds = (st.double() - s64).abs()
+            rel = float((ds.max() / s64.abs().max().clamp_min(1e-30)).item())
+            fig[arith] = {"max_abs_dp": float(dp.max().item()), "mean_abs_dp": float(dp.mean().item()),
+                          "max_abs_dstate": float(ds.max().item()), "mean_abs_dstate": float(ds.mean().item()), "state_err_rel": rel}
+            loose = name in ("quiet_speech_x1e-3", "adversarial")
+            assert fig[arith]["max_abs_dp"] < (TOL if loose else 2e-5), (name, arith, fig[arith])
+            assert rel < (5e-4 if loose else TOL), (name, arith, fig[arith])
+        fig["bf16x9_no_worse"] = {k: fig["bf16x9"][k] <= fig["fp32"][k] for k in fig["fp32"]}
+        report[name] = fig
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(report, open(f"gpurun_out/whole_path_f64_study_{tag}.json", "w"), indent=1)
