@@ -4,7 +4,10 @@
 //
 // Why.  A v_mfma_f32_16x16x4_f32 owns its SIMD's vector issue for 32 cycles (profiles/r03a_issue_pipes2.md): the fp32 frontend's
 // 3 456 MFMAs and ~6 500 VALU instructions per tile ADD, and it sits at 0.86 of that sum.  v_mfma_f32_16x16x32_bf16 does 8x the
-// MACs in half the cycles and runs BESIDE the VALU.
+// MACs in half the cycles and runs BESIDE the VALU -- beside its PLAIN instructions: packed fp32 ones (v_pk_fma_f32, v_pk_add_f32,
+// v_pk_mul_f32) wait for the matrix pipe (profiles/r03p_pipes3.md), so this file is built without them (__graft_entry__.EXTRA_FLAGS).
+// Measured: 3.75-3.90 ms per C2 launch against the fp32 kernel's 4.33 (the clock drops to 1.99 GHz, the operand splitting doubles
+// the VALU work, two waves per SIMD co-execute a fifth of the matrix pipe's busy time: profiles/r03p_front_bf16x9.md).
 //
 // Arithmetic.  Every fp32 operand is the exact sum of three bf16 pieces (8 significand bits each, fp32's exponent range), so a
 // product of two operands is the sum of NINE piece products, each exact in fp32; the MFMA accumulates them in fp32.  Nothing is
