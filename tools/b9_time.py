@@ -16,6 +16,7 @@ for sr in ([int(os.environ['VAD_B9_TIME_SR'])] if os.environ.get('VAD_B9_TIME_SR
     x = 0.1 * torch.randn((B, T * n), device=dev)
     for mma in (sys.argv[1:] or ["bf16x9"]):
         eng.set_option("front_mma", mma)
+        eng.set_option("rec", os.environ.get("VAD_B9_TIME_REC", "fp32"))
         st = torch.zeros((2, B, 128), device=dev)
         ctx = torch.zeros((B, n // 8), device=dev)
         for _ in range(12):
