@@ -15,9 +15,9 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
 using f32x2 = float __attribute__((ext_vector_type(2)));
 using bf8 = __bf16 __attribute__((ext_vector_type(8)));
 
-enum Kind { K_FMA = 0, K_PKFMA, K_PKADD, K_CVT, K_AND, K_LSHL, K_ADD, K_MOV, K_PKMUL, NKIND };
+enum Kind { K_FMA = 0, K_PKFMA, K_PKADD, K_CVT, K_AND, K_LSHL, K_ADD, K_MOV, K_PKMUL, K_DOT2, NKIND };
 static const char *kname[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_cvt_pk_bf16_f32", "v_and_b32", "v_lshlrev_b32", "v_add_f32",
-                              "v_mov_b32", "v_pk_mul_f32"};
+                              "v_mov_b32", "v_pk_mul_f32", "v_dot2c_f32_bf16"};
 
 template <int KIND>
 __device__ __forceinline__ void valu1(float &x, f32x2 &p, float c0, float c1, f32x2 pc) {
@@ -29,6 +29,7 @@ __device__ __forceinline__ void valu1(float &x, f32x2 &p, float c0, float c1, f3
     else if (KIND == K_AND) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(c0));
     else if (KIND == K_LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x));
     else if (KIND == K_ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(c0));
+    else if (KIND == K_DOT2) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x) : "v"(c0), "v"(c1));
     else asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(c0));
 }
 
@@ -238,6 +239,7 @@ static void row2(int n) {
            kname[KIND], ACC ? "AGPR" : "VGPR", v0 / 64, V, m1, v2, mp, vp);
 }
 
+
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 4000;
     hipMalloc(&d_rec, 4096 * sizeof(Rec));
@@ -245,6 +247,7 @@ int main(int argc, char **argv) {
     h_rec.resize(4096);
     printf("two waves per SIMD (even slot: 16 x v_mfma_f32_16x16x32_bf16 per trip, odd slot: V x 8 VALU per trip); ticks per trip.  "
            "In one wave: ticks per 8 x [1 MFMA][K VALU]\n");
+    row2<K_DOT2, 0>(n);
     row2<K_FMA, 0>(n);
     row2<K_FMA, 1>(n);
     row2<K_AND, 0>(n);
