@@ -1622,6 +1622,27 @@ def test_front_bf16x9_against_oracle_and_fp32(model, oracle, golden, tag):
                 return eng.forward_audio(xr, 16000 * k, ctx, st).cpu().numpy()
             want, _, _ = oracle.forward_audio(raw[:, ::k], 16000)
             assert np.abs(with_mma("bf16x9", run_raw) - want).max() < TIGHT, k
+    # callers either side of the path carry the option along: the ragged scheduler's lanes are clones of the engine (same options),
+    # a stream pool's hipGraph captures whatever kernel the option selects
+    from silero_vad_amd import StreamPool, ragged_probs
+    lens = [3 * n + 17, 9 * n, 5 * n + 1, 9 * n - 3, n, 2 * n + n // 2]
+    recs = [torch.from_numpy(rolled_rows(g["wav"], 1, L, 100 + 31 * i)[0].copy()) for i, L in enumerate(lens)]
+
+    got = with_mma("bf16x9", lambda: ragged_probs(recs, model, sr))
+    for a, p in zip(recs, got):
+        want = oracle.audio_forward(a.numpy()[None], sr)[0]
+        assert p.shape == want.shape and np.abs(p.numpy() - want).max() < TIGHT
+
+    def pooled():
+        cap, Tn = 40, 5
+        rows = rolled_rows(g["wav"], cap, Tn * n, 1999)
+        pool = StreamPool(eng, sr, capacity=cap, graph=True)
+        for _ in range(cap):
+            pool.open()
+        out = np.stack([pool.tick(torch.from_numpy(rows[:, t * n:(t + 1) * n]).to(model.device)).cpu().numpy() for t in range(Tn)], 1)
+        want, _, _ = oracle.forward_audio(rows, sr)
+        return float(np.abs(out - want).max())
+    assert with_mma("bf16x9", pooled) < TIGHT
 
 
 def test_front_bf16x9_at_the_c2_shape(model, golden):
