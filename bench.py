@@ -188,6 +188,55 @@ def pmc_traffic(kernel_key, sr, B, T):
     return best
 
 
+def live_pmc_traffic(config, kernels):
+    """HBM bytes per launch of `kernels` measured NOW: two child runs of this same command under `rocprofv3 --pmc` -- FETCH_SIZE
+    and WRITE_SIZE need separate passes (TCC counter budget), counters only, no trace domain -- each a few timed steps of the same
+    workload; per-dispatch means of the last dispatches, corrected as MI355X_MICROARCH.md "HBM" prescribes (FETCH_SIZE counts KiB
+    and, on gfx950, tallies the 128-byte requests of wide coalesced reads at 64 bytes: doubled; WRITE_SIZE in KiB as reported).
+    Returns {kernel: {"bytes", "fetch_bytes", "write_bytes"}} or (None, reason)."""
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="vad_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", VAD_BENCH_PMC_CHILD="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
+                   str(ROOT / "bench.py"), "--config", config, "--no-cpu-baseline", "--no-extras", "--steps", "6", "--warmup", "1"]
+            r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            per = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    for k in kernels:
+                        if k in row["Kernel_Name"]:
+                            per.setdefault(k, []).append(float(row["Counter_Value"]))
+            for k, v in per.items():
+                tail = v[-6:]                                  # the timed dispatches (the clock ramp's come first)
+                vals.setdefault(k, {})[counter] = sum(tail) / len(tail)
+    except Exception as e:  # noqa: BLE001 -- a profiler hiccup must not cost the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for k, c in vals.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            res[k] = {"bytes": int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "fetch_bytes": int(2.0 * c["FETCH_SIZE"] * 1024),
+                      "write_bytes": int(c["WRITE_SIZE"] * 1024)}
+    return (res, None) if res else (None, "no dispatch of the kernels in the counter files")
+
+
 def synth_pcm(B, L, sr, dev, seed):
     """0.03 * N(0,1) as in examples/onnx_sequence/run.py:159-162, plus a per-stream tone so that the
     operands are not sign-symmetric noise only (throughput is data independent; DVFS is not)."""
@@ -219,8 +268,8 @@ def roofline(sr, chunks_per_launch, front_ms_avg, rec_ms_avg, B, T):
     """Dominant kernel = the frontend (STFT + encoder + W_ih).  achieved = matrix flops the kernel EXECUTES per
     launch / its average launch duration, peak = the dense fp32 MFMA peak (157.3 TF): frac <= 1.  The reference's
     dense flop count for the same part of the path ("useful work") is reported separately and is never divided into
-    `frac`.  `traffic` is null: this run collects no PMC counters; `traffic_profiled` quotes the HBM bytes per launch
-    of this kernel from the newest committed rocprofv3 --pmc passes of this same command (profiles/), labelled as such;
+    `frac`.  `traffic` is filled in by main() from a live rocprofv3 --pmc pass of this command (live_pmc_traffic; null if rocprofv3
+    is not available, at N > 1, or with --no-extras); `traffic_profiled` quotes the same figure from the newest committed passes (profiles/);
     `path` relates the whole path (both kernels) to the algorithmic bytes of SURVEY 8(d) the same way."""
     w = WORK[sr]
     s = front_ms_avg / 1e3
@@ -814,6 +863,27 @@ def main():
                     oc[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             if rank == 0:
                 out["other_configs"] = oc
+        if (extras and world == 1 and args.config in ("c2", "8k") and not os.environ.get("VAD_BENCH_PMC_CHILD")
+                and not os.environ.get("VAD_BENCH_NO_PMC")):
+            # roofline.traffic, measured by THIS run: two short child runs of this command under rocprofv3 --pmc
+            fk = WORK[16000 if args.config == "c2" else 8000]["front_kernel"].split("<")[0]
+            t0 = time.perf_counter()
+            got, why = live_pmc_traffic(args.config, [fk, "rec_kernel"])
+            rl = out["roofline"]
+            if got and fk in got:
+                rl["traffic"] = got[fk]["bytes"]
+                rl["traffic_detail"] = dict(got[fk], unit="bytes per launch", how="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one child run of "
+                                            "this command each (6 timed steps), mean of the timed dispatches; FETCH_SIZE x 2 (gfx950 tallies "
+                                            "128-byte requests at 64 bytes, MI355X_MICROARCH.md HBM) + WRITE_SIZE, KiB -> bytes",
+                                            seconds=round(time.perf_counter() - t0, 1))
+                rl["traffic_over_kernel_io"] = round(got[fk]["bytes"] / rl["kernel_io_bytes"], 3)
+                if "rec_kernel" in got:
+                    pt = got[fk]["bytes"] + got["rec_kernel"]["bytes"]
+                    rl["path"]["traffic"] = pt
+                    rl["path"]["traffic_over_algorithmic"] = round(pt / rl["path"]["algorithmic_bytes"], 3)
+                    rl["path"]["traffic_detail"] = {"front": got[fk], "rec": got["rec_kernel"]}
+            else:
+                rl["traffic_note"] = f"live PMC pass unavailable ({why}); traffic_profiled is the committed profile's figure"
 
     if rank == 0:
         if cpu is not None:
