@@ -210,7 +210,7 @@ def live_pmc_traffic(config, kernels):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
                    str(ROOT / "bench.py"), "--config", config, "--no-cpu-baseline", "--no-extras", "--steps", "6", "--warmup", "1"]
-            r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=120)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
