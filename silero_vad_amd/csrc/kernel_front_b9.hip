@@ -16,7 +16,7 @@
 // Weights are split on the host (layout.hpp "bf16 x 9 frontend image": the fp32 program unit for unit, 24 KiB units); activations
 // are split by the lane that holds them, right before they are used as a B operand (8 values -> 3 x 4 registers of bf16 pairs).
 //
-// Structure: as kernel_front_f43.hip (one wave = 16 chunks, 4 waves per workgroup, 2 workgroups per CU, the weight image streamed
+// Structure: as kernel_front_f43.hip (one wave = 16 chunks; here 8 waves per workgroup, 1 workgroup per CU; the weight image streamed
 // through a 3-slot LDS ring, barrier in the middle of a unit, fragment reads carried across unit boundaries).  A K32 step carries
 // what two fp32 k-groups carried: slot (g, e) <-> fp32 k-step 8 kp + e at k = g, so the chain / mag layouts are unchanged.  Per step
 // (1 K32 x 2 row blocks): 6 A fragments (3 pieces x 2 row blocks, 16 B per lane each) and 18 MFMAs, issued piece by piece so that
@@ -33,6 +33,10 @@
 namespace vad {
 namespace {
 
+#ifndef VAD_B9_WAVES
+#define VAD_B9_WAVES 8             // waves (= tiles) per workgroup sharing one weight ring: 8 = one workgroup per CU, half the L2 -> LDS
+#endif                             // traffic of two 4-wave workgroups (front 3.94 -> 3.92 ms, the recurrence launched behind it 1.31 -> 1.22 ms)
+constexpr int kWaves = VAD_B9_WAVES, kShare = 24 * 1024 / kWaves;       // a wave's share of a unit's DMA
 constexpr int kUnitBytes = (int)vadl::kW9UnitHalfs * 2;     // 24 blocks of 1 KiB
 using u32x4 = unsigned __attribute__((ext_vector_type(4)));
 using f32x2 = float __attribute__((ext_vector_type(2)));
@@ -75,14 +79,22 @@ struct Ring {
 __device__ __forceinline__ void ring_request(Ring &r) {
     if (VAD_ABLATE & 8) return;
     unsigned keep_m0;                      // M0 is restored: the compiler may keep its own value there
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %4 offset:2048\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep_m0) : "v"(r.voff), "s"(r.src), "s"(r.d_far), "s"(r.src + 3072), "s"(r.d_far + 3072u) : "memory");
+    if constexpr (kWaves == 4) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %4 offset:2048\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep_m0) : "v"(r.voff), "s"(r.src), "s"(r.d_far), "s"(r.src + 3072), "s"(r.d_far + 3072u) : "memory");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep_m0) : "v"(r.voff), "s"(r.src), "s"(r.d_far) : "memory");
+    }
     r.src += kUnitBytes;
 }
 __device__ __forceinline__ void ring_rotate(Ring &r) {
@@ -165,7 +177,7 @@ __device__ __forceinline__ void gemm_b(f32x4 (&acc)[M], BF bfun, Ring &r) {
 }
 
 template <int Q, typename PcmT, int DEC>
-__global__ void __launch_bounds__(256, 2) front_b9_kernel(const FrontArgs a) {
+__global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) front_b9_kernel(const FrontArgs a) {
     using namespace vadl;
     constexpr Tab tb = make_tab(8 * Q, Q);
     constexpr int TABF = (tb.total + 3) / 4 * 4;
@@ -187,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) front_b9_kernel(const FrontArgs a) {
     ln.g = ln.lane >> 4;
     ln.j = ln.lane & 15;
     const long nst = (a.B + 15) / 16, total = nst * a.nt;
-    long wt = (long)blockIdx.x * 4 + ln.wave;
+    long wt = (long)blockIdx.x * kWaves + ln.wave;
     ln.tile_valid = wt < total;
     if (!ln.tile_valid) wt = total - 1;
     ln.tl = wt % a.nt;
@@ -214,10 +226,10 @@ __global__ void __launch_bounds__(256, 2) front_b9_kernel(const FrontArgs a) {
         ring.a_nxt = ring.a_cur + kUnitBytes;
         ring.a_far = ring.a_cur + 2 * kUnitBytes;
         // the two priming requests go to slots 0 and 1: start rotated by two, so that "far" is slot 0 first, then slot 1
-        ring.d_far = slot0 + (unsigned)ln.wave * 6144u;
+        ring.d_far = slot0 + (unsigned)ln.wave * (unsigned)kShare;
         ring.d_cur = ring.d_far + kUnitBytes;
         ring.d_nxt = ring.d_far + 2 * kUnitBytes;
-        ring.src = reinterpret_cast<const char *>(a.wfront) + ln.wave * 6144;
+        ring.src = reinterpret_cast<const char *>(a.wfront) + ln.wave * kShare;
         ring_request(ring);                               // unit 0 -> slot 0
         {   const unsigned d = ring.d_far; ring.d_far = ring.d_cur; ring.d_cur = ring.d_nxt; ring.d_nxt = d; }
         ring_request(ring);                               // unit 1 -> slot 1
@@ -226,17 +238,17 @@ __global__ void __launch_bounds__(256, 2) front_b9_kernel(const FrontArgs a) {
     }
     {   // tables -> LDS: all loads of a thread are issued before the first is stored
         static_assert(tb.total % 4 == 0, "tables are copied as 16-byte vectors");
-        constexpr int NV = tb.total / 4, PER = (NV + 255) / 256;
+        constexpr int NT = 64 * kWaves, NV = tb.total / 4, PER = (NV + NT - 1) / NT;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.tables);
         f32x4 v[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = threadIdx.x + k * 256;
+            const int i = threadIdx.x + k * NT;
             v[k] = src[i < NV ? i : NV - 1];
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = threadIdx.x + k * 256;
+            const int i = threadIdx.x + k * NT;
             float *base = 4 * i < tb.window ? tab : 4 * i < tb.w_nyq ? tabf : tabn;
             if (i < NV) reinterpret_cast<f32x4 *>(base)[i] = v[k];
         }
@@ -430,13 +442,13 @@ template <typename PcmT>
 hipError_t launch_front_b9(int sr, const FrontArgs &a, hipStream_t s) {
     if (a.B <= 0 || a.nt <= 0) return hipSuccess;
     const long nst = (a.B + 15) / 16, total = nst * a.nt;
-    const unsigned grid = (unsigned)((total + 3) / 4);
+    const unsigned grid = (unsigned)((total + kWaves - 1) / kWaves);
     // a.dec == 2, 3: 32 / 48 kHz input, decimation folded into the loads (fft_wave.hpp load_slice; 16 kHz net only)
     if (a.dec > 1 && (sr != 16000 || a.dec > 3)) return hipErrorInvalidValue;
-    if (a.dec == 3) hipLaunchKernelGGL((front_b9_kernel<32, PcmT, 3>), dim3(grid), dim3(256), 0, s, a);
-    else if (a.dec == 2) hipLaunchKernelGGL((front_b9_kernel<32, PcmT, 2>), dim3(grid), dim3(256), 0, s, a);
-    else if (sr == 16000) hipLaunchKernelGGL((front_b9_kernel<32, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((front_b9_kernel<16, PcmT, 1>), dim3(grid), dim3(256), 0, s, a);
+    if (a.dec == 3) hipLaunchKernelGGL((front_b9_kernel<32, PcmT, 3>), dim3(grid), dim3(64 * kWaves), 0, s, a);
+    else if (a.dec == 2) hipLaunchKernelGGL((front_b9_kernel<32, PcmT, 2>), dim3(grid), dim3(64 * kWaves), 0, s, a);
+    else if (sr == 16000) hipLaunchKernelGGL((front_b9_kernel<32, PcmT, 1>), dim3(grid), dim3(64 * kWaves), 0, s, a);
+    else hipLaunchKernelGGL((front_b9_kernel<16, PcmT, 1>), dim3(grid), dim3(64 * kWaves), 0, s, a);
     return hipGetLastError();
 }
 template hipError_t launch_front_b9<float>(int, const FrontArgs &, hipStream_t);

@@ -45,6 +45,7 @@ VARIANTS = {
     "abl_b9_nosplit_nofft": ["-DVAD_ABLATE=66"], "abl_b9_valu_none": ["-DVAD_ABLATE=70"], "abl_b9_noring_nobar": ["-DVAD_ABLATE=9"],
     "abl_b9_mfma_only": ["-DVAD_ABLATE=207"],
     "nopk_all": [],                                     # every knob unit without packed fp32 (the bf16 x 9 recurrence beside plain VALU only)
+    "b9_w4": ["-DVAD_B9_WAVES=4"],                     # bf16 x 9 frontend: two 4-wave workgroups per CU (default: one 8-wave workgroup)
     "pk_b9": [],                                        # bf16 x 9 frontend WITH packed fp32 VALU instructions (the product builds it without)
 }
 
