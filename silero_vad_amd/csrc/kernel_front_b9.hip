@@ -20,8 +20,8 @@
 // through a 3-slot LDS ring, barrier in the middle of a unit, fragment reads carried across unit boundaries).  A K32 step carries
 // what two fp32 k-groups carried: slot (g, e) <-> fp32 k-step 8 kp + e at k = g, so the chain / mag layouts are unchanged.  Per step
 // (1 K32 x 2 row blocks): 6 A fragments (3 pieces x 2 row blocks, 16 B per lane each) and 18 MFMAs, issued piece by piece so that
-// only two fragments are live and two in flight.  The ring is 3 x 24 KiB; to fit two workgroups in the CU's 160 KiB the FFT's
-// tables (window, twiddles: used before the first request into slot 2) live in slot 2.
+// only two fragments are live and two in flight.  The ring is 3 x 24 KiB; the FFT's tables (window, twiddles: used before the first
+// request into slot 2) live in slot 2, so that the workgroup needs 79 KB and two 4-wave workgroups per CU stay possible (VAD_B9_WAVES).
 // (reference: the same lines as kernel_front_f43.hip.)
 #include <hip/hip_runtime.h>
 
