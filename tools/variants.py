@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Build and time A/B variants of the kernels (compile-time knobs in csrc/*.hip; tools/split_stress.py and
-tools/split_diag.py take a variant through SILERO_VAD_AMD_LIB=build/variants/lib_<name>.so).
+"""Build and time A/B variants of the kernels (compile-time knobs in csrc/*.hip; any tool or test takes a variant through
+SILERO_VAD_AMD_LIB=build/variants/lib_<name>.so -- tools/b9_time.py, tools/trace_b9.py, tools/lat_time.py ...).
 
     python tools/variants.py build            # here (no GPU): build/variants/lib_<name>.so
     python tools/variants.py run [names...]   # on the GPU box: bench each, write gpurun_out/variants.json
