@@ -863,8 +863,9 @@ def main():
                     oc[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             if rank == 0:
                 out["other_configs"] = oc
+        under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
         if (extras and world == 1 and args.config in ("c2", "8k") and not os.environ.get("VAD_BENCH_PMC_CHILD")
-                and not os.environ.get("VAD_BENCH_NO_PMC")):
+                and not os.environ.get("VAD_BENCH_NO_PMC") and not under_profiler):   # (a profiled run does not start a profiler of its own)
             # roofline.traffic, measured by THIS run: two short child runs of this command under rocprofv3 --pmc
             fk = WORK[16000 if args.config == "c2" else 8000]["front_kernel"].split("<")[0]
             t0 = time.perf_counter()
