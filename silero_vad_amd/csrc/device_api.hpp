@@ -86,6 +86,10 @@ struct RecArgs {
     int B;
 };
 hipError_t launch_rec(int sr, const RecArgs &a, hipStream_t s);
+// The same recurrence, bit for bit, for at most kRecSmallMaxB streams (1, 2 or 4 per workgroup): W_hh * h as matrix-vector products on the VALU (kernel_rec_small.hip);
+// `whh` points at the row image (layout.hpp "whh_rows").
+constexpr int kRecSmallMaxB = 1024;
+hipError_t launch_rec_small(int sr, const RecArgs &a, hipStream_t s);
 // The throughput frontend with every matrix product as exact bf16 x 9 piece products on the bf16 matrix pipe (kernel_front_b9.hip);
 // `a.wfront` points at the three-piece image (layout.hpp "bf16 x 9 frontend image").  Same gx layout as launch_front_f43.
 template <typename PcmT>

@@ -30,7 +30,7 @@ struct vad_images {
     int device = -1;
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
-    float *d_front4[2] = {}, *d_whh[2] = {}, *d_whh_lat[2] = {}, *d_tables[2] = {};
+    float *d_front4[2] = {}, *d_whh[2] = {}, *d_whh_lat[2] = {}, *d_whh_rows[2] = {}, *d_tables[2] = {};
     uint16_t *d_whh_b9[2] = {}, *d_front_b9[2] = {};
 #if VAD_AB
     float *d_front[2] = {}, *d_front_wino[2] = {};
@@ -42,6 +42,7 @@ struct vad_images {
             if (d_front4[ni]) (void)hipFree(d_front4[ni]);
             if (d_whh[ni]) (void)hipFree(d_whh[ni]);
             if (d_whh_b9[ni]) (void)hipFree(d_whh_b9[ni]);
+            if (d_whh_rows[ni]) (void)hipFree(d_whh_rows[ni]);
             if (d_front_b9[ni]) (void)hipFree(d_front_b9[ni]);
             if (d_whh_lat[ni]) (void)hipFree(d_whh_lat[ni]);
             if (d_tables[ni]) (void)hipFree(d_tables[ni]);
@@ -64,6 +65,7 @@ struct vad_engine {
     int enc0 = 2;                                   // fp32 frontend, encoder 0: 2 Winograd F(4,3) (the product); test builds: 0 direct, 1 F(2,3)
     bool fuse_step = true;                          // a ONE-step call small enough for the latency frontend runs the LSTM cell and the head in
                                                     // the same kernel (option "fuse_step")
+    int rec_form = 0;                               // fp32 recurrence: 0 auto (VALU matrix-vector form for B <= 1024, same bits), 1 MFMA form always
     bool front_b9 = false;                          // frontend products: fp32 MFMA chain (default) | exact bf16 x 9 (option "front_mma")
     bool rec_b9 = false;                            // recurrence: fp32 MFMA chain (default) | exact bf16 x 9 products (option "rec")
     bool profile = false;
@@ -292,7 +294,12 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         else HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
         if (e->rec_b9) HIP_TRY(e, vad::launch_rec_b9(sr, ra, stream));
-        else HIP_TRY(e, vad::launch_rec(sr, ra, stream));
+        else if (e->rec_form != 1 && B <= vad::kRecSmallMaxB) {
+            // a file at a time, a bucket of a few hundred: W_hh h as matrix-vector products on the VALU, 1-4 streams per CU -- the same bits
+            // at 1.2-2.7 us per step instead of 4.3
+            ra.whh = e->img->d_whh_rows[ni];
+            HIP_TRY(e, vad::launch_rec_small(sr, ra, stream));
+        } else HIP_TRY(e, vad::launch_rec(sr, ra, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[2], stream));
     }
     HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -418,6 +425,7 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
         if (upload(e, &im.d_whh_b9[ni], pk.whh_b9)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_front_b9[ni], pk.front_b9)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_lat[ni], pk.whh_lat)) return bail(VAD_ERR_HIP);
+        if (upload(e, &im.d_whh_rows[ni], pk.whh_rows)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_tables[ni], pk.tables)) return bail(VAD_ERR_HIP);
 #if VAD_AB
         if (upload(e, &im.d_front[ni], pk.front)) return bail(VAD_ERR_HIP);
@@ -480,6 +488,7 @@ int vad_clone(const vad_engine *src, vad_engine **out) {
     e->fused_decimation = src->fused_decimation;
     e->lat_tiles = src->lat_tiles;
     e->rec_b9 = src->rec_b9;
+    e->rec_form = src->rec_form;
     e->front_b9 = src->front_b9;
     e->fuse_step = src->fuse_step;
     e->gx_cap = src->gx_cap;
@@ -523,6 +532,12 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         if (v == "fp32") e->front_b9 = false;        // (bf16x9: every launch takes the throughput form, whatever its size -- the
         else if (v == "bf16x9") e->front_b9 = true;  //  arithmetic of a result must not depend on the batch it came in)
         else return fail(e, VAD_ERR_OPTION, "front_mma must be fp32|bf16x9");
+        return VAD_OK;
+    }
+    if (n == "rec_form") {                           // which form of the fp32 recurrence a launch takes (A/B for tests; results are bit-identical)
+        if (v == "auto" || v == "valu") e->rec_form = 0;
+        else if (v == "mfma") e->rec_form = 1;
+        else return fail(e, VAD_ERR_OPTION, "rec_form must be auto|mfma|valu");
         return VAD_OK;
     }
     if (n == "fuse_step") {                          // "0": a one-step call runs frontend and recurrence as two kernels (A/B for tests)

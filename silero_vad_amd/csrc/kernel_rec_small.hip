@@ -1,0 +1,146 @@
+// kernel_rec_small.hip -- the recurrence (same function, same bits as kernel_rec.hip) for up to 1 024 streams: the reference's own
+// workflow -- one file at a time through get_speech_timestamps (src/silero_vad/utils_vad.py:324-336) -- is B = 1 with thousands of
+// time steps, and rec_kernel's step costs 4.4 us whatever the batch: its 1 024 MFMAs per step multiply W_hh by a 16-column tile of
+// which a single file fills one column.  Here W_hh * h is what it is for one stream, a matrix-vector product, on the VALU:
+//   * 512 threads, thread (q, n) owns gate row 128 q + n: its 128 weights stay in 128 VGPRs for the whole launch, in the ORDER in
+//     which rec_kernel's MFMA chain adds them -- v_mfma_f32_16x16x4_f32 is exactly fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, c))))
+//     (tools/ubench/mfma_order.hip: 1 048 576 of 1 048 576 outputs), k-groups ascending -- so that the same fmaf chain gives the SAME
+//     BITS: position 16 kg + 4 r + g of the chain is hidden unit 16 kg + 4 g + r (layout.hpp "whh_rows");
+//   * h_{t-1} lies in LDS in chain order and is read as broadcast 16-byte vectors; per step and stream 128 fmaf per thread;
+//   * the four gates of a unit meet in LDS; 32 threads per stream -- thread (w, g) holds units 16 w + 4 g + r, r < 4, exactly what a
+//     lane of rec_kernel holds -- do the pointwise update with the same formulas (activations.hpp) and reduce the head's dot
+//     product in rec_kernel's order: fmaf chain over r, ((p0 + p1) + (p2 + p3)) over g, then w = 0..7 onto the bias.
+// Every workgroup carries 1, 2 or 4 streams -- as few as put B streams on the chip's 256 CUs at once -- and a step costs 1.21 / 1.67 /
+// 2.65 us against rec_kernel's 4.34 whatever the batch: a single 60 s file 8.1 -> 2.3 ms, a bucket of 300 recordings 1.7 us per step.
+// The engine takes this kernel for B <= 1 024 (option "rec_form" = auto | mfma); above that rec_kernel's 16 streams per CU win.
+// (reference: aten::lstm_cell, JIT!/torch/nn/modules/rnn.py:69, gate order i,f,g,o; JIT!/vad/model/vad_annotator.py:170-187; head
+//  JIT!/torch/nn/modules/container/___torch_mangle_7.py:10-19.)
+#include <hip/hip_runtime.h>
+
+#include "activations.hpp"
+#include "device_api.hpp"
+#include "layout.hpp"
+
+namespace vad {
+namespace {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+template <int NB, int NTAB_WOUT, int NTAB_BOUT>
+__global__ void __launch_bounds__(512, 1) rec_small_kernel(const RecArgs a) {
+    __shared__ __attribute__((aligned(16))) float hs[2][NB][128];      // h, chain order: [16 kg + 4 r + g] = unit 16 kg + 4 g + r
+    __shared__ __attribute__((aligned(16))) float gs[NB][4][128];      // gate pre-activations [stream][gate][unit]
+
+    const int tid = threadIdx.x, q = tid >> 7, n = tid & 127;
+    const long b0 = (long)blockIdx.x * NB;                 // first stream of this workgroup; NB divides 16: all of them in one gx tile
+    const int nb = (int)(a.B - b0 < NB ? a.B - b0 : NB);   // streams that exist (>= 1)
+    float W[128];
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.whh) + (size_t)(128 * q + n) * 32;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            const f32x4 v = src[m];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) W[4 * m + e] = v[e];
+        }
+    }
+    // where the frontend put this row's gate pre-activation: D-fragment order, tile 0 (layout.hpp, kernel_rec.hip)
+    const int w = n >> 4, g = (n >> 2) & 3, r = n & 3;
+    const float *gxp = a.gx + ((size_t)(b0 >> 4) * a.nt * 32) * 256 + ((size_t)(8 * q + w) * 64 + g * 16 + (b0 & 15)) * 4 + r;   // + t * 32 * 256 + 4 j
+
+    // pointwise role: thread (pj, pw, pg) holds units 16 pw + 4 pg + rr of stream pj
+    const bool pt = tid < 32 * NB;
+    const int pj = tid >> 5, pw = (tid & 31) >> 2, pg = tid & 3;
+    const bool pvalid = pt && pj < nb;
+    const long pb = b0 + (pj < nb ? pj : nb - 1);          // this thread's stream (clamped: lanes of missing streams compute, never store)
+    f32x4 h = {0.f, 0.f, 0.f, 0.f}, c = h, wo = h;
+    float bo = 0.f;
+    size_t soff = 0;
+    if (pt) {
+        soff = (size_t)pb * 128 + 16 * pw + 4 * pg;
+        h = *reinterpret_cast<const f32x4 *>(a.state + soff);
+        c = *reinterpret_cast<const f32x4 *>(a.state + (size_t)a.B * 128 + soff);
+        wo = *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * pw + 4 * pg);
+        bo = a.tables[NTAB_BOUT];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) hs[0][pj][16 * pw + 4 * rr + pg] = h[rr];
+    }
+    float gnext[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) gnext[j] = gxp[4 * (j < nb ? j : nb - 1)];
+    __syncthreads();
+
+    for (long t = 0; t < a.nt; ++t) {
+        const int cur = (int)(t & 1);
+        float acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = gnext[j];
+        if (t + 1 < a.nt) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) gnext[j] = gxp[(size_t)(t + 1) * 32 * 256 + 4 * (j < nb ? j : nb - 1)];
+        }
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const f32x4 hv = *reinterpret_cast<const f32x4 *>(&hs[cur][j][4 * m]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j] = fmaf(W[4 * m + e], hv[e], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) gs[j][q][n] = acc[j];
+        __syncthreads();
+        if (pt) {
+            const int u0 = 16 * pw + 4 * pg;
+            const f32x4 gi = *reinterpret_cast<const f32x4 *>(&gs[pj][0][u0]), gf = *reinterpret_cast<const f32x4 *>(&gs[pj][1][u0]);
+            const f32x4 gg4 = *reinterpret_cast<const f32x4 *>(&gs[pj][2][u0]), go = *reinterpret_cast<const f32x4 *>(&gs[pj][3][u0]);
+            float th[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float ig = sigmoid_f(gi[rr]), fg = sigmoid_f(gf[rr]), gg = tanh_f(gg4[rr]);
+                const float cn = fmaf(fg, c[rr], ig * gg);
+                c[rr] = cn;
+                th[rr] = tanh_f(cn);
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                h[rr] = sigmoid_f(go[rr]) * th[rr];
+                part = fmaf(wo[rr], fmaxf(h[rr], 0.f), part);
+            }
+            part += __shfl_xor(part, 1);
+            part += __shfl_xor(part, 2);
+            float p = bo;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) p += __shfl(part, (tid & 32) + 4 * ww);
+            if (pvalid && pw == 0 && pg == 0) a.probs[(size_t)pb * a.ldp + a.t0 + t] = sigmoid_f(p);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) hs[cur ^ 1][pj][16 * pw + 4 * rr + pg] = h[rr];
+        }
+        __syncthreads();
+    }
+    if (pvalid) {
+        *reinterpret_cast<f32x4 *>(a.state + soff) = h;
+        *reinterpret_cast<f32x4 *>(a.state + (size_t)a.B * 128 + soff) = c;
+    }
+}
+
+template <int NB>
+hipError_t launch_nb(int sr, const RecArgs &a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.B + NB - 1) / NB);
+    if (sr == 16000) hipLaunchKernelGGL((rec_small_kernel<NB, vadl::tab16.w_out, vadl::tab16.b_out>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((rec_small_kernel<NB, vadl::tab8.w_out, vadl::tab8.b_out>), dim3(grid), dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_rec_small(int sr, const RecArgs &a, hipStream_t s) {
+    if (a.B <= 0 || a.nt <= 0) return hipSuccess;
+    if (a.B > kRecSmallMaxB) return hipErrorInvalidValue;
+    // one workgroup per CU (512 threads, 128 weight registers each): as few streams per workgroup as fill the chip's 256 CUs once
+    return a.B <= 256 ? launch_nb<1>(sr, a, s) : a.B <= 512 ? launch_nb<2>(sr, a, s) : launch_nb<4>(sr, a, s);
+}
+
+}  // namespace vad

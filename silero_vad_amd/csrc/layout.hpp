@@ -142,6 +142,11 @@ constexpr long front_b9_halfs(int Q) { return (long)w4_units(Q) * kW9UnitHalfs; 
 // ---- recurrent image: [wave 8][gate 4][kgroup 8][lane 64][4] ------------------------------------
 constexpr long whh_floats() { return 8L * 4 * 8 * 256; }
 
+// ---- recurrent weights row by row (kernel_rec_small.hip): [row 512][128] floats, a row in the order in which rec_kernel's MFMA chain
+// adds its products: position 16 kg + 4 r + g holds W_hh[row][16 kg + 4 g + r] (k-groups ascending; within a k-group the four MFMAs r,
+// within an MFMA the four lane groups g = the instruction's k index)
+constexpr long whh_rows_floats() { return 512L * 128; }
+
 // ---- bf16 x 9 recurrent image (kernel_rec_b9.hip) -----------------------------------------------------------------
 // Every fp32 weight w is stored as THREE bf16 pieces w = p0 + p1 + p2, exactly (p0 = bf16(w), p1 = bf16(w - p0),
 // p2 = w - p0 - p1: bf16 carries 8 significand bits and fp32's exponent range, so three pieces hold all 24 bits and none

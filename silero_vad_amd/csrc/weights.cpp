@@ -216,6 +216,14 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
             return t.w_hh[((size_t)(128 * q + row)) * 128 + chain_chan(s, gg)];
         });
 
+    // row image for the small-batch recurrence: a row's weights in the order rec_kernel's MFMA chain adds them (layout.hpp "whh_rows")
+    p.whh_rows.assign((size_t)whh_rows_floats(), 0.f);
+    for (int row = 0; row < 512; ++row)
+        for (int kg = 0; kg < 8; ++kg)
+            for (int r = 0; r < 4; ++r)
+                for (int gg = 0; gg < 4; ++gg)
+                    p.whh_rows[(size_t)row * 128 + 16 * kg + 4 * r + gg] = t.w_hh[(size_t)row * 128 + 16 * kg + 4 * gg + r];
+
     // recurrent image as three bf16 pieces per weight: [wave][piece][gate][u][lane][8] (layout.hpp)
     p.whh_b9.assign((size_t)whh_b9_halfs(), 0);
     auto bf16_rne = [](float x) -> uint16_t {

@@ -18,7 +18,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
-HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_rec.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
+HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_rec.hip", "kernel_rec_small.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
        "kernel_ingest.hip"]
 CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
