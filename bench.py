@@ -539,6 +539,8 @@ def run_corpus(args, rank, world, local, dist, passes):
     node = _lib.lib().vad_bind_host_to_device(local)            # staging threads + pinned buffers on the GPU's NUMA node
     host_threads = _lib.lib().vad_host_threads()
     model = load_silero_vad(device=local)
+    if os.environ.get("VAD_BENCH_REC_FORM"):                # A/B of the recurrence's form (results are bit-identical)
+        model.engine.set_option("rec_form", os.environ["VAD_BENCH_REC_FORM"])
     n = WORK[sr]["chunk"]
     rng = np.random.default_rng(7)
     base_len = 8 << 20

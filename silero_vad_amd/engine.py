@@ -89,6 +89,11 @@ class Engine:
         if name not in ("profile", "trace_ptr"):
             self.options[name] = str(value)
 
+    def set_transient(self, name, value):
+        """`set_option` for a setting a caller applies for the duration of one call and takes back: not recorded in
+        `options` (clones made later do not inherit it, and nothing that keys on `options` sees a change)."""
+        self._check(self._L.vad_set_option(self._h, name.encode(), str(value).encode()))
+
     def set_precision(self, precision):
         """The engine computes in fp32 only; kept so that callers may state it."""
         self.set_option("precision", precision)

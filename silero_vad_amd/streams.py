@@ -427,6 +427,19 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     for _, st in lane_list[1:]:
         st.wait_stream(cur)                               # sibling lanes start behind whatever the caller has queued
     copies = []                                           # (start event, end event) of every H2D copy, for STATS
+    # Buckets on different lanes overlap because a bucket's recurrence sits on the few CUs its stream tiles need (16 streams per CU,
+    # kernel_rec.hip) beside the other lane's frontend.  The matrix-vector form of the recurrence (kernel_rec_small.hip) finishes a
+    # bucket of a few hundred recordings 2-3 x sooner but spreads it over the whole chip, with nothing left to overlap with: the
+    # pipelined corpus runs 4 % (window route) to 30 % (gather kernel) slower with it.  Lanes therefore pin the MFMA form.
+    rec_form_before = []
+    import os as _os
+    lane_form = _os.environ.get("SILERO_VAD_AMD_LANE_REC", "mfma")     # (A/B: "auto" lets the lanes take the matrix-vector form)
+    if len(lane_list) > 1 and lane_form != "auto":
+        for lane_model, _ in lane_list:
+            eng_l = getattr(lane_model, "engine", None)
+            if eng_l is not None and hasattr(eng_l, "set_transient"):
+                rec_form_before.append((eng_l, eng_l.options.get("rec_form", "auto")))
+                eng_l.set_transient("rec_form", lane_form)
 
     def stage(k):
         idxs = plan.buckets[k]
@@ -523,6 +536,8 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             first[2].synchronize()
             yield finish(first)
     finally:
+        for eng_l, form in rec_form_before:
+            eng_l.set_transient("rec_form", form)
         # also when the consumer stops early or an exception propagates: the sibling lanes' work is ordered before
         # whatever the caller enqueues next, and the copy events are drained
         for _, st in lane_list[1:]:
