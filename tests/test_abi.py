@@ -56,7 +56,7 @@ def test_weights_container_errors(built):
     assert L.vad_set_option(h, b"impl", b"reference") == 0
     # every option states its values; an unknown value or name is VAD_ERR_OPTION with a message, never a silent default
     for name, good_vals, bad in ((b"front_mma", (b"bf16x9", b"fp32"), b"bf16"), (b"rec", (b"bf16x9", b"fp32"), b"fp16"),
-                                 (b"front", (b"latency", b"throughput", b"auto"), b"fast"), (b"precision", (b"fp32",), b"bf16x9"),
+                                 (b"front", (b"latency", b"throughput", b"auto"), b"fast"), (b"rec_form", (b"mfma", b"auto"), b"scalar"), (b"precision", (b"fp32",), b"bf16x9"),
                                  (b"enc0", (b"winograd",), b"direct"), (b"gx_cap_mib", (b"64",), b"0")):
         for v in good_vals:
             assert L.vad_set_option(h, name, v) == 0, (name, v)
