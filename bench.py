@@ -163,7 +163,8 @@ def cpu_baseline(sr, budget_s=24.0):
             "sample": f"same {sr // 1000} kHz synthetic workload (0.03 N(0,1)), audio_forward over B streams x T chunks "
                       f"per run as listed under runs; warm-up {d['warmup']}, median of {d['trials']}; R1 = 1 thread B=1 "
                       "(the reference's shipped default), R2 = 1 thread B=4096, R3 = nproc threads B=4096, "
-                      "R4 = nproc processes x 1 thread sharing the 4096 streams; value = the best of the four"}
+                      "R4 = nproc processes x 1 thread sharing the 4096 streams; value = the best of the four; R5 (another workload, never "
+                      "the value) = get_speech_timestamps on the reference's fixture through the per-chunk protocol, one thread"}
 
 
 def pmc_traffic(kernel_key, sr, B, T):
@@ -209,7 +210,7 @@ def live_pmc_traffic(config, kernels):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
-                   str(ROOT / "bench.py"), "--config", config, "--no-cpu-baseline", "--no-extras", "--steps", "6", "--warmup", "1"]
+                   str(ROOT / "bench.py"), "--config", config, "--no-cpu-baseline", "--no-extras", "--no-parity", "--steps", "6", "--warmup", "1"]
             r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=120)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -235,6 +236,36 @@ def live_pmc_traffic(config, kernels):
             res[k] = {"bytes": int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "fetch_bytes": int(2.0 * c["FETCH_SIZE"] * 1024),
                       "write_bytes": int(c["WRITE_SIZE"] * 1024)}
     return (res, None) if res else (None, "no dispatch of the kernels in the counter files")
+
+
+PARITY_TOL = 1e-4        # BASELINE.json north_star; examples/openvino/verify.py:167
+
+
+def certify(pcm_rows, got_probs, got_state, sr, what, init_state=None, init_ctx=None):
+    """CHECKER, outside every timed region (protocol: examples/openvino/verify.py:157-181): the CPU oracle recomputes the given
+    streams of THE BENCH'S OWN PCM over all their chunks; the leg's probabilities (and final (h, c) when given) must agree to the
+    contract.  pcm_rows [S, L] float32 numpy, got_probs [S, T], got_state [2, S, 128] or None.  (oracle/ is test infrastructure:
+    used here as the checker only, like `smoke()` does.)"""
+    import numpy as np
+    from oracle import Oracle
+    want, _, wst = Oracle().forward_audio(np.ascontiguousarray(pcm_rows, dtype=np.float32), sr, ctx=init_ctx, state=init_state)
+    got_probs = np.asarray(got_probs, dtype=np.float32)
+    dp = float(np.abs(got_probs - want).max())
+    out = {"checker": "oracle/vad_oracle.c on this leg's own PCM, after the timed region", "streams": what,
+           "streams_checked": int(want.shape[0]), "chunks_checked": int(want.size), "parity_max_abs_dp": dp, "tolerance": PARITY_TOL,
+           "max_prob": round(float(want.max()), 4)}
+    ok = dp <= PARITY_TOL
+    if got_state is not None:
+        a, b = np.asarray(got_state, dtype=np.float64), np.asarray(wst, dtype=np.float64)
+        out["final_state_max_rel_err"] = float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())
+        ok = ok and out["final_state_max_rel_err"] <= PARITY_TOL
+    out["ok"] = bool(ok)
+    return out
+
+
+def require_parity(par, leg):
+    if not par["ok"]:
+        raise RuntimeError(f"{leg}: parity check failed: {json.dumps(par)}")
 
 
 def synth_pcm(B, L, sr, dev, seed):
@@ -362,6 +393,13 @@ def run_batch(args, sr, rank, world, local, dist, steps, with_other=False):
         eng.forward_audio(pcm, sr, ctx, state, probs)
 
     elapsed, front_ms, rec_ms, ok = time_batch(eng, step, probs, world, dist, dev, steps, args.warmup)
+    parity = None
+    if not args.no_parity:
+        # self-certification: streams 0..15 and the last 16, all T chunks, of the PCM that was just timed
+        sel = list(range(min(16, B))) + list(range(max(16, B - 16), B))
+        idx = torch.tensor(sel, device=dev)
+        parity = certify(pcm[idx].cpu().numpy(), probs[idx].cpu().numpy(), state[:, idx].cpu().numpy(), sr,
+                         f"streams 0..15 and {B - 16}..{B - 1} of {B}, all {T} chunks")
     other = None
     if with_other and world == 1:
         # for the record, never the headline: the same workload with the recurrence's W_hh * h as exact bf16 x 9 piece products on
@@ -403,6 +441,11 @@ def run_batch(args, sr, rank, world, local, dist, steps, with_other=False):
                      "sharding": f"streams x{world}, no collectives"}
     out["realtime_factor"] = round(value * 0.032, 1)
     out["outputs_finite"] = ok
+    out["parity"] = parity
+    if parity:
+        out["parity_max_abs_dp"] = parity["parity_max_abs_dp"]
+        if world == 1:
+            require_parity(parity, f"{sr // 1000} kHz batch")
     out["clock_ramp_steps"] = max(0, CLOCK_RAMP_STEPS - args.warmup)
     out["timed_region_s"] = round(elapsed, 4)
     out["path_fraction"] = {"dense_flop_vs_fp32_peak": round(value / world * w["flop"] / (PEAK_F32_TFLOPS * 1e12), 4),
@@ -417,17 +460,32 @@ def run_batch(args, sr, rank, world, local, dist, steps, with_other=False):
 
 
 # ---- stream: live streams, hipGraph step -------------------------------------------------------------------
-def run_stream(args, rank, world, local, dist, steps):
+def certify_pool(pool, feed, n_ticks, sr, what):
+    """Self-certification of a stream pool: every slot restarts from zero state, `n_ticks` ticks of the leg's own audio go through
+    the leg's own tick function `feed(k) -> probs[capacity]` (host or device), and the oracle recomputes streams 0..15.  `feed`
+    also returns the float32 audio of those 16 streams for tick k."""
+    import numpy as np
+    pool.open_all()
+    got, rows = [], []
+    for k in range(n_ticks):
+        p, x16 = feed(k)
+        got.append(np.asarray(p[:16].cpu() if hasattr(p, "cpu") else p[:16], dtype=np.float32).copy())
+        rows.append(x16)
+    state = pool.state[:, :16].cpu().numpy()
+    return certify(np.concatenate(rows, axis=1), np.stack(got, axis=1), state, sr, what)
+
+
+def run_stream(args, rank, world, local, dist, steps, sr=16000):
+    """KERNEL ONLY: the audio source is a ring in HBM, nothing crosses PCIe, nobody reads the probabilities (the `stream_host` leg is
+    the end-to-end figure)."""
     import torch
     from silero_vad_amd import Engine, StreamPool
-    sr = 16000
     dev = torch.device("cuda", local)
     eng = Engine(device=local)
     n = WORK[sr]["chunk"]
     cap = args.live
     pool = StreamPool(eng, sr, capacity=cap, graph=True)
-    for _ in range(cap):
-        pool.open()
+    pool.open_all()
     ring = 8                                                   # device-side audio source, 8 ticks long
     src = synth_pcm(cap, ring * n, sr, dev, 23 + rank).view(cap, ring, n).transpose(0, 1).contiguous()
     k = [0]
@@ -455,16 +513,27 @@ def run_stream(args, rank, world, local, dist, steps):
     front_ms, rec_ms, calls = eng.kernel_times()
     eng.set_option("profile", "0")
     ok = bool(torch.isfinite(pool.prob).all().item())
+    parity = None
+    if not args.no_parity:
+        def feed(j):
+            pool.pcm.copy_(src[j % ring])
+            pool.tick_staged()
+            return pool.prob.clone(), src[j % ring][:16].cpu().numpy()
+        parity = certify_pool(pool, feed, 3 * ring, sr, f"streams 0..15 of {cap}, {3 * ring} ticks from zero state through the captured graph")
     if rank != 0:
         return None
     value = cap * world * steps / elapsed
     out = base_line(args, world, sr, value, elapsed, steps)
-    out["config"] = {"workload": f"configs[4]: {cap} live 16 kHz streams/GPU ({cap * 8} per 8-GPU node), one "
-                                 f"hipGraph-captured vad_step per 32 ms tick, (h,c)+context persistent in HBM",
+    out["config"] = {"workload": f"configs[4], KERNEL ONLY (audio source in HBM; see stream_host for host chunks in -> events out): {cap} live "
+                                 f"{sr // 1000} kHz streams/GPU ({cap * 8} per 8-GPU node), one hipGraph-captured vad_step per 32 ms tick, "
+                                 "(h,c)+context persistent in HBM",
                      "streams_per_gpu": cap, "sample_rate": sr, "step": "one tick (one chunk per stream)",
                      "sharding": f"streams x{world}, no collectives"}
     out["realtime_factor"] = round(value * 0.032, 1)
     out["outputs_finite"] = ok
+    out["parity"] = parity
+    if parity and world == 1:
+        require_parity(parity, f"stream {sr // 1000} kHz")
     out["tick_latency_ms"] = {"median": round(lat[len(lat) // 2], 4), "p95": round(lat[int(len(lat) * 0.95)], 4),
                               "budget_ms": 32.0}
     c = max(calls, 1)
@@ -475,10 +544,135 @@ def run_stream(args, rank, world, local, dist, steps):
     # the fused kernel executes the frontend's AND the recurrence's matrix flops
     w = WORK[sr]
     fl = cap * (w["front_mfma"] + w["rec_mfma"])
-    rl.update({"kernel": "front_lat_kernel<32, float, 1, true> (frontend + LSTM cell + head)", "flop_per_launch": fl,
+    rl.update({"kernel": f"front_lat_kernel<{32 if sr == 16000 else 16}, float, 1, true> (frontend + LSTM cell + head)", "flop_per_launch": fl,
                "achieved": round(fl / (front_ms / c / 1e3) / 1e12, 3)})
     rl["frac"] = round(rl["achieved"] / PEAK_F32_TFLOPS, 4)
     out["roofline"] = rl
+    return out
+
+
+def fixture_rows_i16(sr, cap, L):
+    """`cap` streams of real speech for the host-fed legs: the reference's own fixture (tests/data/test.wav / examples/c++/aepyx_8k.wav,
+    committed as tests/golden/audio_*.npz), stream b reading it circularly from offset b * 7919 (SURVEY.md section 8d set iii)."""
+    import numpy as np
+    pcm = np.load(ROOT / "tests" / "golden" / f"audio_{'16k' if sr == 16000 else '8k'}.npz")["pcm"]
+    idx = (np.arange(cap, dtype=np.int64)[:, None] * 7919 + np.arange(L, dtype=np.int64)[None, :]) % len(pcm)
+    return pcm[idx]
+
+
+def h2d_rate_GBps(dev, nbytes=256 << 20, reps=5):
+    """What the host link gives a plain pinned -> HBM copy on this box, now (the ceiling the host-fed legs are held against)."""
+    import torch
+    src = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        best = max(best, nbytes / (time.perf_counter() - t0) / 1e9)
+    return best
+
+
+def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
+    """configs[4] END TO END, the shape of the reference's streaming caller (src/silero_vad/utils_vad.py:507-549: host chunk in,
+    event out): int16 chunks lie in a page-locked ingest ring (what the audio sources write into), ONE hipGraph per ring slot
+    does H2D -> the fused step -> D2H of the probabilities, the host runs the iterator logic of every stream (native
+    vad_iterator_feed) and holds the events.  Two measurements:
+      latency    ONE pool of all `cap` streams, one tick at a time: submit -> probabilities on the host -> events (median / p95)
+      sustained  the same streams as `parts` sub-pools on their own streams (clones of the engine), two ring slots in flight: one
+                 sub-pool's H2D runs beside another's kernel and the host's event pass; chunks/s against the PCIe ceiling"""
+    import numpy as np
+    import torch
+    from silero_vad_amd import BatchVADIterator, Engine, StreamPool
+    dev = torch.device("cuda", local)
+    n = WORK[sr]["chunk"]
+    cap = args.live
+    R = 8                                                       # ingest ring: 8 ticks of audio per stream
+    parts = max(1, int(os.environ.get("VAD_BENCH_STREAM_PARTS", "4")))
+    rows = fixture_rows_i16(sr, cap, R * n)                     # real speech: the iterators do produce events
+    eng = Engine(device=local)
+
+    def make(lo, hi):
+        pool = StreamPool(eng.clone(), sr, capacity=hi - lo, graph=True, dtype=torch.int16, host_slots=R)
+        pool.open_all()
+        ring = pool.host_pcm.numpy()
+        for r in range(R):
+            ring[r][:] = rows[lo:hi, r * n:(r + 1) * n]
+        return pool
+
+    # -- latency: one pool, one tick at a time --------------------------------------------------------------------------------
+    whole = make(0, cap)
+    it = BatchVADIterator(cap, sampling_rate=sr)
+    n_events = 0
+    for k in range(300):                                        # warm-up + clock ramp
+        whole.tick_host(k % R)
+    lat, lat_gpu = [], []
+    for k in range(400):
+        t0 = time.perf_counter()
+        p = whole.tick_host(k % R)
+        t1 = time.perf_counter()
+        n_events += len(it.feed(p.numpy()))
+        t2 = time.perf_counter()
+        lat.append((t2 - t0) * 1e3)
+        lat_gpu.append((t1 - t0) * 1e3)
+    lat.sort()
+    lat_gpu.sort()
+    parity = None
+    if not args.no_parity:
+        def feed(j):
+            return whole.tick_host(j % R).clone(), rows[:16, (j % R) * n:(j % R + 1) * n].astype(np.float32) / 32768.0
+        parity = certify_pool(whole, feed, 3 * R, sr, f"streams 0..15 of {cap}, {3 * R} ticks of int16 speech from zero state: ingest ring "
+                                                       "-> H2D + step + D2H graph -> host")
+    del whole
+    # -- sustained: sub-pools, two ring slots in flight ------------------------------------------------------------------------
+    cuts = [cap * i // parts for i in range(parts + 1)]
+    pools = [make(cuts[i], cuts[i + 1]) for i in range(parts)]
+    its = [BatchVADIterator(cuts[i + 1] - cuts[i], sampling_rate=sr) for i in range(parts)]
+    ev_count = [0]
+    state = {"k": 0}
+
+    def run(nt):
+        """nt ticks of all streams; tick k + 1 is submitted before tick k's probabilities are read."""
+        k0 = state["k"]
+        for k in range(k0, k0 + nt + 1):
+            if k < k0 + nt:
+                for q in pools:
+                    q.submit(k % R)
+            if k > k0:
+                for q, qi in zip(pools, its):
+                    ev_count[0] += len(qi.feed(q.wait((k - 1) % R).numpy()))
+        state["k"] = k0 + nt
+
+    run(600)                                                    # warm-up + clock ramp
+    ev_count[0] = 0
+    elapsed = timed(world, dist, dev, 1, lambda: run(ticks), gpu_sync)
+    link = h2d_rate_GBps(dev)
+    if rank != 0:
+        return None
+    value = cap * world * ticks / elapsed
+    out = base_line(args, world, sr, value, elapsed, ticks)
+    out["ms_per_step"] = round(elapsed / ticks * 1e3, 4)
+    out["config"] = {"workload": f"configs[4] END TO END: {cap} live {sr // 1000} kHz streams/GPU ({cap * 8} per 8-GPU node), int16 chunks in a page-locked "
+                                 f"ingest ring -> ONE hipGraph per tick (H2D, fused vad_step, D2H of the probabilities) -> VADIterator logic of every "
+                                 "stream on the host (vad_iterator_feed) -> events; (h,c)+context persistent in HBM; real-speech fixture audio",
+                     "streams_per_gpu": cap, "sample_rate": sr, "step": "one tick (one chunk per stream)", "sub_pools": parts, "ring_slots": R,
+                     "sharding": f"streams x{world}, no collectives"}
+    out["dtype"] = "f32"
+    out["realtime_factor"] = round(value * 0.032, 1)
+    out["events_emitted"] = {"latency_pass": n_events, "sustained_pass": ev_count[0]}
+    out["tick_latency_ms"] = {"median": round(lat[len(lat) // 2], 4), "p95": round(lat[int(len(lat) * 0.95)], 4),
+                              "to_probabilities_on_host_median": round(lat_gpu[len(lat_gpu) // 2], 4), "budget_ms": 32.0,
+                              "what": "ONE pool of all streams, one tick at a time: submit(graph: H2D -> step -> D2H) -> wait -> events"}
+    ceiling = link * 1e9 / (n * 2) * world
+    out["pcie"] = {"h2d_GBps_plain_copy": round(link, 2), "int16_ceiling_chunks_per_s": round(ceiling, 1),
+                   "fraction_of_pcie_ceiling": round(value / ceiling, 3),
+                   "bytes_per_tick": cap * n * 2}
+    out["parity"] = parity
+    if parity and world == 1:
+        require_parity(parity, f"stream_host {sr // 1000} kHz")
     return out
 
 
@@ -664,14 +858,16 @@ def run_corpus(args, rank, world, local, dist, passes):
 
 
 # ---- plumbing: the reference's default usage, one chunk per call (configs[0]) -----------------------------
-def run_plumbing(args, local):
+def run_plumbing(args, local, sr=16000):
     """B = 1: what an unmodified caller does -- `model(chunk, sr).item()` once per 32 ms chunk
     (src/silero_vad/utils_vad.py:324-336, :528; the reference advertises "< 1 ms per chunk", README.md:103)."""
     import numpy as np
     import torch
     from silero_vad_amd import Engine, StreamPool, get_speech_timestamps, load_silero_vad
-    sr, n = 16000, 512
-    wav = torch.from_numpy(np.load(ROOT / "tests" / "golden" / "audio_16k.npz")["pcm"].astype(np.float32) / 32768.0)
+    n = WORK[sr]["chunk"]
+    tag = "16k" if sr == 16000 else "8k"
+    expect = {"16k": 19, "8k": 44}[tag]                       # what the reference returns for the fixture (SURVEY.md section 8c)
+    wav = torch.from_numpy(np.load(ROOT / "tests" / "golden" / f"audio_{tag}.npz")["pcm"].astype(np.float32) / 32768.0)
     model = load_silero_vad(device=local)
 
     def med(xs):
@@ -697,7 +893,7 @@ def run_plumbing(args, local):
         pool.tick(c).item()
         lat.append(time.perf_counter() - t0)
     graph_ms = med(lat[60:])
-    # (c) get_speech_timestamps on the 60 s fixture: the one-call fast path, and the unmodified per-chunk protocol
+    # (c) get_speech_timestamps on the fixture: the one-call fast path, and the unmodified per-chunk protocol
     class PerChunk:                                            # hides audio_forward_device: the caller loops over chunks
         def __init__(self, m):
             self.m = m
@@ -708,16 +904,19 @@ def run_plumbing(args, local):
     t0 = time.perf_counter(); ts_fast = get_speech_timestamps(wav, model, sampling_rate=sr); fast_s = time.perf_counter() - t0
     t0 = time.perf_counter(); ts_fast = get_speech_timestamps(wav, model, sampling_rate=sr); fast_s = time.perf_counter() - t0
     t0 = time.perf_counter(); ts_chunk = get_speech_timestamps(wav, PerChunk(model), sampling_rate=sr); chunk_s = time.perf_counter() - t0
-    if len(ts_fast) != 19 or ts_chunk != ts_fast:
-        raise RuntimeError(f"plumbing: expected the reference's 19 segments, got {len(ts_fast)} / {len(ts_chunk)}")
+    if len(ts_fast) != expect or ts_chunk != ts_fast:
+        raise RuntimeError(f"plumbing: expected the reference's {expect} segments, got {len(ts_fast)} / {len(ts_chunk)}")
     chunks = (len(wav) + n - 1) // n
-    return {"workload": "configs[0]: tests/data/test.wav (60 s, 16 kHz) through the reference's per-chunk protocol, B = 1",
+    secs = len(wav) / sr
+    return {"workload": f"configs[0]: the reference's fixture ({secs:.0f} s, {sr // 1000} kHz) through the reference's per-chunk protocol, B = 1",
             "per_call_latency_ms": {"eager_model_call_item": eager_ms, "hipgraph_step_item": graph_ms,
-                                    "note": "host chunk in -> float out, median of 400 calls (H2D of the chunk, 2 kernels, D2H of the probability)"},
-            "get_speech_timestamps_60s": {"segments": len(ts_fast), "one_call_fast_path_ms": round(fast_s * 1e3, 2),
-                                          "per_chunk_protocol_ms": round(chunk_s * 1e3, 1), "chunks": chunks,
-                                          "per_chunk_protocol_ms_per_chunk": round(chunk_s * 1e3 / chunks, 4),
-                                          "identical_segments": True},
+                                    "note": "host chunk in -> float out, median of 400 calls (H2D of the chunk, one fused kernel, D2H of the probability)"},
+            f"get_speech_timestamps_{secs:.0f}s": {"segments": len(ts_fast), "one_call_fast_path_ms": round(fast_s * 1e3, 2),
+                                                  "per_chunk_protocol_ms": round(chunk_s * 1e3, 1), "chunks": chunks,
+                                                  "per_chunk_protocol_ms_per_chunk": round(chunk_s * 1e3 / chunks, 4),
+                                                  "identical_segments": True,
+                                                  "cpu_beside_it": "cpu_baseline.runs.R5_get_speech_timestamps_fixture (16 kHz fixture: the same "
+                                                                   "call over the reference's ATen operators, one thread)"},
             "reference_claim": "< 1 ms per chunk on one CPU thread (README.md:103); measured CPU R1 in cpu_baseline"}
 
 
@@ -784,10 +983,10 @@ def small(d):
         return None
     keep = ("value", "unit", "steps", "ms_per_step", "dtype", "kernel_ms", "tick_latency_ms", "legs", "wall_s", "n_gpus",
             "audio_hours_all_gpus", "ten_k_hours_at_this_rate_s", "parity_sample", "parity_sample_max_abs_dp",
-            "outputs_finite", "realtime_factor", "timed_region_s")
+            "outputs_finite", "realtime_factor", "timed_region_s", "parity", "parity_max_abs_dp", "pcie", "events_emitted")
     out = {k: d[k] for k in keep if k in d}
     out["workload"] = d["config"]["workload"]
-    for k in ("sharding", "host_threads_per_rank", "numa_node_bound", "recordings_per_gpu", "audio_hours_per_gpu"):
+    for k in ("sharding", "host_threads_per_rank", "numa_node_bound", "recordings_per_gpu", "audio_hours_per_gpu", "sub_pools", "ring_slots"):
         if k in d["config"]:
             out[k] = d["config"][k]
     if "roofline" in d:
@@ -800,7 +999,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["c2", "8k", "stream", "corpus", "plumbing"], default="c2")
+    ap.add_argument("--config", choices=["c2", "8k", "stream", "stream_host", "stream_8k", "stream_host_8k", "corpus", "plumbing", "plumbing_8k"],
+                    default="c2")
     ap.add_argument("--streams", type=int, default=STREAMS, help=argparse.SUPPRESS)
     ap.add_argument("--chunks", type=int, default=CHUNKS_PER_STREAM, help=argparse.SUPPRESS)
     ap.add_argument("--live", type=int, default=LIVE_STREAMS, help=argparse.SUPPRESS)
@@ -812,7 +1012,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs")
     ap.add_argument("--dry", action="store_true", help="no GPU: exercise launch/shard/gather/barrier/reduce/print only (gloo)")
     args = ap.parse_args()
-    default_steps = {"c2": 200, "8k": 200, "stream": 2000, "corpus": 1, "plumbing": 1}   # corpus: one step = the whole shard
+    default_steps = {"c2": 200, "8k": 200, "stream": 2000, "stream_8k": 2000, "stream_host": 2000, "stream_host_8k": 2000,
+                     "corpus": 1, "plumbing": 1, "plumbing_8k": 1}   # corpus: one step = the whole shard
     if args.steps is None:
         args.steps = default_steps[args.config]
 
@@ -838,20 +1039,26 @@ def main():
         if args.config in ("c2", "8k"):
             sr = 16000 if args.config == "c2" else 8000
             out = run_batch(args, sr, rank, world, local, dist, args.steps, with_other=extras and args.config == "c2")
-        elif args.config == "stream":
-            out = run_stream(args, rank, world, local, dist, args.steps)
+        elif args.config in ("stream", "stream_8k"):
+            out = run_stream(args, rank, world, local, dist, args.steps, 16000 if args.config == "stream" else 8000)
+        elif args.config in ("stream_host", "stream_host_8k"):
+            out = run_stream_host(args, rank, world, local, dist, args.steps, 16000 if args.config == "stream_host" else 8000)
         elif args.config == "corpus":
             out = run_corpus(args, rank, world, local, dist, args.corpus_passes)
         else:
             out = {"metric": "per-call latency (plumbing, no throughput claim)", "value": None, "n_gpus": 1,
-                   "config": {"workload": "configs[0]"}, "plumbing": run_plumbing(args, local)}
+                   "config": {"workload": "configs[0]"}, "plumbing": run_plumbing(args, local, 16000 if args.config == "plumbing" else 8000)}
         if extras and args.config == "c2":              # the other BASELINE configs, for the record
             oc = {}
             legs = [("stream", lambda: run_stream(args, rank, world, local, dist, 1000)),
+                    ("stream_host", lambda: run_stream_host(args, rank, world, local, dist, 1000)),
                     ("corpus", lambda: run_corpus(args, rank, world, local, dist, args.corpus_passes))]
             if world == 1:
                 legs = [("8k", lambda: run_batch(args, 8000, rank, world, local, dist, 100))] + legs + \
-                       [("plumbing", lambda: {"config": {"workload": "configs[0]"}, **run_plumbing(args, local)})]
+                       [("stream_8k", lambda: run_stream(args, rank, world, local, dist, 1000, 8000)),
+                        ("stream_host_8k", lambda: run_stream_host(args, rank, world, local, dist, 1000, 8000)),
+                        ("plumbing", lambda: {"config": {"workload": "configs[0]"}, **run_plumbing(args, local)}),
+                        ("plumbing_8k", lambda: {"config": {"workload": "configs[0], 8 kHz"}, **run_plumbing(args, local, 8000)})]
             for name, fn in legs:
                 if world > 1:                           # every rank takes part in a leg's barriers: no swallowing of errors there
                     r = fn()
@@ -860,7 +1067,7 @@ def main():
                     continue
                 try:
                     r = fn()
-                    oc[name] = r if name == "plumbing" else small(r)
+                    oc[name] = r if name.startswith("plumbing") else small(r)
                 except Exception as e:                  # an extra must never cost the headline line
                     oc[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             if rank == 0:

@@ -202,6 +202,18 @@ int  vad_segment_probs_device(vad_engine *e, const float *probs, long ldp, const
                               const long *n_chunks, long n_chunks_all, const long *audio_len, const vad_segment_params *p,
                               vad_segment *out, long cap_per_stream, long *counts, void *stream);
 
+/* The streaming caller, VADIterator.__call__ (src/silero_vad/utils_vad.py:507-549), for every slot of a lock-step batch: probs[n]
+ * = this tick's probabilities (what vad_step left, copied to the host), active (may be NULL = all) marks the slots that carry a
+ * live stream.  triggered / temp_end / current_sample are the iterator's per-stream state (zero after a reset, :500-503), updated
+ * in place.  Writes at most `cap` events (slot order; kind 0 = {'start': sample}, 1 = {'end': sample}, the numbers the reference
+ * iterator returns for that stream) and returns how many there were (may exceed cap; at most n), <0 on bad arguments.
+ * threshold, min_silence_samples = sr * min_silence_duration_ms / 1000 and speech_pad_samples = sr * speech_pad_ms / 1000 are
+ * doubles because the reference compares Python floats (:494-498).                                                          */
+typedef struct vad_iter_event { int32_t slot; int32_t kind; int64_t sample; } vad_iter_event;
+long vad_iterator_feed(const float *probs, const uint8_t *active, long n, int window, double threshold,
+                       double min_silence_samples, double speech_pad_samples, uint8_t *triggered,
+                       int64_t *temp_end, int64_t *current_sample, vad_iter_event *out, long cap);
+
 /* ---- host-side ingest ---------------------------------------------------------------------------------
  * Pack n recordings of different lengths (lens[i] samples of elem_size 2 = int16 or 4 = float32 at
  * rows[i]) into one zero-padded row-major [n][width] batch at dst (typically pinned host memory that

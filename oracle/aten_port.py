@@ -204,10 +204,47 @@ def run_protocol(name, sr, share_s, trials=5, warmup=3):
             res = pool.map(_worker, [(sr, Bp, share_s, warmup, trials, 100 + i) for i in range(ncpu)])
         return {"chunks_per_s": round(sum(r[0] for r in res), 1), "B_per_proc": Bp, "T": res[0][1], "procs": ncpu,
                 "threads": 1}
+    if name == "R5_get_speech_timestamps_fixture":
+        # the reference's default usage end to end -- get_speech_timestamps over the 60 s / 169 s fixture,
+        # one model(chunk, sr).item() per 32 ms chunk on one thread (src/silero_vad/utils_vad.py:324-336), then the scan.  The
+        # caller is silero_vad_amd.timestamps.get_speech_timestamps driving this port through the per-chunk protocol (the port has
+        # no one-call fast path); its scan is the native one, which favours the CPU figure by the ~0.07 ms per chunk the reference's
+        # Python scan loop costs.
+        import numpy as np
+        from silero_vad_amd.timestamps import get_speech_timestamps
+        torch.set_num_threads(1)
+        tag = "16k" if sr == 16000 else "8k"
+        pcm = np.load(HERE.parent / "tests" / "golden" / f"audio_{tag}.npz")["pcm"]
+        wav = torch.from_numpy(pcm.astype(np.float32) / 32768.0)
+        n = 512 if sr == 16000 else 256
+        chunks = (len(wav) + n - 1) // n
+
+        class PerChunk:                                   # hides audio_forward: the caller loops over chunks, as the reference does
+            def __init__(self, m):
+                self.m = m
+
+            def reset_states(self):
+                self.m.reset_states()
+
+            def __call__(self, x, sr):
+                return self.m(x, sr)
+
+        m = PerChunk(AtenVAD())
+        get_speech_timestamps(wav[:n * 50], m, sampling_rate=sr)      # first touch
+        ts, segs = [], None
+        for _ in range(max(1, min(trials, 3))):
+            t0 = time.perf_counter()
+            segs = get_speech_timestamps(wav, m, sampling_rate=sr)
+            ts.append(time.perf_counter() - t0)
+        dt = statistics.median(ts)
+        return {"chunks_per_s": round(chunks / dt, 1), "wall_ms": round(dt * 1e3, 1), "chunks": chunks, "segments": len(segs),
+                "expected_segments": {"16k": 19, "8k": 44}[tag], "B": 1, "threads": 1,
+                "what": "get_speech_timestamps on the fixture, per-chunk model(chunk, sr).item() protocol + scan"}
     raise ValueError(name)
 
 
 PROTOCOLS = ("R1_1thread_B1", "R2_1thread_B4096", "R3_nproc_threads_B4096", "R4_nproc_procs_1thread")
+EXTRA_PROTOCOLS = ("R5_get_speech_timestamps_fixture",)      # another workload (one file, end to end): reported, never `best`
 
 
 def baseline(sr=16000, budget_s=25.0, trials=5, warmup=3):
@@ -227,7 +264,7 @@ def baseline(sr=16000, budget_s=25.0, trials=5, warmup=3):
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_WAIT_POLICY="passive",
                KMP_BLOCKTIME="0", GOMP_SPINCOUNT="0")
     res = {}
-    for name in PROTOCOLS:
+    for name in PROTOCOLS + EXTRA_PROTOCOLS:
         try:
             r = subprocess.run([sys.executable, "-m", "oracle.aten_port", "--sr", str(sr), "--protocol", name,
                                 "--share-s", str(share)], cwd=str(HERE.parent), env=env, capture_output=True,
@@ -237,7 +274,7 @@ def baseline(sr=16000, budget_s=25.0, trials=5, warmup=3):
         except subprocess.TimeoutExpired:
             res[name] = {"error": f"timed out after {4 * share + 45:.0f} s"}
     out["runs"] = res
-    ok = {k: v for k, v in res.items() if "chunks_per_s" in v}
+    ok = {k: v for k, v in res.items() if "chunks_per_s" in v and k in PROTOCOLS}
     out["best"] = max(ok, key=lambda k: ok[k]["chunks_per_s"]) if ok else None
     out["value"] = ok[out["best"]]["chunks_per_s"] if ok else None
     return out

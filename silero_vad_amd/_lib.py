@@ -33,6 +33,10 @@ class Segment(Structure):
     _fields_ = [("start", c_int64), ("end", c_int64)]
 
 
+class IterEvent(Structure):
+    _fields_ = [("slot", ctypes.c_int32), ("kind", ctypes.c_int32), ("sample", c_int64)]
+
+
 # every symbol include/silero_vad_hip.h declares: name -> (restype, argtypes)
 f32p, i16p = POINTER(c_float), POINTER(c_int16)
 SYMBOLS = {
@@ -60,6 +64,8 @@ SYMBOLS = {
                                          POINTER(c_long), c_int]),
     "vad_segment_probs_device": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p,
                                          POINTER(SegmentParams), c_void_p, c_long, c_void_p, c_void_p]),
+    "vad_iterator_feed": (c_long, [c_void_p, c_void_p, c_long, c_int, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_long]),
     "vad_stage_rows": (c_int, [POINTER(c_void_p), POINTER(c_long), c_long, c_long, c_size_t, c_void_p, c_int]),
     "vad_upload_rows": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_long), c_long, c_long, c_size_t, c_void_p, c_int,
                                 c_void_p]),

@@ -742,15 +742,28 @@ struct Registered {
 std::mutex g_reg_mutex;
 std::map<const uint8_t *, Registered> g_registered;       // hipHostRegister'ed ranges and their device-side addresses
 
-// device-visible address of a pinned host pointer: registered ranges translate, hipHostMalloc'ed memory is identity-mapped
+// device-visible address of a pinned host pointer, or nullptr if the runtime does not know it as page-locked memory: ranges
+// registered through vad_host_register translate from the table; anything else (hipHostMalloc / torch pin_memory: identity-mapped;
+// memory page-locked by somebody else's hipHostRegister: NOT necessarily) is resolved by the runtime -- the gather kernel must never
+// dereference a host virtual address on faith.
 const void *device_view(const void *p) {
-    std::lock_guard<std::mutex> g(g_reg_mutex);
-    if (g_registered.empty()) return p;
-    auto it = g_registered.upper_bound(static_cast<const uint8_t *>(p));
-    if (it == g_registered.begin()) return p;
-    --it;
-    const size_t off = static_cast<const uint8_t *>(p) - it->first;
-    return off < it->second.bytes ? static_cast<const uint8_t *>(it->second.dev) + off : p;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mutex);
+        if (!g_registered.empty()) {
+            auto it = g_registered.upper_bound(static_cast<const uint8_t *>(p));
+            if (it != g_registered.begin()) {
+                --it;
+                const size_t off = static_cast<const uint8_t *>(p) - it->first;
+                if (off < it->second.bytes) return static_cast<const uint8_t *>(it->second.dev) + off;
+            }
+        }
+    }
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, const_cast<void *>(p), 0) != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return dev;
 }
 }  // namespace
 
@@ -815,7 +828,17 @@ int vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, lo
         e->tab_cap[slot] = cap;
     }
     if (!e->tab_ev[slot]) HIP_TRY(e, hipEventCreateWithFlags(&e->tab_ev[slot], hipEventDisableTiming));
-    for (long i = 0; i < n; ++i) e->h_tab[slot][i] = vad::RowDesc{lens[i] ? device_view(rows[i]) : nullptr, lens[i]};
+    if (how == 2) {                                    // rows[] are device addresses already
+        for (long i = 0; i < n; ++i) e->h_tab[slot][i] = vad::RowDesc{lens[i] ? rows[i] : nullptr, lens[i]};
+    } else {
+        for (long i = 0; i < n; ++i) {
+            const void *dv = lens[i] ? device_view(rows[i]) : nullptr;
+            if (lens[i] && !dv)
+                return fail(e, VAD_ERR_ARG, "vad_upload_rows: a row is not in page-locked memory the runtime knows "
+                                            "(hipHostMalloc / pin_memory / vad_host_register)");
+            e->h_tab[slot][i] = vad::RowDesc{dv, lens[i]};
+        }
+    }
     HIP_TRY(e, vad::launch_gather_rows(e->h_tab[slot], n, width, (int)elem_size, dst, how == 2, stream));
     HIP_TRY(e, hipEventRecord(e->tab_ev[slot], stream));
     e->tab_busy[slot] = true;

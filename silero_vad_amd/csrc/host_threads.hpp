@@ -13,6 +13,7 @@
 // Where.  vad_bind_host_to_device (engine.hip) narrows the calling thread's affinity to the CPUs of the GPU's NUMA node;
 // pool threads are created afterwards and inherit it, and pinned buffers allocated afterwards are first touched there.
 #pragma once
+#include <pthread.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -21,6 +22,7 @@
 #include <cstdlib>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -75,6 +77,10 @@ inline int default_host_threads(int cap) {
 // caller and returns when all are done.  Threads are created on first use (after any affinity binding the process did) and sleep on a condition
 // variable between calls; one run at a time (callers are serialised by a mutex: the engine's users are single-threaded
 // per engine, but the pool is process-wide).
+//
+// fork(): only the forking thread exists in the child, the workers do not.  pthread_atfork handlers take both mutexes around the
+// fork (so the child never inherits one held by a thread that is not there) and mark the child's copy of the pool; the child drops
+// the stale thread handles (detach: nothing to join) before its first run and in its destructor, and grows a pool of its own.
 class HostPool {
 public:
     static HostPool &get() {
@@ -83,6 +89,7 @@ public:
     }
     int size() {                               // worker threads + the caller
         std::lock_guard<std::mutex> g(api_);
+        drop_stale();
         return (int)threads_.size() + 1;
     }
     void run(int nthreads, int n, const std::function<void(int)> &fn) {
@@ -93,6 +100,7 @@ public:
             return;
         }
         std::lock_guard<std::mutex> g(api_);
+        drop_stale();
         ensure(nthreads - 1);
         {
             std::lock_guard<std::mutex> l(m_);
@@ -111,8 +119,9 @@ public:
     }
 
 private:
-    HostPool() = default;
+    HostPool() { pthread_atfork(&HostPool::before_fork, &HostPool::after_fork_parent, &HostPool::after_fork_child); }
     ~HostPool() {
+        drop_stale();
         {
             std::lock_guard<std::mutex> l(m_);
             stop_ = true;
@@ -120,6 +129,32 @@ private:
         }
         cv_.notify_all();
         for (auto &t : threads_) t.join();
+    }
+    static void before_fork() {
+        get().api_.lock();
+        get().m_.lock();
+    }
+    static void after_fork_parent() {
+        get().m_.unlock();
+        get().api_.unlock();
+    }
+    static void after_fork_child() {
+        HostPool &p = get();
+        p.forked_ = true;                       // threads_ lists threads of the PARENT process
+        p.fn_ = nullptr;
+        p.next_ = p.total_ = p.pending_ = p.limit_ = 0;
+        // the parent's workers were asleep on cv_: its copy here still counts waiters that do not exist (a glibc condition variable in
+        // that state can block its next signaller for good).  Fresh objects in place, the old ones are not destroyed.
+        new (&p.cv_) std::condition_variable();
+        new (&p.done_) std::condition_variable();
+        new (&p.m_) std::mutex();
+        new (&p.api_) std::mutex();
+    }
+    void drop_stale() {
+        if (!forked_) return;
+        for (auto &t : threads_) t.detach();    // handles of threads that do not exist here: nothing to join
+        threads_.clear();
+        forked_ = false;
     }
     void ensure(int want) {
         want = std::min(want, 255);
@@ -163,6 +198,7 @@ private:
     int next_ = 0, total_ = 0, pending_ = 0, limit_ = 0;
     unsigned long epoch_ = 0;
     bool stop_ = false;
+    bool forked_ = false;
 };
 
 }  // namespace vad

@@ -8,8 +8,8 @@
 // to touch them on the CPU: this kernel reads them over PCIe (host memory is mapped into the GPU's address space) and
 // writes the device batch, padding included, in ONE launch for any number of rows.
 //
-//   * a persistent grid of 48 ONE-WAVE workgroups walks the (row, 8 KiB segment) pairs, 8 x 16 B per lane in flight: enough
-//     outstanding reads for the link, on 5 % of the chip's SIMDs (see the kernel's comment for why so few);
+//   * a persistent grid of VAD_GATHER_WAVES (96) ONE-WAVE workgroups walks the (row, 8 KiB segment) pairs, 8 x 16 B per lane in
+//     flight: enough outstanding reads for the link, on 9 % of the chip's SIMDs (see the kernel's comment for why so few);
 //   * rows whose source address is 16-byte aligned move as 16-byte vectors; others (a view that starts at an odd sample)
 //     fall back to element-wise loads for that row (wave-uniform choice) -- correct for any alignment, fast for the usual;
 //   * the row table (pointer, length) is itself read from pinned memory, so the host only fills a small table and launches.
@@ -27,10 +27,10 @@ constexpr int kSegBytes = 8192;        // one wave-iteration: 64 lanes x 16 B x 
 constexpr int kGatherWaves = VAD_GATHER_WAVES;   // one-wave workgroups: the whole kernel occupies this many of the chip's 1024 SIMDs
 
 // One wave per workgroup, a persistent grid of kGatherWaves: each iteration a wave moves one 8 KiB segment of one row with 8
-// independent 16-byte loads per lane in flight (48 waves x 8 KiB = 384 KiB outstanding against PCIe's ~100-150 KB
-// bandwidth-delay product).  The footprint is deliberate: a first version with 256 four-wave workgroups reached the same
+// independent 16-byte loads per lane in flight (96 waves x 8 KiB = 768 KiB outstanding against PCIe's ~100-150 KB
+// bandwidth-delay product; 48 waves reach the same rate alone and lose more to the compute kernels beside them).  The footprint is deliberate: a first version with 256 four-wave workgroups reached the same
 // 53 GB/s but sat on every SIMD of the chip, where its registers kept the frontend (two 243-VGPR waves per SIMD) from
-// placing its second wave: the compute kernels beside it ran 4x slower (tools/ingest_diag.py).  48 single waves touch 5 % of
+// placing its second wave: the compute kernels beside it ran 4x slower (tools/ingest_diag.py).  96 single waves touch 9 % of
 // the SIMDs.
 __global__ void __launch_bounds__(64) gather_rows_kernel(const RowDesc *rows, long n, long width_bytes, int esz, uint8_t *dst,
                                                          long segs_per_row) {

@@ -67,3 +67,41 @@ extern "C" long vad_segment_probs_batch(const float *probs, long ldp, long n_str
     for (long i = 0; i < n_streams; ++i) total += counts[i];
     return total;
 }
+
+// VADIterator (reference src/silero_vad/utils_vad.py:507-549) for every slot of a lock-step batch: one call advances all n streams
+// by one chunk of `window` samples.  The reference's conventions: current_sample counts the END of the chunk, the entry test is
+// p >= threshold, the exit threshold is fixed at threshold - 0.15 (in double, like Python), a pending end is dropped by the next
+// loud chunk, positions are shifted back by one window and truncated like int().  Events come out in slot order.
+extern "C" long vad_iterator_feed(const float *probs, const uint8_t *active, long n, int window, double threshold,
+                                  double min_silence_samples, double speech_pad_samples, uint8_t *triggered,
+                                  int64_t *temp_end, int64_t *current_sample, vad_iter_event *out, long cap) {
+    if (n < 0 || window <= 0 || cap < 0 || (n > 0 && (!probs || !triggered || !temp_end || !current_sample)) || (cap > 0 && !out))
+        return -1;
+    const double exit_thr = threshold - 0.15;
+    long m = 0;
+    for (long s = 0; s < n; ++s) {
+        if (active && !active[s]) continue;
+        const double p = (double)probs[s];
+        const int64_t cs = (current_sample[s] += window);
+        const bool loud = p >= threshold;
+        if (loud && temp_end[s]) temp_end[s] = 0;
+        if (loud && !triggered[s]) {
+            triggered[s] = 1;
+            double start = (double)cs - speech_pad_samples - (double)window;
+            if (start < 0) start = 0;
+            if (m < cap) out[m] = vad_iter_event{(int32_t)s, 0, (int64_t)start};
+            ++m;
+            continue;
+        }
+        if (p < exit_thr && triggered[s]) {
+            if (!temp_end[s]) temp_end[s] = cs;
+            if ((double)(cs - temp_end[s]) < min_silence_samples) continue;
+            const double end = (double)temp_end[s] + speech_pad_samples - (double)window;
+            temp_end[s] = 0;
+            triggered[s] = 0;
+            if (m < cap) out[m] = vad_iter_event{(int32_t)s, 1, (int64_t)end};
+            ++m;
+        }
+    }
+    return m;
+}

@@ -222,7 +222,11 @@ class HipSileroVAD:
         if x.dtype != torch.int16:
             x = x.to(torch.float32)
         x = x.to(self.device, non_blocking=True)
-        return x if x.stride(-1) == 1 else x.contiguous()     # rows may be strided (the engine takes a row pitch)
+        # rows may be strided (the engine takes a row pitch) -- but not overlapping: `x.expand(B, -1)` (stride 0) or an
+        # `unfold` view (row stride < row length) is materialised, as the reference's operators would read it
+        if x.stride(-1) == 1 and (x.shape[0] == 1 or x.stride(0) >= x.shape[1]):
+            return x
+        return x.contiguous()
 
     def _ensure_state(self, sr, batch_size):
         if self._last_sr and self._last_sr != sr:
@@ -237,7 +241,11 @@ class HipSileroVAD:
 
     # -- reference: vad_annotator.py:14-90 ------------------------------------------------------------
     def __call__(self, x, sr: int):
+        """-> Tensor[B, 1] on the device the INPUT lives on: a CPU chunk gives a CPU tensor, like the reference's model
+        objects (src/silero_vad/utils_vad.py:91-92: `.item()` and `.numpy()` callers both work); a CUDA chunk keeps the
+        result in HBM (no host synchronisation)."""
         x, sr_raw, sr, n_net = self._front_door(x, sr)
+        home = x.device
         num_samples = 512 if sr == 16000 else 256
         if n_net != num_samples:
             raise ValueError(_MSG_SAMPLES.format(n_net))
@@ -254,7 +262,7 @@ class HipSileroVAD:
                 self.engine.forward_audio(xd, sr_raw, self._context, self._state, out)
         self._last_sr = sr
         self._last_batch_size = batch_size
-        return out
+        return out if home.type == self.device.type else out.to(home)
 
     forward = __call__
 
@@ -274,6 +282,24 @@ class HipSileroVAD:
         self._last_sr = sr
         self._last_batch_size = batch_size
         return probs
+
+
+    def audio_forward_slabs(self, x, sr: int, slab_chunks: int = 256):
+        """`audio_forward_device` in time slabs of `slab_chunks` chunks with the state carried between them: yields
+        (index of the slab's first chunk, probs[B, t] in HBM) slab by slab -- the same probabilities as one call (the engine slabs
+        long inputs internally the same way).  What `get_speech_timestamps` uses to fire its `progress_tracking_callback` while
+        the recording is being processed, as the reference's per-chunk loop does (src/silero_vad/utils_vad.py:330-336)."""
+        x, sr_raw, sr, _ = self._front_door(x, sr)
+        self.reset_states()
+        batch_size = x.shape[0]
+        self._ensure_state(sr, batch_size)
+        raw = (512 if sr == 16000 else 256) * (sr_raw // sr)       # raw samples per chunk
+        with self._device_ctx():
+            xd = self._to_device(x)
+            for s in range(0, xd.shape[1], slab_chunks * raw):
+                yield s // raw, self.engine.forward_audio(xd[:, s:s + slab_chunks * raw], sr_raw, self._context, self._state)
+        self._last_sr = sr
+        self._last_batch_size = batch_size
 
 
 def load_silero_vad(onnx=False, opset_version=16, device=0, precision="fp32"):

@@ -399,8 +399,13 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
                 j = v % 3
                 nb = (b - a) * esz
                 if win["buf"][j] is None or win["buf"][j].numel() < nb:
+                    # (the old block goes back to the caching allocator: its cuts on pool.stream were recorded against it
+                    #  -- record_stream below -- and the copy stream waits for the last of them before anything else)
+                    if win["free"][j] is not None:
+                        win["stream"].wait_event(win["free"][j])
                     with torch.cuda.stream(win["stream"]):
                         win["buf"][j] = torch.empty(max(nb, 1 << 20), dtype=torch.uint8, device=dev)
+                    win["buf"][j].record_stream(pool.stream)  # allocated on the copy stream, read by the cut kernels on pool.stream
                     win["free"][j] = None
                 if win["free"][j] is not None:                # every bucket cut from the buffer's previous window is done
                     win["stream"].wait_event(win["free"][j])
@@ -439,7 +444,14 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             eng_l = getattr(lane_model, "engine", None)
             if eng_l is not None and hasattr(eng_l, "set_transient"):
                 rec_form_before.append((eng_l, eng_l.options.get("rec_form", "auto")))
-                eng_l.set_transient("rec_form", lane_form)
+
+    def pin_lanes(on):
+        """The pin holds only while this generator runs: it is taken back before every `yield` (the caller's own engine is lane 0;
+        a consumer that never exhausts the generator must not be left with the slower form) and re-applied on resumption."""
+        for eng_l, form in rec_form_before:
+            eng_l.set_transient("rec_form", lane_form if on else form)
+
+    pin_lanes(True)
 
     def stage(k):
         idxs = plan.buckets[k]
@@ -531,18 +543,24 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             while len(inflight) > len(lane_list):
                 first = inflight.pop(0)
                 first[2].synchronize()
+                pin_lanes(False)
                 yield finish(first)
+                pin_lanes(True)
         for first in inflight:
             first[2].synchronize()
+            pin_lanes(False)
             yield finish(first)
+            pin_lanes(True)
     finally:
-        for eng_l, form in rec_form_before:
-            eng_l.set_transient("rec_form", form)
+        pin_lanes(False)
         # also when the consumer stops early or an exception propagates: the sibling lanes' work is ordered before
         # whatever the caller enqueues next, and the copy events are drained
         for _, st in lane_list[1:]:
             cur.wait_stream(st)
         cur.wait_stream(pool.stream)
+        if windowed:                                      # cuts still pending on pool.stream read the window buffers: the copy
+            win["stream"].wait_stream(pool.stream)        # stream (where they were allocated and will be freed) falls in behind them
+            cur.wait_stream(win["stream"])
         for a, b in copies:
             b.synchronize()
             STATS["h2d_s"] += a.elapsed_time(b) / 1e3
@@ -945,29 +963,64 @@ class StreamPool:
     tick(chunks[capacity, N]) -> probs[capacity] (a CUDA tensor that is overwritten by the next
     tick).  Rows of closed slots are computed too (lock-step batch) and ignored.  With
     `graph=True` the step is captured once into a hipGraph and replayed; the input is then copied
-    into a fixed staging buffer first."""
+    into a fixed staging buffer first.
 
-    def __init__(self, engine, sampling_rate: int = 16000, capacity: int = 8192, graph: bool = True):
+    `dtype=torch.int16`: the chunks are 16-bit PCM, scaled by 1/32768 inside the kernel's loads -- what every
+    non-Python client of the reference feeds (examples/onnx_sequence/run.py:115-119, examples/cpp/wav.h:113-118) and
+    half the PCIe bytes of fp32.
+
+    `host_slots=R` (R >= 1) makes the pool a HOST-TO-HOST server, the shape of the reference's streaming caller (host chunk
+    in, probability out: src/silero_vad/utils_vad.py:507-549): a page-locked ingest ring `host_pcm[R, capacity, N]` that the
+    audio sources write into directly (no staging copy on the host) and `host_prob[R, capacity]`; slot r has ONE hipGraph =
+    H2D of host_pcm[r] -> the fused step -> D2H of the probabilities into host_prob[r], replayed on the pool's own stream.
+    `submit(r)` starts a tick and returns, `wait(r)` blocks until its probabilities are readable on the host;
+    `tick_host(r)` = both.  Ticks of one pool execute in submission order (the carried state demands it); with R >= 2 the
+    next tick may be submitted while the host still reads the previous one, and several pools (each on a clone of the
+    engine) overlap one pool's H2D with another's kernel."""
+
+    def __init__(self, engine, sampling_rate: int = 16000, capacity: int = 8192, graph: bool = True,
+                 dtype: torch.dtype = torch.float32, host_slots: int = 0):
+        if dtype not in (torch.float32, torch.int16):
+            raise TypeError(f"StreamPool dtype must be float32 or int16, got {dtype}")
         self.engine = engine
         self.sr = int(sampling_rate)
         self.n = chunk_size(self.sr)
         self.capacity = int(capacity)
+        self.dtype = dtype
         self.device = torch.device("cuda", engine.device)
         with torch.cuda.device(self.device):
             self.ctx = torch.zeros((self.capacity, self.n // 8), device=self.device)
             self.state = torch.zeros((2, self.capacity, 128), device=self.device)
-            self.pcm = torch.zeros((self.capacity, self.n), device=self.device)
+            self.pcm = torch.zeros((self.capacity, self.n), dtype=dtype, device=self.device)
             self.prob = torch.zeros((self.capacity,), device=self.device)
+            self.host_slots = int(host_slots)
+            self.host_pcm = self.host_prob = self.stream = None
+            if self.host_slots:
+                self.host_pcm = torch.zeros((self.host_slots, self.capacity, self.n), dtype=dtype, pin_memory=True)
+                self.host_prob = torch.zeros((self.host_slots, self.capacity), dtype=torch.float32, pin_memory=True)
+                self.stream = torch.cuda.Stream(self.device)
+                self._done = [torch.cuda.Event() for _ in range(self.host_slots)]
         self.open_mask = np.zeros(self.capacity, dtype=bool)
         self._free = list(range(self.capacity - 1, -1, -1))
         self._graph = None
+        self._host_graphs = None
         self._graph_gen = None
+        self._use_graph = bool(graph)
         engine.reserve(self.sr, self.capacity, 1)
         if graph:
             self._capture()
 
     def _launch(self):
-        self.engine.step(self.pcm, self.sr, self.ctx, self.state, self.prob)
+        if self.dtype == torch.float32:
+            self.engine.step(self.pcm, self.sr, self.ctx, self.state, self.prob)
+        else:       # one chunk of int16 PCM per stream: a ONE-step vad_forward_audio_i16 call (the same fused kernel)
+            self.engine.forward_audio(self.pcm, self.sr, self.ctx, self.state, self.prob.view(self.capacity, 1))
+
+    def _host_tick(self, r):
+        """What slot r's graph holds: ingest ring -> HBM, the step, probabilities -> host."""
+        self.pcm.copy_(self.host_pcm[r], non_blocking=True)
+        self._launch()
+        self.host_prob[r].copy_(self.prob, non_blocking=True)
 
     def _capture(self):
         """Capture one step into a hipGraph.  The graph bakes in the engine's scratch addresses, so it is tied to
@@ -986,9 +1039,17 @@ class StreamPool:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._launch()
+            self._graph = g
+            if self.host_slots:
+                self._host_graphs = []
+                for r in range(self.host_slots):
+                    hg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(hg, stream=self.stream):
+                        self._host_tick(r)
+                    self._host_graphs.append(hg)
+            torch.cuda.synchronize(self.device)
             self.ctx.copy_(keep_ctx)                       # the warm-up step advanced them
             self.state.copy_(keep_state)
-            self._graph = g
             self._graph_gen = self.engine.scratch_generation()
 
     # -- slots ---------------------------------------------------------------------------------------
@@ -1001,6 +1062,13 @@ class StreamPool:
         self.state[:, s].zero_()
         self.open_mask[s] = True
         return s
+
+    def open_all(self):
+        """Admit `capacity` streams at once (every slot from zero state)."""
+        self.ctx.zero_()
+        self.state.zero_()
+        self.open_mask[:] = True
+        self._free = []
 
     def close(self, slot: int):
         if not self.open_mask[slot]:
@@ -1016,6 +1084,8 @@ class StreamPool:
     def tick(self, chunks: torch.Tensor) -> torch.Tensor:
         if chunks.shape != (self.capacity, self.n):
             raise ValueError(f"expected chunks of shape {(self.capacity, self.n)}, got {tuple(chunks.shape)}")
+        if (chunks.dtype == torch.int16) != (self.dtype == torch.int16):
+            raise TypeError(f"this pool takes {self.dtype} chunks, got {chunks.dtype}")
         with torch.cuda.device(self.device):
             self.pcm.copy_(chunks, non_blocking=True)
             self.tick_staged()
@@ -1031,6 +1101,30 @@ class StreamPool:
         else:
             self._launch()
         return self.prob
+
+    # -- host to host ------------------------------------------------------------------------------------
+    def submit(self, r: int = 0):
+        """Start one tick over `host_pcm[r]` on the pool's stream; returns at once (see the class docstring)."""
+        if not self.host_slots:
+            raise RuntimeError("StreamPool was created without host_slots")
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            if self._use_graph:
+                if self.engine.scratch_generation() != self._graph_gen:
+                    self._capture()
+                self._host_graphs[r].replay()
+            else:
+                self._host_tick(r)
+            self._done[r].record(self.stream)
+
+    def wait(self, r: int = 0) -> torch.Tensor:
+        """Block until the tick submitted for slot r has delivered; returns `host_prob[r]` (page-locked, overwritten by the
+        slot's next tick)."""
+        self._done[r].synchronize()
+        return self.host_prob[r]
+
+    def tick_host(self, r: int = 0) -> torch.Tensor:
+        self.submit(r)
+        return self.wait(r)
 
 
 class BatchVADIterator:
@@ -1053,6 +1147,7 @@ class BatchVADIterator:
         self.triggered = np.zeros(batch, dtype=bool)
         self.temp_end = np.zeros(batch, dtype=np.int64)
         self.current_sample = np.zeros(batch, dtype=np.int64)
+        self._events = None
 
     def reset(self, slot=None):
         sl = slice(None) if slot is None else slot
@@ -1061,24 +1156,25 @@ class BatchVADIterator:
         self.current_sample[sl] = 0
 
     def feed(self, probs, active=None):
-        p = np.asarray(probs.detach().cpu() if torch.is_tensor(probs) else probs, dtype=np.float32).astype(np.float64)
-        act = np.ones(p.shape[0], dtype=bool) if active is None else np.asarray(active, dtype=bool)
-        win = self.window
-        self.current_sample[act] += win
-        loud = (p >= self.threshold) & act
-        self.temp_end[loud & (self.temp_end != 0)] = 0
-        starts = loud & ~self.triggered
-        self.triggered[starts] = True
-        events = []
-        for s in np.flatnonzero(starts):
-            events.append((int(s), {"start": int(max(0, self.current_sample[s] - self.speech_pad_samples - win))}))
-        quiet = act & ~starts & self.triggered & (p < self.threshold - 0.15)
-        first = quiet & (self.temp_end == 0)
-        self.temp_end[first] = self.current_sample[first]
-        ends = quiet & ((self.current_sample - self.temp_end) >= self.min_silence_samples)
-        for s in np.flatnonzero(ends):
-            events.append((int(s), {"end": int(self.temp_end[s] + self.speech_pad_samples - win)}))
-        self.temp_end[ends] = 0
-        self.triggered[ends] = False
-        events.sort(key=lambda e: e[0])
-        return events
+        """One tick: probs[B] (host or device tensor / array) -> [(slot, {'start': n} | {'end': n}), ...] in slot order.  The
+        per-stream logic runs in the native library (vad_iterator_feed, csrc/segmenter.cpp): one pass over the batch, no
+        per-stream Python."""
+        if torch.is_tensor(probs):
+            probs = probs.detach().cpu().numpy()
+        p = np.ascontiguousarray(probs, dtype=np.float32).reshape(-1)
+        B = self.triggered.shape[0]
+        if p.shape[0] != B:
+            raise ValueError(f"expected {B} probabilities, got {p.shape[0]}")
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.bool_)
+        if act is not None and act.shape[0] != B:
+            raise ValueError(f"expected {B} active flags, got {act.shape[0]}")
+        if self._events is None or len(self._events) < B:
+            self._events = (_lib.IterEvent * B)()
+        m = lib().vad_iterator_feed(p.ctypes.data, None if act is None else act.ctypes.data, B, self.window,
+                                    float(self.threshold), float(self.min_silence_samples), float(self.speech_pad_samples),
+                                    self.triggered.ctypes.data, self.temp_end.ctypes.data, self.current_sample.ctypes.data,
+                                    self._events, B)
+        if m < 0:
+            raise ValueError("vad_iterator_feed: bad arguments")
+        ev = self._events
+        return [(ev[i].slot, {"end" if ev[i].kind else "start": ev[i].sample}) for i in range(m)]

@@ -27,12 +27,28 @@ def _speech_probs(audio, model, sampling_rate, window, progress_cb, step=1):
     the RAW signal and rate and reads every step-th sample on the GPU (the reference's `audio[::step]`,
     utils_vad.py:301-307, without the decimated copy); any other model object gets the decimated view."""
     n = (len(audio) + step - 1) // step                  # len(audio[::step])
+
+    def report(first, count):                            # the reference's per-chunk progress values (utils_vad.py:332-336)
+        for start in range(first * window, min((first + count) * window, n), window):
+            progress_cb(min(start + window, n) / n * 100)
+
     fast = getattr(model, "audio_forward_device", None)
+    slabs = getattr(model, "audio_forward_slabs", None)
     if fast is not None and n > 0:
         x = audio.unsqueeze(0)
         if n < window:      # the reference pads every chunk to a full window (utils_vad.py:326-327), so a
             x = torch.nn.functional.pad(x, (0, window * step - len(audio)))   # recording shorter than one window is legal here
-        probs = fast(x, sampling_rate * step)[0].cpu()
+        if progress_cb and slabs is not None:
+            # progress while the recording is being processed: one report per chunk, slab by slab (a slab = 256 chunks = 8 s)
+            parts = []
+            for first, p in slabs(x, sampling_rate * step):
+                parts.append(p[0].cpu())
+                report(first, parts[-1].numel())
+            probs = torch.cat(parts)
+        else:
+            probs = fast(x, sampling_rate * step)[0].cpu()
+            if progress_cb:
+                report(0, probs.numel())
     else:
         if step > 1:
             audio = audio[::step]
@@ -43,10 +59,9 @@ def _speech_probs(audio, model, sampling_rate, window, progress_cb, step=1):
             if len(chunk) < window:
                 chunk = torch.nn.functional.pad(chunk, (0, int(window - len(chunk))))
             vals.append(model(chunk, sampling_rate).item())
+            if progress_cb:
+                progress_cb(min(start + window, n) / n * 100)
         probs = torch.tensor(vals, dtype=torch.float32)
-    if progress_cb and n > 0:
-        for start in range(0, n, window):
-            progress_cb(min(start + window, n) / n * 100)
     return probs
 
 

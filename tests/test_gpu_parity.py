@@ -464,6 +464,57 @@ def test_streaming_step_in_hip_graph(model, oracle, golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_stream_pool_host_int16_chunks_in_events_out(model, golden, tag):
+    """BASELINE configs[4] end to end, the shape of the reference's streaming caller (src/silero_vad/utils_vad.py:507-549: host
+    chunk in, event out): int16 chunks written into the pool's page-locked ingest ring -> ONE hipGraph per ring slot (H2D, fused
+    step, D2H of the probabilities) -> BatchVADIterator (native vad_iterator_feed) -> events.  Stream 0 plays the fixture from
+    its start: its event list must EQUAL the one the reference's VADIterator produced with the reference's model (all 1875 /
+    5286 ticks); other streams play rolled copies and must equal our per-stream VADIterator over model(chunk, sr)."""
+    from silero_vad_amd import BatchVADIterator, StreamPool, VADIterator
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    pcm = g["pcm_i16"]
+    T = len(pcm) // n
+    cap = 100                                             # not a multiple of 16
+    rows = np.stack([np.roll(pcm, -s * 7919)[:T * n] for s in range(cap)])
+    pool = StreamPool(model.engine.clone(), sr, capacity=cap, graph=True, dtype=torch.int16, host_slots=2)
+    assert pool._host_graphs is not None and len(pool._host_graphs) == 2 and pool.host_pcm.is_pinned() and pool.host_prob.is_pinned()
+    pool.open_all()
+    rec = golden["segments"][tag]["iterator"]["default"]
+    it = BatchVADIterator(cap, sampling_rate=sr, **rec["init"])
+    events = {s: [] for s in range(cap)}
+    probs0 = np.zeros(T, np.float32)
+    ring = pool.host_pcm.numpy()
+    for t in range(T + 1):                                # tick t is submitted while tick t - 1 is read (two ring slots)
+        if t < T:
+            ring[t % 2][:] = rows[:, t * n:(t + 1) * n]
+            pool.submit(t % 2)
+        if t > 0:
+            p = pool.wait((t - 1) % 2)
+            probs0[t - 1] = float(p[0])
+            for s, e in it.feed(p):
+                events[s].append(e)
+    assert events[0] == rec["events"], tag                # the reference's own events (39 / 92)
+    assert np.abs(probs0 - np.asarray(g["probs_wav"]).reshape(-1)[:T]).max() < TIGHT   # the reference model's own probabilities
+    for s in (1, 37, 99):
+        model.reset_states()
+        one = VADIterator(model, sampling_rate=sr, **rec["init"])
+        ref = [e for t in range(T) if (e := one(torch.from_numpy(rows[s, t * n:(t + 1) * n].copy())))]
+        assert events[s] == ref and len(ref) > 4, s
+    # an eager pool (no graph) takes the same route and gives the same bits
+    eager = StreamPool(model.engine.clone(), sr, capacity=cap, graph=False, dtype=torch.int16, host_slots=1)
+    eager.open_all()
+    again = StreamPool(model.engine.clone(), sr, capacity=cap, graph=True, dtype=torch.int16, host_slots=1)
+    again.open_all()
+    for t in range(6):
+        for q in (eager, again):
+            q.host_pcm.numpy()[0][:] = rows[:, t * n:(t + 1) * n]
+        assert torch.equal(eager.tick_host(0), again.tick_host(0))
+    with pytest.raises(TypeError):
+        again.tick(torch.zeros((cap, n)))                 # a float chunk handed to an int16 pool
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
 def test_ragged_corpus_equals_single_recording_runs(model, oracle, golden, tag):
     """configs[3] plumbing: recordings of different lengths bucketed into lock-step batches give
     bit-identical probabilities and identical segments to one-recording-at-a-time calls."""

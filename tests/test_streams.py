@@ -244,6 +244,47 @@ def test_stage_rows_on_the_persistent_pool(built):
             assert np.array_equal(dst[i, :lens[i]], base[offs[i]:offs[i] + lens[i]]) and not dst[i, lens[i]:].any()
 
 
+def test_host_pool_survives_fork(built):
+    """The process-wide helper pool after fork(): the child inherits handles of worker threads that do not exist in it.  It must (a)
+    stage correctly with a pool of its own and (b) leave through exit() -- static destructors run -- without hanging on a join."""
+    import ctypes
+    import os
+    import time
+    from silero_vad_amd import _lib
+    rng = np.random.default_rng(9)
+    base = rng.integers(-3000, 3000, 1 << 21).astype(np.int16)
+    width, n = 200_000, 24
+    lens = rng.integers(0, width + 1, n)
+    offs = rng.integers(0, len(base) - width, n)
+    rows = (ctypes.c_void_p * n)(*[base.ctypes.data + 2 * int(o) for o in offs])
+    clens = (ctypes.c_long * n)(*[int(v) for v in lens])
+
+    def stage_ok():
+        dst = np.full((n, width), 9, np.int16)
+        rc = _lib.lib().vad_stage_rows(rows, clens, n, width, 2, dst.ctypes.data, 6)
+        return rc == 0 and all(np.array_equal(dst[i, :lens[i]], base[offs[i]:offs[i] + lens[i]]) and not dst[i, lens[i]:].any()
+                               for i in range(n))
+
+    assert stage_ok()                                       # the parent's pool exists now (5 workers)
+    pid = os.fork()
+    if pid == 0:
+        code = 0 if (stage_ok() and stage_ok()) else 3
+        ctypes.CDLL(None).exit(code)                        # libc exit(): atexit handlers and static destructors run
+    deadline = time.time() + 30
+    status = None
+    while time.time() < deadline:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        time.sleep(0.05)
+    else:
+        os.kill(pid, 9)
+        os.waitpid(pid, 0)
+        pytest.fail("the forked child hung (joining worker threads that do not exist in it?)")
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    assert stage_ok()                                       # and the parent's pool still works
+
+
 def test_packed_recordings_windows_and_plan():
     """PackedRecordings: arena-order runs become windows of bounded span; a recording that starts before its
     predecessor ends (a ring that wrapped, overlapping views) starts a new window; WindowedPlan buckets every recording
@@ -315,3 +356,58 @@ def test_packed_recordings_through_the_cpu_stand_in(oracle):
     first = np.concatenate([[0], np.cumsum(counts)])
     assert [[{"start": int(p), "end": int(q)} for p, q in flat[first[i]:first[i + 1]]] for i in range(len(lens))] == segs
     assert sum(len(s) for s in segs) > 0 and counts[4] == 0
+
+
+# ---- callers' protocol details (CPU stand-in engine: the oracle behind the engine's Python surface) ----------------------------
+def _stand_in(oracle):
+    from replay_engine import ReplayEngine
+    from silero_vad_amd.engine import HipSileroVAD
+    return HipSileroVAD(engine=ReplayEngine(oracle))
+
+
+def test_progress_callback_fires_slab_by_slab_with_the_reference_values(oracle):
+    """src/silero_vad/utils_vad.py:330-336: one report per chunk, min(start + window, n) / n * 100.  With the one-call fast path
+    the reports come slab by slab WHILE the recording is processed (audio_forward_slabs: 256 chunks per slab, carried state),
+    not after the fact -- and the probabilities are those of one audio_forward call."""
+    from silero_vad_amd import get_speech_timestamps
+    model = _stand_in(oracle)
+    wav = torch.from_numpy(_wav()[:16000 * 21 + 77])                  # 657 chunks: three slabs, the last chunk partial
+    n = len(wav)
+    seen, calls_at_report = [], []
+
+    def cb(pct):
+        seen.append(pct)
+        calls_at_report.append(model.engine.calls["forward_audio"])
+
+    with_cb = get_speech_timestamps(wav, model, progress_tracking_callback=cb)
+    assert seen == [min(s + 512, n) / n * 100 for s in range(0, n, 512)] and seen[-1] == 100.0
+    assert calls_at_report[0] == 1 and calls_at_report[255] == 1 and calls_at_report[256] == 2 and calls_at_report[-1] == 3
+    model.engine.calls["forward_audio"] = 0
+    assert get_speech_timestamps(wav, model) == with_cb and model.engine.calls["forward_audio"] == 1
+    # 32 kHz input: slabs are cut at multiples of the RAW chunk (1024 samples)
+    seen.clear()
+    wav32 = torch.from_numpy(np.repeat(_wav()[:16000 * 9], 2))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = get_speech_timestamps(wav32, model, sampling_rate=32000, progress_tracking_callback=cb)
+        b = get_speech_timestamps(wav32, model, sampling_rate=32000)
+    assert a == b and len(seen) == (16000 * 9 + 511) // 512
+
+
+def test_model_call_returns_a_tensor_where_the_input_lives(oracle):
+    """src/silero_vad/utils_vad.py:91-92: the reference's model objects hand back a CPU tensor for a CPU chunk -- `.item()`
+    (utils_vad.py:328, :528) and `.numpy()` callers both work."""
+    model = _stand_in(oracle)
+    out = model(torch.from_numpy(_wav()[:512]), 16000)
+    assert out.device.type == "cpu" and out.shape == (1, 1) and out.dtype == torch.float32
+    assert 0.0 <= float(out.numpy()[0, 0]) <= 1.0 and isinstance(out.item(), float)
+    # rows that overlap in memory (expand: stride 0; unfold: row stride < row length) are materialised, not rejected
+    row = torch.from_numpy(_wav()[:512])
+    model.reset_states()
+    p_expand = model(row.expand(3, -1), 16000)
+    model.reset_states()
+    assert torch.equal(p_expand, model(row.repeat(3, 1), 16000))
+    sig = torch.from_numpy(_wav()[:512 + 2 * 256])
+    x = model._to_device(sig.unfold(0, 512, 256))
+    assert x.shape == (3, 512) and x.stride(0) >= 512
