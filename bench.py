@@ -582,8 +582,9 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
     does H2D -> the fused step -> D2H of the probabilities, the host runs the iterator logic of every stream (native
     vad_iterator_feed) and holds the events.  Two measurements:
       latency    ONE pool of all `cap` streams, one tick at a time: submit -> probabilities on the host -> events (median / p95)
-      sustained  the same streams as `parts` sub-pools on their own streams (clones of the engine), two ring slots in flight: one
-                 sub-pool's H2D runs beside another's kernel and the host's event pass; chunks/s against the PCIe ceiling"""
+      sustained  the same streams as `parts` sub-pools on their own streams (clones of the engine), submitted natively
+                 (vad_step_host), two ticks in flight: one sub-pool's H2D runs beside another's kernel and the host's event pass;
+                 chunks/s against the PCIe ceiling"""
     import numpy as np
     import torch
     from silero_vad_amd import BatchVADIterator, Engine, StreamPool
@@ -591,12 +592,12 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
     n = WORK[sr]["chunk"]
     cap = args.live
     R = 8                                                       # ingest ring: 8 ticks of audio per stream
-    parts = max(1, int(os.environ.get("VAD_BENCH_STREAM_PARTS", "4")))
+    parts = max(1, int(os.environ.get("VAD_BENCH_STREAM_PARTS", "2")))
     rows = fixture_rows_i16(sr, cap, R * n)                     # real speech: the iterators do produce events
     eng = Engine(device=local)
 
-    def make(lo, hi):
-        pool = StreamPool(eng.clone(), sr, capacity=hi - lo, graph=True, dtype=torch.int16, host_slots=R)
+    def make(lo, hi, graph=True):
+        pool = StreamPool(eng.clone(), sr, capacity=hi - lo, graph=graph, dtype=torch.int16, host_slots=R)
         pool.open_all()
         ring = pool.host_pcm.numpy()
         for r in range(R):
@@ -629,7 +630,9 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
     del whole
     # -- sustained: sub-pools, two ring slots in flight ------------------------------------------------------------------------
     cuts = [cap * i // parts for i in range(parts + 1)]
-    pools = [make(cuts[i], cuts[i + 1]) for i in range(parts)]
+    # (submitted natively, vad_step_host on each sub-pool's stream: on ROCm 7.2 a hipGraphLaunch of the 4-node tick graph costs ~0.1 ms
+    #  of host time against ~0.03 ms for the same operations issued directly -- tools/stream_host_diag.py; the graph is the latency leg's)
+    pools = [make(cuts[i], cuts[i + 1], graph=False) for i in range(parts)]
     its = [BatchVADIterator(cuts[i + 1] - cuts[i], sampling_rate=sr) for i in range(parts)]
     ev_count = [0]
     state = {"k": 0}
@@ -647,6 +650,17 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
         state["k"] = k0 + nt
 
     run(600)                                                    # warm-up + clock ramp
+    lat_parts = []
+    for _ in range(200):                                        # the sub-pools one tick at a time: part 2's H2D beside part 1's kernel
+        t0 = time.perf_counter()
+        kk = state["k"]
+        for q in pools:
+            q.submit(kk % R)
+        for q, qi in zip(pools, its):
+            qi.feed(q.wait(kk % R).numpy())
+        state["k"] = kk + 1
+        lat_parts.append((time.perf_counter() - t0) * 1e3)
+    lat_parts.sort()
     ev_count[0] = 0
     elapsed = timed(world, dist, dev, 1, lambda: run(ticks), gpu_sync)
     link = h2d_rate_GBps(dev)
@@ -665,7 +679,10 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
     out["events_emitted"] = {"latency_pass": n_events, "sustained_pass": ev_count[0]}
     out["tick_latency_ms"] = {"median": round(lat[len(lat) // 2], 4), "p95": round(lat[int(len(lat) * 0.95)], 4),
                               "to_probabilities_on_host_median": round(lat_gpu[len(lat_gpu) // 2], 4), "budget_ms": 32.0,
-                              "what": "ONE pool of all streams, one tick at a time: submit(graph: H2D -> step -> D2H) -> wait -> events"}
+                              "what": "ONE pool of all streams, one tick at a time: submit(ONE hipGraph: H2D -> step -> D2H) -> wait -> events",
+                              "as_sub_pools_median": round(lat_parts[len(lat_parts) // 2], 4),
+                              "as_sub_pools_what": f"the same tick as {parts} sub-pools submitted natively on their own streams (one sub-pool's "
+                                                   "H2D beside another's kernel), one tick at a time, to events"}
     ceiling = link * 1e9 / (n * 2) * world
     out["pcie"] = {"h2d_GBps_plain_copy": round(link, 2), "int16_ceiling_chunks_per_s": round(ceiling, 1),
                    "fraction_of_pcie_ceiling": round(value / ceiling, 3),

@@ -117,6 +117,17 @@ int  vad_set_option(vad_engine *e, const char *name, const char *value);
 int  vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ctx, float *state,
               float *prob, void *stream);
 
+/* The same step from HOST audio to HOST probabilities, the shape of the reference's streaming callers (host chunk in, probability out:
+ * src/silero_vad/utils_vad.py:507-549 VADIterator; examples/cpp/silero-vad-onnx.cpp:103-142 feeds int16-derived chunks the same way):
+ * one copy of the B chunks host -> dev_pcm, the step, one copy of the B probabilities dev_prob -> host_prob, all asynchronous on
+ * `stream` (record an event behind the call and wait for it before reading host_prob).  May be issued inside a stream capture: the
+ * three operations then become one hipGraph (what StreamPool replays per tick).
+ *   host_pcm   host [B][N], PAGE-LOCKED; elem_size 2 = int16 (scaled by 1/32768 in the kernel's loads), 4 = fp32
+ *   dev_pcm    dev  [B][N] of the same element type: staging the caller owns (16-byte aligned)
+ *   dev_prob   dev  [B];   host_prob  host [B], page-locked                                                                     */
+int  vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, void *dev_pcm, float *ctx, float *state,
+                   float *dev_prob, float *host_prob, void *stream);
+
 /* T = ceil(L / N) lock-step steps for B streams: VADRNNJITMerge.audio_forward
  * (JIT!/vad/model/vad_annotator.py:128-156; ONNX twin utils_vad.py:94-110) with the carried
  * state made explicit (pass zeroed ctx/state for the reference's reset-then-run behaviour).

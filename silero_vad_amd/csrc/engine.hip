@@ -580,6 +580,27 @@ int vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ctx
     return forward_impl<float>(e, sr, B, N, pcm, ld, ctx, state, prob, 1, stream);
 }
 
+int vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, void *dev_pcm, float *ctx, float *state,
+                  float *dev_prob, float *host_prob, void *stream_v) {
+    if (!e) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    const int ni = net_index(sr);
+    if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000]");
+    if (B < 0 || (elem_size != 2 && elem_size != 4) || (B > 0 && (!host_pcm || !dev_pcm || !ctx || !state || !dev_prob || !host_prob)))
+        return fail(e, VAD_ERR_ARG, "bad argument");
+    if (B == 0) return VAD_OK;
+    hipStream_t stream = (hipStream_t)stream_v;
+    const long N = sr == 16000 ? 512 : 256;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpyAsync(dev_pcm, host_pcm, (size_t)B * N * elem_size, hipMemcpyHostToDevice, stream));
+    const int rc = elem_size == 2
+        ? forward_impl<int16_t>(e, sr, B, N, static_cast<const int16_t *>(dev_pcm), N, ctx, state, dev_prob, 1, stream_v)
+        : forward_impl<float>(e, sr, B, N, static_cast<const float *>(dev_pcm), N, ctx, state, dev_prob, 1, stream_v);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(host_prob, dev_prob, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, stream));
+    return VAD_OK;
+}
+
 int vad_forward_audio(vad_engine *e, int sr, int B, long L, const float *pcm, long ld, float *ctx,
                       float *state, float *probs, long ldp, void *stream) {
     return forward_impl<float>(e, sr, B, L, pcm, ld, ctx, state, probs, ldp, stream);

@@ -140,6 +140,14 @@ class Engine:
                                      ctx.data_ptr(), state.data_ptr(), prob.data_ptr(), self._stream()))
         return prob
 
+    def step_host(self, host_pcm, dev_pcm, sr, ctx, state, dev_prob, host_prob, stream=None):
+        """One tick from page-locked host chunks to page-locked host probabilities on `stream` (a raw stream handle; default:
+        torch's current stream): H2D, the step, D2H -- vad_step_host, asynchronous."""
+        B = host_pcm.shape[0]
+        self._check(self._L.vad_step_host(self._h, sr, B, host_pcm.data_ptr(), host_pcm.element_size(), dev_pcm.data_ptr(),
+                                          ctx.data_ptr(), state.data_ptr(), dev_prob.data_ptr(), host_prob.data_ptr(),
+                                          self._stream() if stream is None else ctypes.c_void_p(stream)))
+
     def upload_rows(self, rows, lens, n, width, elem_size, dst, how=0):
         """Ragged rows in PINNED host memory -> dst[n, width] on the GPU, zero padded, on the current stream
         (vad_upload_rows; how 0: copy engines, 1: gather kernel).  rows / lens: ctypes arrays."""

@@ -1016,11 +1016,9 @@ class StreamPool:
         else:       # one chunk of int16 PCM per stream: a ONE-step vad_forward_audio_i16 call (the same fused kernel)
             self.engine.forward_audio(self.pcm, self.sr, self.ctx, self.state, self.prob.view(self.capacity, 1))
 
-    def _host_tick(self, r):
-        """What slot r's graph holds: ingest ring -> HBM, the step, probabilities -> host."""
-        self.pcm.copy_(self.host_pcm[r], non_blocking=True)
-        self._launch()
-        self.host_prob[r].copy_(self.prob, non_blocking=True)
+    def _host_tick(self, r, stream=None):
+        """What slot r's graph holds: ingest ring -> HBM, the step, probabilities -> host (one native call: vad_step_host)."""
+        self.engine.step_host(self.host_pcm[r], self.pcm, self.sr, self.ctx, self.state, self.prob, self.host_prob[r], stream)
 
     def _capture(self):
         """Capture one step into a hipGraph.  The graph bakes in the engine's scratch addresses, so it is tied to
@@ -1107,14 +1105,14 @@ class StreamPool:
         """Start one tick over `host_pcm[r]` on the pool's stream; returns at once (see the class docstring)."""
         if not self.host_slots:
             raise RuntimeError("StreamPool was created without host_slots")
-        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
-            if self._use_graph:
-                if self.engine.scratch_generation() != self._graph_gen:
-                    self._capture()
+        if self._use_graph:
+            if self.engine.scratch_generation() != self._graph_gen:
+                self._capture()
+            with torch.cuda.stream(self.stream):             # (replay launches on torch's current stream)
                 self._host_graphs[r].replay()
-            else:
-                self._host_tick(r)
-            self._done[r].record(self.stream)
+        else:       # one native call on the pool's stream: no stream switch on the host side
+            self._host_tick(r, self.stream.cuda_stream)
+        self._done[r].record(self.stream)
 
     def wait(self, r: int = 0) -> torch.Tensor:
         """Block until the tick submitted for slot r has delivered; returns `host_prob[r]` (page-locked, overwritten by the
