@@ -98,6 +98,12 @@ struct vad_engine {
     bool tab_busy[kTabSlots] = {};
     int tab_next = 0;
 
+    // vad_upload_rows how = 0: the per-row DMAs are dealt round-robin to these side streams (several copy engines at once; one engine
+    // spends ~30 us per copy whatever its size), forked from and joined to the caller's stream by events
+    static constexpr int kDmaStreams = 4;
+    hipStream_t dma_stream[kDmaStreams] = {};
+    hipEvent_t dma_fork = nullptr, dma_join[kDmaStreams] = {};
+
     // profiling: 3 events per (call, slab), read back lazily by vad_kernel_times
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -453,6 +459,15 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
 }
 
 void vad_destroy(vad_engine *e) {
+    if (e && e->dma_fork) {
+        (void)hipSetDevice(e->device);
+        for (int k = 0; k < vad_engine::kDmaStreams; ++k) {
+            if (e->dma_stream[k]) { (void)hipStreamSynchronize(e->dma_stream[k]); (void)hipStreamDestroy(e->dma_stream[k]); }
+            if (e->dma_join[k]) (void)hipEventDestroy(e->dma_join[k]);
+        }
+        (void)hipEventDestroy(e->dma_fork);
+        e->dma_fork = nullptr;
+    }
     if (!e) return;
     if (!e->host_only && e->device >= 0) {
         (void)hipSetDevice(e->device);
@@ -826,10 +841,31 @@ int vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, lo
     if (how == 0) {
         // copy engines: one H2D DMA per row (any alignment; no CU time), the padding by one fill of the batch first
         HIP_TRY(e, hipMemsetAsync(dst, 0, (size_t)n * width * elem_size, stream));
+        int ways = vad_engine::kDmaStreams;
+        if (const char *v = std::getenv("SILERO_VAD_AMD_DMA_STREAMS")) ways = std::max(1, std::min(ways, std::atoi(v)));
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (n < 2 * ways || (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)) ways = 1;
+        if (ways > 1) {
+            if (!e->dma_fork) {
+                HIP_TRY(e, hipEventCreateWithFlags(&e->dma_fork, hipEventDisableTiming));
+                for (int k = 0; k < vad_engine::kDmaStreams; ++k) {
+                    HIP_TRY(e, hipStreamCreateWithFlags(&e->dma_stream[k], hipStreamNonBlocking));
+                    HIP_TRY(e, hipEventCreateWithFlags(&e->dma_join[k], hipEventDisableTiming));
+                }
+            }
+            HIP_TRY(e, hipEventRecord(e->dma_fork, stream));         // behind the fill (and whatever the caller queued before)
+            for (int k = 0; k < ways; ++k) HIP_TRY(e, hipStreamWaitEvent(e->dma_stream[k], e->dma_fork, 0));
+        }
         for (long i = 0; i < n; ++i)
             if (lens[i])
                 HIP_TRY(e, hipMemcpyAsync(static_cast<uint8_t *>(dst) + (size_t)i * width * elem_size, rows[i],
-                                          (size_t)lens[i] * elem_size, hipMemcpyHostToDevice, stream));
+                                          (size_t)lens[i] * elem_size, hipMemcpyHostToDevice,
+                                          ways > 1 ? e->dma_stream[i % ways] : stream));
+        if (ways > 1)
+            for (int k = 0; k < ways; ++k) {
+                HIP_TRY(e, hipEventRecord(e->dma_join[k], e->dma_stream[k]));
+                HIP_TRY(e, hipStreamWaitEvent(stream, e->dma_join[k], 0));
+            }
         return VAD_OK;
     }
     // gather kernel: the row table goes into a pinned slot the kernel reads itself; a slot is reused once its kernel is done
@@ -843,7 +879,10 @@ int vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, lo
         if (e->h_tab[slot]) (void)hipHostFree(e->h_tab[slot]);
         e->h_tab[slot] = nullptr;
         e->tab_cap[slot] = 0;
-        const long cap = std::max<long>(n, 1024);
+        // (hipHostFree waits for the device: a table that grows by a few rows per bucket would drain the whole pipeline every
+        //  time -- capacities are powers of two from 4096 up, so a slot is reallocated a handful of times in a process' life)
+        long cap = 4096;
+        while (cap < n) cap *= 2;
         if (hipHostMalloc((void **)&e->h_tab[slot], (size_t)cap * sizeof(vad::RowDesc), hipHostMallocDefault) != hipSuccess)
             return fail(e, VAD_ERR_ALLOC, "cannot allocate the pinned row table");
         e->tab_cap[slot] = cap;
