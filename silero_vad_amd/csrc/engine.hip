@@ -85,6 +85,13 @@ struct vad_engine {
     size_t tail_bytes = 0;
     void *d_realign = nullptr;                      // aligned copy of a misaligned input (rare)
     size_t realign_bytes = 0;
+    float *d_mags = nullptr;                        // front_mma=bf16x9: the STFT magnitudes between the FFT kernel and the GEMM kernel
+    size_t mags_bytes = 0;
+    hipStream_t fft_stream = nullptr;               // ... the FFT kernel's stream, forked from / joined to the caller's by events
+    hipEvent_t fft_fork = nullptr;
+    std::vector<hipEvent_t> fft_done;
+    int cus = 0;                                    // compute units of the device (the persistent GEMM kernel's grid)
+    int b9_slabs = 8;                               // tile slabs per launch: the FFT kernel of slab s + 1 runs beside the GEMM kernel of slab s
     void *d_decim = nullptr;                        // 16 kHz copy of a 64/80/... kHz input
     size_t decim_bytes = 0;
     unsigned long scratch_gen = 0;                  // bumped whenever a scratch buffer is reallocated: a hipGraph that
@@ -144,7 +151,9 @@ int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
     // worst case of the tail copy: fp32 samples at 48 kHz (dec = 3) -- sized here so that no forward call has to grow it
     // (a growth is a device synchronisation and cannot happen while the call is being captured into a hipGraph)
     const size_t need_tail = (size_t)B * (sr == 16000 ? 512 * 3 : 256) * sizeof(float);
-    if (need_gx > e->gx_floats || need_ctx > e->ctx_floats || need_tail > e->tail_bytes) {
+    // front_mma=bf16x9: the magnitudes of one gx slab's tiles between the FFT kernel and the GEMM kernel
+    const size_t need_mags = e->front_b9 == 2 ? (size_t)nst * slab * vad::mag_tile_floats(sr) * sizeof(float) : 0;
+    if (need_gx > e->gx_floats || need_ctx > e->ctx_floats || need_tail > e->tail_bytes || need_mags > e->mags_bytes) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
             return fail(e, VAD_ERR_CAPTURE, "scratch must grow during stream capture; call vad_reserve first");
@@ -165,6 +174,14 @@ int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
             if (hipMalloc((void **)&e->d_ctx_new, need_ctx * sizeof(float)) != hipSuccess)
                 return fail(e, VAD_ERR_ALLOC, "cannot allocate context scratch");
             e->ctx_floats = need_ctx;
+        }
+        if (need_mags > e->mags_bytes) {
+            if (e->d_mags) (void)hipFree(e->d_mags);
+            e->d_mags = nullptr;
+            e->mags_bytes = 0;
+            if (hipMalloc((void **)&e->d_mags, need_mags) != hipSuccess)
+                return fail(e, VAD_ERR_ALLOC, "cannot allocate magnitude scratch");
+            e->mags_bytes = need_mags;
         }
         if (need_tail > e->tail_bytes) {
             if (e->d_tail) (void)hipFree(e->d_tail);
@@ -290,8 +307,37 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             continue;
         }
         if (e->front_b9 == 2) {
+            // two kernels side by side: the FFT kernel runs slab by slab on the engine's side stream, ahead of the GEMM kernel
             fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9w[ni]);
-            HIP_TRY(e, vad::launch_front_b9w<PcmT>(sr, fa, stream));
+            const long per = vad::mag_tile_floats(sr);
+            rc = grow(e, reinterpret_cast<void **>(&e->d_mags), &e->mags_bytes, (size_t)tiles * per * sizeof(float), stream, "magnitude");
+            if (rc) return rc;
+            if (!e->fft_stream) {
+                HIP_TRY(e, hipStreamCreateWithFlags(&e->fft_stream, hipStreamNonBlocking));
+                HIP_TRY(e, hipEventCreateWithFlags(&e->fft_fork, hipEventDisableTiming));
+                hipDeviceProp_t prop;
+                HIP_TRY(e, hipGetDeviceProperties(&prop, e->device));
+                e->cus = prop.multiProcessorCount;
+            }
+            const int S = (int)std::max<long>(1, std::min<long>(e->b9_slabs, tiles / (4L * e->cus)));
+            while ((int)e->fft_done.size() < S) {
+                hipEvent_t x;
+                HIP_TRY(e, hipEventCreateWithFlags(&x, hipEventDisableTiming));
+                e->fft_done.push_back(x);
+            }
+            HIP_TRY(e, hipEventRecord(e->fft_fork, stream));          // the FFT kernels start behind whatever the caller queued (the PCM)
+            HIP_TRY(e, hipStreamWaitEvent(e->fft_stream, e->fft_fork, 0));
+            const long chunk = (tiles + S - 1) / S / 4 * 4 + 4;
+            for (int sidx = 0; sidx < S; ++sidx) {
+                const long lo = std::min<long>(tiles, sidx * chunk), hi = std::min<long>(tiles, lo + chunk);
+                HIP_TRY(e, vad::launch_fft_mags<PcmT>(sr, fa, e->d_mags, lo, hi - lo, e->fft_stream));
+                HIP_TRY(e, hipEventRecord(e->fft_done[sidx], e->fft_stream));
+            }
+            for (int sidx = 0; sidx < S; ++sidx) {
+                const long lo = std::min<long>(tiles, sidx * chunk), hi = std::min<long>(tiles, lo + chunk);
+                HIP_TRY(e, hipStreamWaitEvent(stream, e->fft_done[sidx], 0));
+                HIP_TRY(e, vad::launch_front_b9g(sr, fa, e->d_mags, lo, hi - lo, e->cus, stream));
+            }
         } else if (e->front_b9) {
             fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
             HIP_TRY(e, vad::launch_front_b9<PcmT>(sr, fa, stream));
@@ -483,6 +529,10 @@ void vad_destroy(vad_engine *e) {
         if (e->d_tail) (void)hipFree(e->d_tail);
         if (e->d_realign) (void)hipFree(e->d_realign);
         if (e->d_decim) (void)hipFree(e->d_decim);
+        if (e->d_mags) (void)hipFree(e->d_mags);
+        if (e->fft_stream) (void)hipStreamDestroy(e->fft_stream);
+        if (e->fft_fork) (void)hipEventDestroy(e->fft_fork);
+        for (auto &ev : e->fft_done) (void)hipEventDestroy(ev);
         for (int i = 0; i < vad_engine::kTabSlots; ++i) {
             if (e->h_tab[i]) (void)hipHostFree(e->h_tab[i]);
             if (e->tab_ev[i]) (void)hipEventDestroy(e->tab_ev[i]);
@@ -554,6 +604,12 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         else if (v == "bf16x9" || v == "bf16x9_wide") e->front_b9 = 2;       //  arithmetic of a result must not depend on the batch it came in)
         else if (v == "bf16x9_narrow") e->front_b9 = 1;                       // the round-3 kernel: the same bits, A/B for tests
         else return fail(e, VAD_ERR_OPTION, "front_mma must be fp32|bf16x9|bf16x9_wide|bf16x9_narrow");
+        return VAD_OK;
+    }
+    if (n == "b9_slabs") {                           // front_mma=bf16x9: tile slabs per launch (1: the FFT kernel runs entirely before the GEMM kernel)
+        const long v2 = std::strtol(value, nullptr, 0);
+        if (v2 < 1 || v2 > 64) return fail(e, VAD_ERR_OPTION, "b9_slabs must be 1..64");
+        e->b9_slabs = (int)v2;
         return VAD_OK;
     }
     if (n == "rec_form") {                           // which form of the fp32 recurrence a launch takes (A/B for tests; results are bit-identical)
@@ -762,7 +818,11 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.trace = e->trace;
     if (e->front_b9 == 2) {
         fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9w[ni]);
-        HIP_TRY(e, vad::launch_front_b9w<float>(sr, fa, stream));
+        const long tiles = (long)((B + 15) / 16) * T;
+        int rc2 = grow(e, reinterpret_cast<void **>(&e->d_mags), &e->mags_bytes, (size_t)tiles * vad::mag_tile_floats(sr) * sizeof(float), stream, "magnitude");
+        if (rc2) return rc2;
+        HIP_TRY(e, vad::launch_fft_mags<float>(sr, fa, e->d_mags, 0, tiles, stream));
+        HIP_TRY(e, vad::launch_front_b9g(sr, fa, e->d_mags, 0, tiles, 256, stream));
     } else if (e->front_b9) {
         fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
         HIP_TRY(e, vad::launch_front_b9<float>(sr, fa, stream));

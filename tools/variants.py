@@ -47,6 +47,13 @@ VARIANTS = {
     "nopk_all": [],                                     # every knob unit without packed fp32 (the bf16 x 9 recurrence beside plain VALU only)
     "b9_w4": ["-DVAD_B9_WAVES=4"],                     # bf16 x 9 frontend: two 4-wave workgroups per CU (default: one 8-wave workgroup)
     "pk_b9": [],
+    # two-kernel bf16 x 9 frontend: register budgets (GEMM kernel total = 2 x VAD_B9G_VGPRS; FFT kernel 512 / (4 VAD_FFT_WG_PER_CU) ... )
+    "b9g_344_fft128": ["-DVAD_B9G_VGPRS=172", "-DVAD_FFT_WG_PER_CU=4"], "b9g_344_fft160": ["-DVAD_B9G_VGPRS=172", "-DVAD_FFT_WG_PER_CU=3"],
+    "b9g_384_fft128": ["-DVAD_B9G_VGPRS=192", "-DVAD_FFT_WG_PER_CU=4"], "b9g_512_fft160": ["-DVAD_B9G_VGPRS=256", "-DVAD_FFT_WG_PER_CU=3"],
+    "b9g_d1": ["-DVAD_B9G_VGPRS=256", "-DVAD_FFT_WG_PER_CU=3", "-DVAD_B9G_DEPTH=1", "-DVAD_B9G_PRIO=0"],
+    "b9g_d2": ["-DVAD_B9G_VGPRS=256", "-DVAD_FFT_WG_PER_CU=3", "-DVAD_B9G_DEPTH=2", "-DVAD_B9G_PRIO=0"],
+    "b9g_d2_p3_344": ["-DVAD_B9G_VGPRS=172", "-DVAD_FFT_WG_PER_CU=3", "-DVAD_B9G_DEPTH=2", "-DVAD_B9G_PRIO=3"],
+    "b9g_d2_p0_344": ["-DVAD_B9G_VGPRS=172", "-DVAD_FFT_WG_PER_CU=3", "-DVAD_B9G_DEPTH=2", "-DVAD_B9G_PRIO=0"],
     # wide bf16 x 9 frontend (tools/b9w_time.py): timing-only ablations
     "abl_w_nofft": ["-DVAD_ABLATE=2"], "abl_w_nofft_noload": ["-DVAD_ABLATE=6"], "abl_w_nosplit": ["-DVAD_ABLATE=64"], "abl_w_nofrag": ["-DVAD_ABLATE=128"],
     "abl_w_nobar_noring": ["-DVAD_ABLATE=9"], "abl_w_mfma_only": ["-DVAD_ABLATE=207"],                                        # bf16 x 9 frontend WITH packed fp32 VALU instructions (the product builds it without)
