@@ -94,15 +94,6 @@ hipError_t launch_rec_small(int sr, const RecArgs &a, hipStream_t s);
 // `a.wfront` points at the three-piece image (layout.hpp "bf16 x 9 frontend image").  Same gx layout as launch_front_f43.
 template <typename PcmT>
 hipError_t launch_front_b9(int sr, const FrontArgs &a, hipStream_t s);
-// The same function and bits as TWO kernels (kernel_front_b9w.hip): launch_fft_mags leaves the STFT magnitudes of the tiles
-// [tile0, tile0 + ntiles) of the launch (tile index = stream tile * a.nt + slab-relative step) in `mags` (mag_tile_floats(sr) floats per
-// tile) and writes ctx_out; launch_front_b9g turns them into gate pre-activations -- GEMM only, persistent, at most `cus` workgroups,
-// encoder 0 matrix by matrix over all 128 rows; `a.wfront` points at the wide image (layout.hpp "bf16 x 9 frontend image, WIDE program").
-// The two are meant for two streams: the FFT kernel of the next slab runs beside the GEMM kernel of this one.
-template <typename PcmT>
-hipError_t launch_fft_mags(int sr, const FrontArgs &a, float *mags, long tile0, long ntiles, hipStream_t s);
-hipError_t launch_front_b9g(int sr, const FrontArgs &a, const float *mags, long tile0, long ntiles, int cus, hipStream_t s);
-long mag_tile_floats(int sr);
 // The same recurrence with W_hh * h as exact bf16 x 9 piece products on the bf16 matrix pipe (kernel_rec_b9.hip); `whh` points
 // to the three-piece image (layout.hpp "bf16 x 9 recurrent image").  Option "rec" = "bf16x9".
 hipError_t launch_rec_b9(int sr, const RecArgs &a, hipStream_t s);

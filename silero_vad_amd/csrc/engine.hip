@@ -31,7 +31,7 @@ struct vad_images {
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
     float *d_front4[2] = {}, *d_whh[2] = {}, *d_whh_lat[2] = {}, *d_whh_rows[2] = {}, *d_tables[2] = {};
-    uint16_t *d_whh_b9[2] = {}, *d_front_b9[2] = {}, *d_front_b9w[2] = {};
+    uint16_t *d_whh_b9[2] = {}, *d_front_b9[2] = {};
 #if VAD_AB
     float *d_front[2] = {}, *d_front_wino[2] = {};
 #endif
@@ -44,7 +44,6 @@ struct vad_images {
             if (d_whh_b9[ni]) (void)hipFree(d_whh_b9[ni]);
             if (d_whh_rows[ni]) (void)hipFree(d_whh_rows[ni]);
             if (d_front_b9[ni]) (void)hipFree(d_front_b9[ni]);
-            if (d_front_b9w[ni]) (void)hipFree(d_front_b9w[ni]);
             if (d_whh_lat[ni]) (void)hipFree(d_whh_lat[ni]);
             if (d_tables[ni]) (void)hipFree(d_tables[ni]);
 #if VAD_AB
@@ -67,8 +66,7 @@ struct vad_engine {
     bool fuse_step = true;                          // a ONE-step call small enough for the latency frontend runs the LSTM cell and the head in
                                                     // the same kernel (option "fuse_step")
     int rec_form = 0;                               // fp32 recurrence: 0 auto (VALU matrix-vector form for B <= 1024, same bits), 1 MFMA form always
-    int front_b9 = 0;                               // frontend products: 0 fp32 MFMA chain (default) | exact bf16 x 9 piece products: 2 the wide
-                                                    // form (kernel_front_b9w.hip), 1 the narrow form (kernel_front_b9.hip; same bits) (option "front_mma")
+    bool front_b9 = false;                          // frontend products: fp32 MFMA chain (default) | exact bf16 x 9 (option "front_mma")
     bool rec_b9 = false;                            // recurrence: fp32 MFMA chain (default) | exact bf16 x 9 products (option "rec")
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the frontend's loads (option "fused_decimation")
@@ -85,13 +83,6 @@ struct vad_engine {
     size_t tail_bytes = 0;
     void *d_realign = nullptr;                      // aligned copy of a misaligned input (rare)
     size_t realign_bytes = 0;
-    float *d_mags = nullptr;                        // front_mma=bf16x9: the STFT magnitudes between the FFT kernel and the GEMM kernel
-    size_t mags_bytes = 0;
-    hipStream_t fft_stream = nullptr;               // ... the FFT kernel's stream, forked from / joined to the caller's by events
-    hipEvent_t fft_fork = nullptr;
-    std::vector<hipEvent_t> fft_done;
-    int cus = 0;                                    // compute units of the device (the persistent GEMM kernel's grid)
-    int b9_slabs = 8;                               // tile slabs per launch: the FFT kernel of slab s + 1 runs beside the GEMM kernel of slab s
     void *d_decim = nullptr;                        // 16 kHz copy of a 64/80/... kHz input
     size_t decim_bytes = 0;
     unsigned long scratch_gen = 0;                  // bumped whenever a scratch buffer is reallocated: a hipGraph that
@@ -151,9 +142,7 @@ int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
     // worst case of the tail copy: fp32 samples at 48 kHz (dec = 3) -- sized here so that no forward call has to grow it
     // (a growth is a device synchronisation and cannot happen while the call is being captured into a hipGraph)
     const size_t need_tail = (size_t)B * (sr == 16000 ? 512 * 3 : 256) * sizeof(float);
-    // front_mma=bf16x9: the magnitudes of one gx slab's tiles between the FFT kernel and the GEMM kernel
-    const size_t need_mags = e->front_b9 == 2 ? (size_t)nst * slab * vad::mag_tile_floats(sr) * sizeof(float) : 0;
-    if (need_gx > e->gx_floats || need_ctx > e->ctx_floats || need_tail > e->tail_bytes || need_mags > e->mags_bytes) {
+    if (need_gx > e->gx_floats || need_ctx > e->ctx_floats || need_tail > e->tail_bytes) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
             return fail(e, VAD_ERR_CAPTURE, "scratch must grow during stream capture; call vad_reserve first");
@@ -174,14 +163,6 @@ int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
             if (hipMalloc((void **)&e->d_ctx_new, need_ctx * sizeof(float)) != hipSuccess)
                 return fail(e, VAD_ERR_ALLOC, "cannot allocate context scratch");
             e->ctx_floats = need_ctx;
-        }
-        if (need_mags > e->mags_bytes) {
-            if (e->d_mags) (void)hipFree(e->d_mags);
-            e->d_mags = nullptr;
-            e->mags_bytes = 0;
-            if (hipMalloc((void **)&e->d_mags, need_mags) != hipSuccess)
-                return fail(e, VAD_ERR_ALLOC, "cannot allocate magnitude scratch");
-            e->mags_bytes = need_mags;
         }
         if (need_tail > e->tail_bytes) {
             if (e->d_tail) (void)hipFree(e->d_tail);
@@ -306,39 +287,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             }
             continue;
         }
-        if (e->front_b9 == 2) {
-            // two kernels side by side: the FFT kernel runs slab by slab on the engine's side stream, ahead of the GEMM kernel
-            fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9w[ni]);
-            const long per = vad::mag_tile_floats(sr);
-            rc = grow(e, reinterpret_cast<void **>(&e->d_mags), &e->mags_bytes, (size_t)tiles * per * sizeof(float), stream, "magnitude");
-            if (rc) return rc;
-            if (!e->fft_stream) {
-                HIP_TRY(e, hipStreamCreateWithFlags(&e->fft_stream, hipStreamNonBlocking));
-                HIP_TRY(e, hipEventCreateWithFlags(&e->fft_fork, hipEventDisableTiming));
-                hipDeviceProp_t prop;
-                HIP_TRY(e, hipGetDeviceProperties(&prop, e->device));
-                e->cus = prop.multiProcessorCount;
-            }
-            const int S = (int)std::max<long>(1, std::min<long>(e->b9_slabs, tiles / (4L * e->cus)));
-            while ((int)e->fft_done.size() < S) {
-                hipEvent_t x;
-                HIP_TRY(e, hipEventCreateWithFlags(&x, hipEventDisableTiming));
-                e->fft_done.push_back(x);
-            }
-            HIP_TRY(e, hipEventRecord(e->fft_fork, stream));          // the FFT kernels start behind whatever the caller queued (the PCM)
-            HIP_TRY(e, hipStreamWaitEvent(e->fft_stream, e->fft_fork, 0));
-            const long chunk = (tiles + S - 1) / S / 4 * 4 + 4;
-            for (int sidx = 0; sidx < S; ++sidx) {
-                const long lo = std::min<long>(tiles, sidx * chunk), hi = std::min<long>(tiles, lo + chunk);
-                HIP_TRY(e, vad::launch_fft_mags<PcmT>(sr, fa, e->d_mags, lo, hi - lo, e->fft_stream));
-                HIP_TRY(e, hipEventRecord(e->fft_done[sidx], e->fft_stream));
-            }
-            for (int sidx = 0; sidx < S; ++sidx) {
-                const long lo = std::min<long>(tiles, sidx * chunk), hi = std::min<long>(tiles, lo + chunk);
-                HIP_TRY(e, hipStreamWaitEvent(stream, e->fft_done[sidx], 0));
-                HIP_TRY(e, vad::launch_front_b9g(sr, fa, e->d_mags, lo, hi - lo, e->cus, stream));
-            }
-        } else if (e->front_b9) {
+        if (e->front_b9) {
             fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
             HIP_TRY(e, vad::launch_front_b9<PcmT>(sr, fa, stream));
         } else
@@ -481,7 +430,6 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
         if (upload(e, &im.d_whh[ni], pk.whh)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_b9[ni], pk.whh_b9)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_front_b9[ni], pk.front_b9)) return bail(VAD_ERR_HIP);
-        if (upload(e, &im.d_front_b9w[ni], pk.front_b9w)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_lat[ni], pk.whh_lat)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_rows[ni], pk.whh_rows)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_tables[ni], pk.tables)) return bail(VAD_ERR_HIP);
@@ -529,10 +477,6 @@ void vad_destroy(vad_engine *e) {
         if (e->d_tail) (void)hipFree(e->d_tail);
         if (e->d_realign) (void)hipFree(e->d_realign);
         if (e->d_decim) (void)hipFree(e->d_decim);
-        if (e->d_mags) (void)hipFree(e->d_mags);
-        if (e->fft_stream) (void)hipStreamDestroy(e->fft_stream);
-        if (e->fft_fork) (void)hipEventDestroy(e->fft_fork);
-        for (auto &ev : e->fft_done) (void)hipEventDestroy(ev);
         for (int i = 0; i < vad_engine::kTabSlots; ++i) {
             if (e->h_tab[i]) (void)hipHostFree(e->h_tab[i]);
             if (e->tab_ev[i]) (void)hipEventDestroy(e->tab_ev[i]);
@@ -600,16 +544,9 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         return VAD_OK;
     }
     if (n == "front_mma") {                          // the frontend's matrix products: fp32 MFMA chain | exact bf16 x 9 piece products
-        if (v == "fp32") e->front_b9 = 0;            // (bf16x9: every launch takes the throughput form, whatever its size -- the
-        else if (v == "bf16x9" || v == "bf16x9_wide") e->front_b9 = 2;       //  arithmetic of a result must not depend on the batch it came in)
-        else if (v == "bf16x9_narrow") e->front_b9 = 1;                       // the round-3 kernel: the same bits, A/B for tests
-        else return fail(e, VAD_ERR_OPTION, "front_mma must be fp32|bf16x9|bf16x9_wide|bf16x9_narrow");
-        return VAD_OK;
-    }
-    if (n == "b9_slabs") {                           // front_mma=bf16x9: tile slabs per launch (1: the FFT kernel runs entirely before the GEMM kernel)
-        const long v2 = std::strtol(value, nullptr, 0);
-        if (v2 < 1 || v2 > 64) return fail(e, VAD_ERR_OPTION, "b9_slabs must be 1..64");
-        e->b9_slabs = (int)v2;
+        if (v == "fp32") e->front_b9 = false;        // (bf16x9: every launch takes the throughput form, whatever its size -- the
+        else if (v == "bf16x9") e->front_b9 = true;  //  arithmetic of a result must not depend on the batch it came in)
+        else return fail(e, VAD_ERR_OPTION, "front_mma must be fp32|bf16x9");
         return VAD_OK;
     }
     if (n == "rec_form") {                           // which form of the fp32 recurrence a launch takes (A/B for tests; results are bit-identical)
@@ -750,15 +687,15 @@ long vad_debug_packed_floats(const vad_engine *e, int sr, int which) {
     const vad::PackedNet &p = e->weights->packed[ni];
     return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size() : which == 2 ? (long)p.tables.size()
          : which == 5 ? (long)p.front_wino.size() : which == 6 ? (long)p.front_wino4.size()
-         : which == 7 ? (long)p.whh_b9.size() / 2 : which == 8 ? (long)p.front_b9.size() / 2 : which == 9 ? (long)p.front_b9w.size() / 2 : -1;
+         : which == 7 ? (long)p.whh_b9.size() / 2 : which == 8 ? (long)p.front_b9.size() / 2 : -1;
 }
 
 int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n) {
     const int ni = net_index(sr);
     if (!e || ni < 0 || !dst) return VAD_ERR_ARG;
     const vad::PackedNet &p = e->weights->packed[ni];
-    if (which == 7 || which == 8 || which == 9) {                 // three-piece bf16 images: raw 4-byte words holding two bf16 each
-        const std::vector<uint16_t> &h = which == 7 ? p.whh_b9 : which == 8 ? p.front_b9 : p.front_b9w;
+    if (which == 7 || which == 8) {                 // three-piece bf16 images: raw 4-byte words holding two bf16 each
+        const std::vector<uint16_t> &h = which == 7 ? p.whh_b9 : p.front_b9;
         if (n != (long)h.size() / 2) return VAD_ERR_ARG;
         std::memcpy(dst, h.data(), h.size() * sizeof(uint16_t));
         return VAD_OK;
@@ -816,14 +753,7 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.gx = e->d_gx;
     fa.B = B;
     fa.trace = e->trace;
-    if (e->front_b9 == 2) {
-        fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9w[ni]);
-        const long tiles = (long)((B + 15) / 16) * T;
-        int rc2 = grow(e, reinterpret_cast<void **>(&e->d_mags), &e->mags_bytes, (size_t)tiles * vad::mag_tile_floats(sr) * sizeof(float), stream, "magnitude");
-        if (rc2) return rc2;
-        HIP_TRY(e, vad::launch_fft_mags<float>(sr, fa, e->d_mags, 0, tiles, stream));
-        HIP_TRY(e, vad::launch_front_b9g(sr, fa, e->d_mags, 0, tiles, 256, stream));
-    } else if (e->front_b9) {
+    if (e->front_b9) {
         fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
         HIP_TRY(e, vad::launch_front_b9<float>(sr, fa, stream));
     } else
@@ -911,8 +841,10 @@ int vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, lo
     if (how == 0) {
         // copy engines: one H2D DMA per row (any alignment; no CU time), the padding by one fill of the batch first
         HIP_TRY(e, hipMemsetAsync(dst, 0, (size_t)n * width * elem_size, stream));
-        int ways = vad_engine::kDmaStreams;
-        if (const char *v = std::getenv("SILERO_VAD_AMD_DMA_STREAMS")) ways = std::max(1, std::min(ways, std::atoi(v)));
+        // (one stream by default: dealing the copies to 2-4 streams reached 46 GB/s on one box and 29 on another, with the calls
+        //  themselves blocking for milliseconds -- profiles/r04d_ingest_routes.md; SILERO_VAD_AMD_DMA_STREAMS=2..4 is the A/B)
+        int ways = 1;
+        if (const char *v = std::getenv("SILERO_VAD_AMD_DMA_STREAMS")) ways = std::max(1, std::min(vad_engine::kDmaStreams, std::atoi(v)));
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (n < 2 * ways || (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)) ways = 1;
         if (ways > 1) {

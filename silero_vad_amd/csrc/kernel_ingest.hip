@@ -15,9 +15,6 @@
 //   * the row table (pointer, length) is itself read from pinned memory, so the host only fills a small table and launches.
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
-#include <cstdlib>
-
 #include "device_api.hpp"
 
 namespace vad {
@@ -35,14 +32,13 @@ constexpr int kGatherWaves = VAD_GATHER_WAVES;   // one-wave workgroups: the who
 // 53 GB/s but sat on every SIMD of the chip, where its registers kept the frontend (two 243-VGPR waves per SIMD) from
 // placing its second wave: the compute kernels beside it ran 4x slower (tools/ingest_diag.py).  96 single waves touch 9 % of
 // the SIMDs.
-__global__ void __launch_bounds__(1024) gather_rows_kernel(const RowDesc *rows, long n, long width_bytes, int esz, uint8_t *dst,
-                                                           long segs_per_row) {
+__global__ void __launch_bounds__(64) gather_rows_kernel(const RowDesc *rows, long n, long width_bytes, int esz, uint8_t *dst,
+                                                         long segs_per_row) {
     using u32x4 = unsigned __attribute__((ext_vector_type(4)));
     const long items = n * segs_per_row;
-    const int lane = threadIdx.x & 63;
-    const long wpb = blockDim.x >> 6;        // waves per workgroup: every wave walks its own items
+    const int lane = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);          // few instructions, long waits: let them issue ahead of the compute waves' streams
-    for (long item = blockIdx.x * wpb + (threadIdx.x >> 6); item < items; item += gridDim.x * wpb) {
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
         const long row = item / segs_per_row, seg = item % segs_per_row;
         const uint8_t *src = reinterpret_cast<const uint8_t *>(rows[row].ptr);
         const long live = rows[row].len * esz;                     // bytes that exist; the rest of the row is zero
@@ -87,14 +83,9 @@ hipError_t launch_gather_rows(const RowDesc *rows, long n, long width, int esz, 
     if (items > 0x7fffffffL) return hipErrorInvalidValue;
     // sources in HBM (a packed window that one big DMA brought over): an HBM-to-HBM scatter, as wide as the chip -- it runs
     // for a fraction of a millisecond; sources in host memory: the narrow persistent grid described above
-    long waves = rows_on_device ? 4096 : kGatherWaves, wpb = 1;
-    if (!rows_on_device) {                    // bring-up knobs (tools/ingest_diag.py): total waves, waves per workgroup
-        if (const char *v = std::getenv("VAD_GATHER_WAVES_RT")) waves = std::max(1L, std::atol(v));
-        if (const char *v = std::getenv("VAD_GATHER_WPB_RT")) wpb = std::min(16L, std::max(1L, std::atol(v)));
-    }
-    const long wgs = (waves + wpb - 1) / wpb;
-    const unsigned grid = (unsigned)std::max(1L, std::min(wgs, (items + wpb - 1) / wpb));
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(64 * (unsigned)wpb), 0, s, rows, n, wb, esz, static_cast<uint8_t *>(dst), segs);
+    const long waves = rows_on_device ? 4096 : kGatherWaves;
+    const unsigned grid = (unsigned)(items < waves ? items : waves);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(64), 0, s, rows, n, wb, esz, static_cast<uint8_t *>(dst), segs);
     return hipGetLastError();
 }
 

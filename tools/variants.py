@@ -18,7 +18,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
-HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_front_b9w.hip", "kernel_rec.hip", "kernel_rec_small.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
+HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_rec.hip", "kernel_rec_small.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
        "kernel_ingest.hip"]
 CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
@@ -47,16 +47,6 @@ VARIANTS = {
     "nopk_all": [],                                     # every knob unit without packed fp32 (the bf16 x 9 recurrence beside plain VALU only)
     "b9_w4": ["-DVAD_B9_WAVES=4"],                     # bf16 x 9 frontend: two 4-wave workgroups per CU (default: one 8-wave workgroup)
     "pk_b9": [],
-    # two-kernel bf16 x 9 frontend: register budgets (GEMM kernel total = 2 x VAD_B9G_VGPRS; FFT kernel 512 / (4 VAD_FFT_WG_PER_CU) ... )
-    "b9g_344_fft128": ["-DVAD_B9G_VGPRS=172", "-DVAD_FFT_WG_PER_CU=4"], "b9g_344_fft160": ["-DVAD_B9G_VGPRS=172", "-DVAD_FFT_WG_PER_CU=3"],
-    "b9g_384_fft128": ["-DVAD_B9G_VGPRS=192", "-DVAD_FFT_WG_PER_CU=4"], "b9g_512_fft160": ["-DVAD_B9G_VGPRS=256", "-DVAD_FFT_WG_PER_CU=3"],
-    "b9g_d1": ["-DVAD_B9G_VGPRS=256", "-DVAD_FFT_WG_PER_CU=3", "-DVAD_B9G_DEPTH=1", "-DVAD_B9G_PRIO=0"],
-    "b9g_d2": ["-DVAD_B9G_VGPRS=256", "-DVAD_FFT_WG_PER_CU=3", "-DVAD_B9G_DEPTH=2", "-DVAD_B9G_PRIO=0"],
-    "b9g_d2_p3_344": ["-DVAD_B9G_VGPRS=172", "-DVAD_FFT_WG_PER_CU=3", "-DVAD_B9G_DEPTH=2", "-DVAD_B9G_PRIO=3"],
-    "b9g_d2_p0_344": ["-DVAD_B9G_VGPRS=172", "-DVAD_FFT_WG_PER_CU=3", "-DVAD_B9G_DEPTH=2", "-DVAD_B9G_PRIO=0"],
-    # wide bf16 x 9 frontend (tools/b9w_time.py): timing-only ablations
-    "abl_w_nofft": ["-DVAD_ABLATE=2"], "abl_w_nofft_noload": ["-DVAD_ABLATE=6"], "abl_w_nosplit": ["-DVAD_ABLATE=64"], "abl_w_nofrag": ["-DVAD_ABLATE=128"],
-    "abl_w_nobar_noring": ["-DVAD_ABLATE=9"], "abl_w_mfma_only": ["-DVAD_ABLATE=207"],                                        # bf16 x 9 frontend WITH packed fp32 VALU instructions (the product builds it without)
 }
 
 
@@ -68,7 +58,7 @@ def build(names):
     shared.mkdir(exist_ok=True)
     procs = []
     # translation units without knobs are compiled once
-    knob_units = {"kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_front_b9w.hip", "kernel_rec.hip", "kernel_rec_b9.hip"}
+    knob_units = {"kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_rec.hip", "kernel_rec_b9.hip"}
     if os.environ.get("VAD_VARIANT_UNITS"):      # only these translation units carry the knobs (the others come from the shared build)
         knob_units = set(os.environ["VAD_VARIANT_UNITS"].split(","))
     for src in HIP + CPP:
@@ -83,7 +73,7 @@ def build(names):
         d = OUT / ("obj_" + name)
         d.mkdir(exist_ok=True)
         for src in knob_units:
-            extra = nopk if (name.startswith("nopk") or (src in ("kernel_front_b9.hip", "kernel_front_b9w.hip") and not name.startswith("pk_"))) else []
+            extra = nopk if (name.startswith("nopk") or (src == "kernel_front_b9.hip" and not name.startswith("pk_"))) else []
             procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950"] + common + extra + VARIANTS[name]
                                           + ["-c", str(CSRC / src), "-o", str(d / (src + ".o"))]))
     for p in procs:
