@@ -55,7 +55,16 @@ struct Lane {
     bool tile_valid;         // wave-uniform
     bool from_tail;          // wave-uniform: this is the last, partial chunk -> read a.tail
     float sgnA, sgnB;        // +-1 butterfly signs for the cross-lane radix-4
+#if VAD_TRACE
+    mutable unsigned long long ts[20] = {};    // bring-up: shader-clock timestamps of this WAVE, kept in SGPRs (wave-uniform) and written
+                                               // out at the end of the kernel -- no vector register, no memory operation in flight
+#endif
 };
+#if VAD_TRACE
+#define VAD_WAVE_STAMP(ln, slot) do { (ln).ts[(slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VAD_WAVE_STAMP(ln, slot) do { } while (0)
+#endif
 
 // ---- PCM slice loads --------------------------------------------------------------------------------
 __device__ __forceinline__ void cvt8(const u32x4 v, float *o) {       // 8 x int16 -> float / 32768
@@ -256,6 +265,7 @@ __device__ __forceinline__ void fft_frame(float (&X)[Q + 1], const int V, const 
                                           const Lane &ln) {
     constexpr int SL = 2 * Q;
     __builtin_amdgcn_sched_barrier(0);     // keep each pass's loads inside the pass (register budget)
+    VAD_WAVE_STAMP(ln, 16 + V);            // (trace builds: the pass begins -- behind the shift-register moves)
     float s[SL];
     if (VAD_ABLATE & 4) {
 #pragma unroll
@@ -263,6 +273,10 @@ __device__ __forceinline__ void fft_frame(float (&X)[Q + 1], const int V, const 
     } else {
         load_slice<Q, PcmT, DEC>(s, a, ln, V);
     }
+#if VAD_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (trace builds: the frame's samples have arrived -> slot 2 + 2 V)
+    VAD_WAVE_STAMP(ln, 2 + 2 * V);
+#endif
     if (VAD_ABLATE & 2) {
 #pragma unroll
         for (int k = 0; k < Q; ++k) X[k] = s[k] + s[k + Q];
@@ -270,6 +284,7 @@ __device__ __forceinline__ void fft_frame(float (&X)[Q + 1], const int V, const 
         return;
     }
     fft_math<Q>(X, s, tab_lds, ln);
+    VAD_WAVE_STAMP(ln, 3 + 2 * V);
 }
 
 template <int Q>

@@ -134,6 +134,9 @@ __device__ __forceinline__ void gemm_r(f32x4 (&acc)[M], BF bfun, Ring &r) {
     });
 }
 
+#ifndef VAD_F43_FFT_PRIO
+#define VAD_F43_FFT_PRIO 0         // A/B (tools/variants.py fftprio*): issue priority of a wave while it transforms a frame
+#endif
 template <int Q, typename PcmT, int DEC>
 __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     using namespace vadl;
@@ -162,6 +165,11 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     ln.from_tail = a.tail != nullptr && ln.t == a.T - 1;
     ln.sgnA = ln.g < 2 ? 1.f : -1.f;
     ln.sgnB = (ln.g & 1) ? -1.f : 1.f;
+#if VAD_TRACE
+    // bring-up (tools/trace_f43.py): 32 slots of shader-clock timestamps per WAVE (16 + v: frame v's pass begins) -- 0 start, 1 tables + units 0, 1 in LDS, 2 + 2 v / 3 + 2 v samples
+    // of frame v arrived / its FFT done, 10 encoders 0 + 1 done, 11 encoders 2 + 3 done, 12 end; 13 HW_ID, 14 XCC_ID
+    VAD_WAVE_STAMP(ln, 0);
+#endif
 
     Ring ring;
     {
@@ -199,6 +207,7 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // units 0 and 1 (and the tables) have landed
     __syncthreads();
+    VAD_WAVE_STAMP(ln, 1);
 
     // ---- the 4 frames: one FFT body ------------------------------------------------------------------------------------
     // The four magnitude arrays are a shift register: every iteration moves the frames down one place and transforms the
@@ -222,7 +231,9 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
 #pragma unroll
             for (int k = 0; k <= Q; ++k) X2[k] = X3[k];
         }
+        if (VAD_F43_FFT_PRIO) __builtin_amdgcn_s_setprio(VAD_F43_FFT_PRIO);
         fft_frame<Q, PcmT, DEC>(X3, v, a, tab, ln);
+        if (VAD_F43_FFT_PRIO) __builtin_amdgcn_s_setprio(0);
     }
     // |Y_nyq| of chunk j lives in lane group 0 (X[Q]); every lane of the chunk needs it
     const float xn0 = __shfl(X0[Q], ln.j), xn1 = __shfl(X1[Q], ln.j), xn2 = __shfl(X2[Q], ln.j), xn3 = __shfl(X3[Q], ln.j);
@@ -344,6 +355,7 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     }
     relu<4>(Z0);
     relu<4>(Z1);
+    VAD_WAVE_STAMP(ln, 10);
 
     // ---- enc2 (T 2 -> 1, stride 2: taps 1,2 see enc1 outputs 0,1), enc3 (T = 1: centre tap only), W_ih -----------------
     f32x4 Vv[4];
@@ -359,6 +371,7 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     init_bias<8>(Fe, tab + tb.b_e3, ln);
     gemm_r<8, 4, 2>(Fe, bV, ring);
     relu<8>(Fe);
+    VAD_WAVE_STAMP(ln, 11);
 
     // LSTM input-gate pre-activations, one gate (8 row blocks) at a time, stored in D-fragment order: gates 0..2 share a
     // loop body, the last gate knows that the program ends
@@ -385,6 +398,17 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
             for (int m = 0; m < 8; ++m) *reinterpret_cast<f32x4 *>(gxt + (size_t)m * 256) = G[m];
         }
     }
+#if VAD_TRACE
+    VAD_WAVE_STAMP(ln, 12);
+    if (a.trace && ln.lane == 0) {
+        long long *tr = a.trace + ((size_t)blockIdx.x * 4 + ln.wave) * 32;
+#pragma unroll
+        for (int k = 0; k < 20; ++k) tr[k] = (long long)ln.ts[k];
+        tr[13] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        tr[14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+        tr[15] = (long long)wall_clock64();
+    }
+#endif
 }
 
 }  // namespace

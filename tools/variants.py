@@ -32,6 +32,8 @@ VARIANTS = {
     "nobvbatch": ["-DVAD_BV_BATCH=0"],                 # frontend: B-operand transforms interleaved with the MFMAs (round-2 form)
     "xbasis": ["-DVAD_F43_EF=0"],                       # F(4,3) input transform from x0..x3 instead of (E, F, x1, x2) (f43 form only)
     "trace": ["-DVAD_TRACE=1"],
+    "fftprio1": ["-DVAD_F43_FFT_PRIO=1"], "fftprio3": ["-DVAD_F43_FFT_PRIO=3"],
+    "trace_fftprio3": ["-DVAD_TRACE=1", "-DVAD_F43_FFT_PRIO=3"],
     "trace_noload": ["-DVAD_TRACE=1", "-DVAD_ABLATE=4"],
     "abl_nobar": ["-DVAD_ABLATE=1"],
     "abl_nofft": ["-DVAD_ABLATE=2"],
