@@ -134,6 +134,9 @@ __device__ __forceinline__ void gemm_r(f32x4 (&acc)[M], BF bfun, Ring &r) {
     });
 }
 
+#ifndef VAD_F43_GEMM_PRIO
+#define VAD_F43_GEMM_PRIO 0        // A/B: issue priority of a wave from the end of its FFT passes on
+#endif
 #ifndef VAD_F43_FFT_PRIO
 #define VAD_F43_FFT_PRIO 0         // A/B (tools/variants.py fftprio*): issue priority of a wave while it transforms a frame
 #endif
@@ -235,6 +238,7 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
         fft_frame<Q, PcmT, DEC>(X3, v, a, tab, ln);
         if (VAD_F43_FFT_PRIO) __builtin_amdgcn_s_setprio(0);
     }
+    if (VAD_F43_GEMM_PRIO) __builtin_amdgcn_s_setprio(VAD_F43_GEMM_PRIO);
     // |Y_nyq| of chunk j lives in lane group 0 (X[Q]); every lane of the chunk needs it
     const float xn0 = __shfl(X0[Q], ln.j), xn1 = __shfl(X1[Q], ln.j), xn2 = __shfl(X2[Q], ln.j), xn3 = __shfl(X3[Q], ln.j);
 

@@ -34,6 +34,7 @@ VARIANTS = {
     "trace": ["-DVAD_TRACE=1"],
     "fftprio1": ["-DVAD_F43_FFT_PRIO=1"], "fftprio3": ["-DVAD_F43_FFT_PRIO=3"],
     "trace_fftprio3": ["-DVAD_TRACE=1", "-DVAD_F43_FFT_PRIO=3"],
+    "gemmprio3": ["-DVAD_F43_GEMM_PRIO=3"], "trace_gemmprio3": ["-DVAD_TRACE=1", "-DVAD_F43_GEMM_PRIO=3"],
     "trace_noload": ["-DVAD_TRACE=1", "-DVAD_ABLATE=4"],
     "abl_nobar": ["-DVAD_ABLATE=1"],
     "abl_nofft": ["-DVAD_ABLATE=2"],
