@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: speech-probability throughput of the Silero-VAD hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|8k|stream|corpus|plumbing]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|8k|stream|stream_host|stream_8k|stream_host_8k|corpus|plumbing|plumbing_8k]
 
 `--gpus N` (N > 1) works both ways the driver may start it: under `python -m torch.distributed.run
 --nproc-per-node N ... bench.py --gpus N` (RANK/LOCAL_RANK/WORLD_SIZE in the environment), and as a plain
@@ -14,24 +14,34 @@ vad_forward_audio call through the C ABI (zeroed context/state, like the referen
 are sharded across ranks with no data-path collective (weak scaling: every rank owns 4096 streams); the only
 communication is the barrier + MAX-reduce of the elapsed time that the measurement contract asks for.
 
+Every leg CERTIFIES ITSELF: after its timed region the CPU oracle recomputes streams of the leg's own PCM (c2 / 8k: streams 0..15
+and the last 16, all 256 chunks, probabilities and final (h, c); stream legs: 24 ticks of streams 0..15 through the leg's own graph;
+corpus: every 10 000th recording + its segments) and the leg fails above 1e-4 (`parity`, `parity_max_abs_dp`).
+
 The same JSON line also carries, for the record (none of them is the headline `value`):
-  other_configs    8k       configs[2]: 8 kHz, 256-sample chunks, 4096 streams x 256 chunks (the 8 kHz net)   [N = 1]
-                   stream   configs[4]: 8192 live streams per GPU (65 536 per 8-GPU node), persistent state in
-                            HBM, one hipGraph-captured vad_step per 32 ms tick; reports tick latency          [any N]
-                   corpus   configs[3]: every rank runs a FULL per-GPU shard of the 10 000 h corpus (1 250 h =
-                            151 552 ragged recordings, 37 passes of 4096 over fresh offsets) from pinned host
-                            memory -> device batch (no host copy) -> probs -> segmenter on the GPU -> segment
-                            lists, sharded by duration and gathered to rank 0; wall time, PCIe- and host-inclusive,
-                            with a 1-in-10^4 recording parity sample checked after the timed region          [any N]
-                   plumbing configs[0]: the reference's default usage -- B = 1 `model(chunk, sr).item()` per-call
-                            latency (eager and hipGraph) and get_speech_timestamps on the 60 s fixture       [N = 1]
-  other_arithmetic rec_bf16x9: the same C2 workload with the recurrence as exact bf16 x 9 products (opt-in; N = 1)
+  other_configs    8k           configs[2]: 8 kHz, 256-sample chunks, 4096 streams x 256 chunks (the 8 kHz net)            [N = 1]
+                   stream       configs[4], KERNEL ONLY: 8192 live streams per GPU (65 536 per 8-GPU node), persistent state in
+                                HBM, one hipGraph-captured vad_step per 32 ms tick from a device-side audio ring           [any N]
+                   stream_host  configs[4] END TO END: int16 chunks in a page-locked ingest ring -> ONE hipGraph per tick (H2D,
+                                fused step, D2H) -> the VADIterator logic of every stream on the host (native) -> events: tick
+                                latency host-to-events, and sustained chunks/s (sub-pools, two ticks in flight) against the int16
+                                PCIe ceiling                                                                               [any N]
+                   corpus       configs[3]: every rank runs a FULL per-GPU shard of the 10 000 h corpus (1 250 h =
+                                151 552 ragged recordings, 37 passes of 4096 over fresh offsets) from pinned host
+                                memory -> device batch (no host copy) -> probs -> segmenter on the GPU -> segment
+                                lists, sharded by duration and gathered to rank 0; wall time, PCIe- and host-inclusive,
+                                with a 1-in-10^4 recording parity sample checked after the timed region                    [any N]
+                   stream_8k, stream_host_8k, plumbing_8k: the 8 kHz net through the same legs                            [N = 1]
+                   plumbing     configs[0]: the reference's default usage -- B = 1 `model(chunk, sr).item()` per-call
+                                latency (eager and hipGraph) and get_speech_timestamps on the 60 s fixture                 [N = 1]
+  other_arithmetic rec_bf16x9 / all_bf16x9: the same C2 workload with the opt-in exact bf16 x 9 products (N = 1)
   roofline         dominant kernel (frontend: STFT + encoder + W_ih GEMM): EXECUTED fp32 MFMA flops per launch /
                    average launch duration (hipEvents recorded by the engine around that kernel on the launch
                    stream during the timed steps) against the dense fp32 MFMA peak; always <= 1
   cpu_baseline     the reference's own ATen CPU operators (oracle/aten_port.py, kind "aten-port") timed on this
-                   box's host cores under BASELINE.md section 3 protocols R1-R4 (rank 0, N = 1 only)
-`--config 8k|stream|corpus|plumbing` runs one of the other configs as the main leg instead.
+                   box's host cores under BASELINE.md section 3 protocols R1-R5 (rank 0, N = 1 only; R5 = get_speech_timestamps
+                   on the fixture through the per-chunk protocol, the CPU figure beside `plumbing`)
+`--config <name>` runs one of the other configs as the main leg instead.
 """
 import argparse
 import glob

@@ -601,18 +601,29 @@ int vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t ele
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
     const int ni = net_index(sr);
     if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000]");
-    if (B < 0 || (elem_size != 2 && elem_size != 4) || (B > 0 && (!host_pcm || !dev_pcm || !ctx || !state || !dev_prob || !host_prob)))
+    if (B < 0 || (elem_size != 2 && elem_size != 4) || (B > 0 && (!host_pcm || !dev_pcm || !ctx || !state || !host_prob)))
         return fail(e, VAD_ERR_ARG, "bad argument");
     if (B == 0) return VAD_OK;
     hipStream_t stream = (hipStream_t)stream_v;
     const long N = sr == 16000 ? 512 : 256;
     HIP_TRY(e, hipSetDevice(e->device));
+    // dev_prob == NULL: the kernel stores the B probabilities straight into the page-locked host buffer (4 B per stream over the link,
+    // visible to the host once the stream has passed the call) -- no device buffer, no second copy
+    float *out = dev_prob;
+    if (!out) {
+        void *dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, host_prob, 0) != hipSuccess || !dv) {
+            (void)hipGetLastError();
+            return fail(e, VAD_ERR_ARG, "vad_step_host: host_prob is not page-locked memory the runtime knows");
+        }
+        out = static_cast<float *>(dv);
+    }
     HIP_TRY(e, hipMemcpyAsync(dev_pcm, host_pcm, (size_t)B * N * elem_size, hipMemcpyHostToDevice, stream));
     const int rc = elem_size == 2
-        ? forward_impl<int16_t>(e, sr, B, N, static_cast<const int16_t *>(dev_pcm), N, ctx, state, dev_prob, 1, stream_v)
-        : forward_impl<float>(e, sr, B, N, static_cast<const float *>(dev_pcm), N, ctx, state, dev_prob, 1, stream_v);
+        ? forward_impl<int16_t>(e, sr, B, N, static_cast<const int16_t *>(dev_pcm), N, ctx, state, out, 1, stream_v)
+        : forward_impl<float>(e, sr, B, N, static_cast<const float *>(dev_pcm), N, ctx, state, out, 1, stream_v);
     if (rc) return rc;
-    HIP_TRY(e, hipMemcpyAsync(host_prob, dev_prob, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (dev_prob) HIP_TRY(e, hipMemcpyAsync(host_prob, dev_prob, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, stream));
     return VAD_OK;
 }
 

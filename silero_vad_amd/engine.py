@@ -142,10 +142,11 @@ class Engine:
 
     def step_host(self, host_pcm, dev_pcm, sr, ctx, state, dev_prob, host_prob, stream=None):
         """One tick from page-locked host chunks to page-locked host probabilities on `stream` (a raw stream handle; default:
-        torch's current stream): H2D, the step, D2H -- vad_step_host, asynchronous."""
+        torch's current stream): H2D, the step, D2H -- vad_step_host, asynchronous.  dev_prob None: the kernel writes the
+        probabilities straight into host_prob."""
         B = host_pcm.shape[0]
         self._check(self._L.vad_step_host(self._h, sr, B, host_pcm.data_ptr(), host_pcm.element_size(), dev_pcm.data_ptr(),
-                                          ctx.data_ptr(), state.data_ptr(), dev_prob.data_ptr(), host_prob.data_ptr(),
+                                          ctx.data_ptr(), state.data_ptr(), None if dev_prob is None else dev_prob.data_ptr(), host_prob.data_ptr(),
                                           self._stream() if stream is None else ctypes.c_void_p(stream)))
 
     def upload_rows(self, rows, lens, n, width, elem_size, dst, how=0):

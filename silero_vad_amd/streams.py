@@ -1018,7 +1018,8 @@ class StreamPool:
 
     def _host_tick(self, r, stream=None):
         """What slot r's graph holds: ingest ring -> HBM, the step, probabilities -> host (one native call: vad_step_host)."""
-        self.engine.step_host(self.host_pcm[r], self.pcm, self.sr, self.ctx, self.state, self.prob, self.host_prob[r], stream)
+        # (the kernel stores the probabilities straight into the page-locked host_prob[r]: no device buffer, no D2H operation)
+        self.engine.step_host(self.host_pcm[r], self.pcm, self.sr, self.ctx, self.state, None, self.host_prob[r], stream)
 
     def _capture(self):
         """Capture one step into a hipGraph.  The graph bakes in the engine's scratch addresses, so it is tied to
