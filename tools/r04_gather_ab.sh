@@ -1,9 +1,10 @@
-for q in 4 8 16 4 8 16; do
-export GPU_MAX_HW_QUEUES=$q
-VAD_BENCH_CORPUS_UPLOAD=gather python bench.py --config corpus --no-cpu-baseline --corpus-main-only --no-parity --corpus-passes 8 > gpurun_out/corpus_g_$q.log 2>gpurun_out/corpus_g_$q.err || tail -5 gpurun_out/corpus_g_$q.err
-python - gpurun_out/corpus_g_$q.log $q <<'PY'
+# the default line's corpus routes, repeated, with the staging stream at normal / high priority
+for rep in 1 2; do for prio in 0 1; do
+SILERO_VAD_AMD_STAGE_PRIO=$prio python bench.py --no-cpu-baseline > gpurun_out/line_p$prio.log 2>gpurun_out/line_p$prio.err || tail -3 gpurun_out/line_p$prio.err
+python - gpurun_out/line_p$prio.log $prio <<'PY'
 import json,sys
 d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
-v=d["legs"]["main"]; print("corpus gather, GPU_MAX_HW_QUEUES", sys.argv[2], {a:v[a] for a in ("value","wall_s","h2d_GBps_while_copying","host_upload_call_ms","buckets")}, "of 55.5M:", round(v["value"]/55.5e6,3))
+oc=d["other_configs"]
+print("stage prio", sys.argv[2], {k: v["fraction_of_pcie_ceiling"] for k, v in oc["corpus"]["legs"].items()}, "stream_host", oc["stream_host"]["pcie"]["fraction_of_pcie_ceiling"], oc["stream_host_8k"]["pcie"]["fraction_of_pcie_ceiling"])
 PY
-done
+done; done
