@@ -101,3 +101,33 @@ def test_packed_image_sizes(built):
     w = read_container(good)["_model.decoder.rnn.weight_hh"]
     assert np.array_equal(np.sort(whh), np.sort(w.ravel()))
     L.vad_destroy(h)
+
+
+def build_c_client(tmp_path):
+    """tests/c_client/client.c -> an executable linked against the in-tree library: strict C99 against the header alone."""
+    import subprocess
+    from silero_vad_amd import _lib
+    exe = tmp_path / "client"
+    obj = tmp_path / "client.o"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c",
+                    str(ROOT / "tests" / "c_client" / "client.c"), "-o", str(obj)], check=True)
+    libdir = _lib.LIB_PATH.parent
+    subprocess.run(["gcc", str(obj), "-o", str(exe), "-L", str(libdir), f"-l:{_lib.LIB_PATH.name}", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_header_is_valid_c_and_a_plain_c_client_links(built, tmp_path):
+    """The boundary is a C ABI: the header must compile as strict C99 (no C++, no HIP headers) and a client that uses the streaming
+    entry points (vad_create, vad_reserve, vad_host_register, vad_step_host, vad_iterator_feed, ...) must link against the library.
+    Without a GPU the client fails loudly at vad_create (there is no CPU fallback behind the ABI either)."""
+    import subprocess
+    import torch
+    from silero_vad_amd import _lib
+    exe = build_c_client(tmp_path)
+    assert subprocess.run([str(exe)], capture_output=True).returncode == 64          # usage
+    if not torch.cuda.is_available():
+        pcm = tmp_path / "pcm.raw"
+        np.zeros(2048, np.int16).tofile(pcm)
+        r = subprocess.run([str(exe), str(_lib.WEIGHTS_PATH), str(pcm), "16000", "2"], capture_output=True, text=True)
+        assert r.returncode == 1 and "vad_create" in r.stderr, (r.returncode, r.stderr)

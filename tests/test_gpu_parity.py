@@ -525,6 +525,38 @@ def test_stream_pool_host_int16_chunks_in_events_out(model, golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_plain_c_client_streams_chunks_to_events(model, golden, tag, tmp_path):
+    """A non-Python client (tests/c_client/client.c: C99 against include/silero_vad_hip.h, the shape of the reference's ONNX Runtime
+    clients, examples/cpp/silero-vad-onnx.cpp:103-142) streams the fixture through vad_step_host + vad_iterator_feed: stream 0's
+    probabilities equal the reference model's (golden) and its events EQUAL the reference VADIterator's; the other streams equal the
+    Python path bit for bit."""
+    import subprocess
+    from test_abi import build_c_client
+    from silero_vad_amd import _lib
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    T = 400                                                   # 400 ticks of 3 streams
+    pcm = g["pcm_i16"]
+    raw = tmp_path / "pcm.raw"
+    pcm.tofile(raw)
+    exe = build_c_client(tmp_path)
+    full = len(pcm) // n
+    r = subprocess.run([str(exe), str(_lib.WEIGHTS_PATH), str(raw), str(sr), "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    probs = np.array([[float(v) for v in l.split()[2:]] for l in r.stdout.splitlines() if l.startswith("P ")], dtype=np.float32)
+    assert probs.shape == (full, 3)
+    assert np.abs(probs[:, 0] - np.asarray(g["probs_wav"]).reshape(-1)[:full]).max() < TIGHT
+    ev0 = [{l.split()[3]: int(l.split()[4])} for l in r.stdout.splitlines() if l.startswith("E ") and l.split()[2] == "0"]
+    assert ev0 == golden["segments"][tag]["iterator"]["default"]["events"]
+    # the Python path on the same chunks: bit for bit
+    rows = np.stack([np.roll(pcm, -b * 7919)[:T * n] for b in range(3)])
+    st = torch.zeros((2, 3, 128), device=model.device)
+    ctx = torch.zeros((3, n // 8), device=model.device)
+    want = model.engine.forward_audio(torch.from_numpy(rows).to(model.device), sr, ctx, st).cpu().numpy()
+    assert np.array_equal(probs[:T].T, want)
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
 def test_ragged_corpus_equals_single_recording_runs(model, oracle, golden, tag):
     """configs[3] plumbing: recordings of different lengths bucketed into lock-step batches give
     bit-identical probabilities and identical segments to one-recording-at-a-time calls."""
