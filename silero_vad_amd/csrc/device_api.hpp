@@ -94,10 +94,6 @@ hipError_t launch_rec_small(int sr, const RecArgs &a, hipStream_t s);
 // `a.wfront` points at the three-piece image (layout.hpp "bf16 x 9 frontend image").  Same gx layout as launch_front_f43.
 template <typename PcmT>
 hipError_t launch_front_b9(int sr, const FrontArgs &a, hipStream_t s);
-// The same function and bits in the PAIR form (kernel_front_b9p.hip: two waves share a tile, split its rows and its operand work and
-// exchange operand pieces through LDS); `a.wfront` points at the wide image (layout.hpp "bf16 x 9 frontend image, WIDE program").
-template <typename PcmT>
-hipError_t launch_front_b9p(int sr, const FrontArgs &a, hipStream_t s);
 // The same recurrence with W_hh * h as exact bf16 x 9 piece products on the bf16 matrix pipe (kernel_rec_b9.hip); `whh` points
 // to the three-piece image (layout.hpp "bf16 x 9 recurrent image").  Option "rec" = "bf16x9".
 hipError_t launch_rec_b9(int sr, const RecArgs &a, hipStream_t s);

@@ -31,7 +31,7 @@ struct vad_images {
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
     float *d_front4[2] = {}, *d_whh[2] = {}, *d_whh_lat[2] = {}, *d_whh_rows[2] = {}, *d_tables[2] = {};
-    uint16_t *d_whh_b9[2] = {}, *d_front_b9[2] = {}, *d_front_b9w[2] = {};
+    uint16_t *d_whh_b9[2] = {}, *d_front_b9[2] = {};
 #if VAD_AB
     float *d_front[2] = {}, *d_front_wino[2] = {};
 #endif
@@ -44,7 +44,6 @@ struct vad_images {
             if (d_whh_b9[ni]) (void)hipFree(d_whh_b9[ni]);
             if (d_whh_rows[ni]) (void)hipFree(d_whh_rows[ni]);
             if (d_front_b9[ni]) (void)hipFree(d_front_b9[ni]);
-            if (d_front_b9w[ni]) (void)hipFree(d_front_b9w[ni]);
             if (d_whh_lat[ni]) (void)hipFree(d_whh_lat[ni]);
             if (d_tables[ni]) (void)hipFree(d_tables[ni]);
 #if VAD_AB
@@ -67,8 +66,7 @@ struct vad_engine {
     bool fuse_step = true;                          // a ONE-step call small enough for the latency frontend runs the LSTM cell and the head in
                                                     // the same kernel (option "fuse_step")
     int rec_form = 0;                               // fp32 recurrence: 0 auto (VALU matrix-vector form for B <= 1024, same bits), 1 MFMA form always
-    int front_b9 = 0;                               // frontend products: 0 fp32 MFMA chain (default) | exact bf16 x 9 piece products: 2 the pair
-                                                    // form (kernel_front_b9p.hip), 1 the narrow form (kernel_front_b9.hip; same bits) (option "front_mma")
+    bool front_b9 = false;                          // frontend products: fp32 MFMA chain (default) | exact bf16 x 9 (option "front_mma")
     bool rec_b9 = false;                            // recurrence: fp32 MFMA chain (default) | exact bf16 x 9 products (option "rec")
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the frontend's loads (option "fused_decimation")
@@ -289,10 +287,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             }
             continue;
         }
-        if (e->front_b9 == 2) {
-            fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9w[ni]);
-            HIP_TRY(e, vad::launch_front_b9p<PcmT>(sr, fa, stream));
-        } else if (e->front_b9) {
+        if (e->front_b9) {
             fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
             HIP_TRY(e, vad::launch_front_b9<PcmT>(sr, fa, stream));
         } else
@@ -435,7 +430,6 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
         if (upload(e, &im.d_whh[ni], pk.whh)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_b9[ni], pk.whh_b9)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_front_b9[ni], pk.front_b9)) return bail(VAD_ERR_HIP);
-        if (upload(e, &im.d_front_b9w[ni], pk.front_b9w)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_lat[ni], pk.whh_lat)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_whh_rows[ni], pk.whh_rows)) return bail(VAD_ERR_HIP);
         if (upload(e, &im.d_tables[ni], pk.tables)) return bail(VAD_ERR_HIP);
@@ -550,10 +544,9 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         return VAD_OK;
     }
     if (n == "front_mma") {                          // the frontend's matrix products: fp32 MFMA chain | exact bf16 x 9 piece products
-        if (v == "fp32") e->front_b9 = 0;            // (bf16x9: every launch takes the throughput form, whatever its size -- the
-        else if (v == "bf16x9_pair") e->front_b9 = 2;                         //  arithmetic of a result must not depend on the batch it came in)
-        else if (v == "bf16x9" || v == "bf16x9_narrow") e->front_b9 = 1;     // the two forms give the same bits
-        else return fail(e, VAD_ERR_OPTION, "front_mma must be fp32|bf16x9|bf16x9_pair|bf16x9_narrow");
+        if (v == "fp32") e->front_b9 = false;        // (bf16x9: every launch takes the throughput form, whatever its size -- the
+        else if (v == "bf16x9") e->front_b9 = true;  //  arithmetic of a result must not depend on the batch it came in)
+        else return fail(e, VAD_ERR_OPTION, "front_mma must be fp32|bf16x9");
         return VAD_OK;
     }
     if (n == "rec_form") {                           // which form of the fp32 recurrence a launch takes (A/B for tests; results are bit-identical)
@@ -705,15 +698,15 @@ long vad_debug_packed_floats(const vad_engine *e, int sr, int which) {
     const vad::PackedNet &p = e->weights->packed[ni];
     return which == 0 ? (long)p.front.size() : which == 1 ? (long)p.whh.size() : which == 2 ? (long)p.tables.size()
          : which == 5 ? (long)p.front_wino.size() : which == 6 ? (long)p.front_wino4.size()
-         : which == 7 ? (long)p.whh_b9.size() / 2 : which == 8 ? (long)p.front_b9.size() / 2 : which == 9 ? (long)p.front_b9w.size() / 2 : -1;
+         : which == 7 ? (long)p.whh_b9.size() / 2 : which == 8 ? (long)p.front_b9.size() / 2 : -1;
 }
 
 int vad_debug_packed_copy(const vad_engine *e, int sr, int which, float *dst, long n) {
     const int ni = net_index(sr);
     if (!e || ni < 0 || !dst) return VAD_ERR_ARG;
     const vad::PackedNet &p = e->weights->packed[ni];
-    if (which == 7 || which == 8 || which == 9) {                 // three-piece bf16 images: raw 4-byte words holding two bf16 each
-        const std::vector<uint16_t> &h = which == 7 ? p.whh_b9 : which == 8 ? p.front_b9 : p.front_b9w;
+    if (which == 7 || which == 8) {                 // three-piece bf16 images: raw 4-byte words holding two bf16 each
+        const std::vector<uint16_t> &h = which == 7 ? p.whh_b9 : p.front_b9;
         if (n != (long)h.size() / 2) return VAD_ERR_ARG;
         std::memcpy(dst, h.data(), h.size() * sizeof(uint16_t));
         return VAD_OK;
@@ -771,10 +764,7 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.gx = e->d_gx;
     fa.B = B;
     fa.trace = e->trace;
-    if (e->front_b9 == 2) {
-        fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9w[ni]);
-        HIP_TRY(e, vad::launch_front_b9p<float>(sr, fa, stream));
-    } else if (e->front_b9) {
+    if (e->front_b9) {
         fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
         HIP_TRY(e, vad::launch_front_b9<float>(sr, fa, stream));
     } else

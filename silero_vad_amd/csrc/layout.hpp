@@ -139,25 +139,6 @@ constexpr int w4_unit_m(int u, int Q) {               // row blocks of the segme
 constexpr long kW9UnitHalfs = 4L * 3 * 2 * 64 * 8;   // 12 288 bf16 = 24 KiB
 constexpr long front_b9_halfs(int Q) { return (long)w4_units(Q) * kW9UnitHalfs; }
 
-// ---- bf16 x 9 frontend image, WIDE program (kernel_front_b9w.hip) ---------------------------------------------------------------
-// The same units' worth of weights in the order of a different loop nest: encoder 0 matrix by matrix over ALL 8 row blocks (the
-// transformed input of a K32 step is formed and split into pieces ONCE instead of once per row part), then encoder 1 part by part,
-// then the tail -- every accumulator still sees its MFMAs in the order of the narrow program above, so the results are the same bits.
-//   units 0 .. 6 KP - 1 (KP = Q / 8 K32 steps):  unit j KP + kp = matrix j (order U1, U2, U3, U4, U0, U5), K32 step kp, all rows:
-//       [piece 3][row block 8][lane 64][8 bf16] = 24 KiB; fragment (pa, rb) = the narrow image's fragment of part rb / RB, matrix j,
-//       K32 step kp, piece pa, row block rb % RB
-//   then the encoder-1 units of part 0, part 1, ... (narrow units w4_e1(p, i), copied as they are), then the tail (copied).
-constexpr int w9w_kp(int Q) { return Q / 8; }
-constexpr int w9w_e0(int j, int kp, int Q) { return j * w9w_kp(Q) + kp; }
-constexpr int w9w_e1_0(int p, int Q) {                        // first encoder-1 unit of part p
-    int u = 6 * w9w_kp(Q);
-    for (int i = 0; i < p; ++i) u += w4_e1_units(i, Q);
-    return u;
-}
-constexpr int w9w_tail0(int Q) { return w9w_e1_0(w_parts(Q), Q); }
-constexpr int w9w_units(int Q) { return w9w_tail0(Q) + 20; }
-static_assert(w9w_units(32) == w4_units(32) && w9w_units(16) == w4_units(16), "the wide program holds the narrow program's units");
-
 // ---- recurrent image: [wave 8][gate 4][kgroup 8][lane 64][4] ------------------------------------
 constexpr long whh_floats() { return 8L * 4 * 8 * 256; }
 

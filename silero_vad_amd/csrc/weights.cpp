@@ -273,32 +273,6 @@ void pack_net(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
                         }
                     }
     }
-    // ... and in the order of the wide program: a permutation of the narrow image's 1 KiB fragments (layout.hpp)
-    p.front_b9w.assign((size_t)front_b9_halfs(Q), 0);
-    {
-        const int RBn = w_rb(Q), H = RBn / 2, KP = w9w_kp(Q), P = w_parts(Q);
-        constexpr size_t FRAG = 64 * 8;                          // bf16 per fragment
-        auto narrow_frag = [&](int u, int step, int piece, int rb2) {     // [step 4][piece 3][row block 2][lane][8]
-            return p.front_b9.data() + (size_t)u * kW9UnitHalfs + (((size_t)step * 3 + piece) * 2 + rb2) * FRAG;
-        };
-        for (int j = 0; j < 6; ++j)
-            for (int kp = 0; kp < KP; ++kp) {
-                uint16_t *dst = p.front_b9w.data() + (size_t)w9w_e0(j, kp, Q) * kW9UnitHalfs;
-                for (int pa = 0; pa < 3; ++pa)
-                    for (int rb = 0; rb < 8; ++rb) {
-                        // narrow unit (part, j): step i = kp * H + mh carries row blocks 2 mh, 2 mh + 1 of the part
-                        const int part = rb / RBn, rbl = rb % RBn, mh = rbl / 2;
-                        const uint16_t *src = narrow_frag(w4_e0(part, j, Q), kp * H + mh, pa, rbl % 2);
-                        std::memcpy(dst + ((size_t)pa * 8 + rb) * FRAG, src, FRAG * sizeof(uint16_t));
-                    }
-            }
-        for (int part = 0; part < P; ++part)
-            for (int i = 0; i < w4_e1_units(part, Q); ++i)
-                std::memcpy(p.front_b9w.data() + (size_t)(w9w_e1_0(part, Q) + i) * kW9UnitHalfs,
-                            p.front_b9.data() + (size_t)w4_e1(part, i, Q) * kW9UnitHalfs, kW9UnitHalfs * sizeof(uint16_t));
-        std::memcpy(p.front_b9w.data() + (size_t)w9w_tail0(Q) * kW9UnitHalfs, p.front_b9.data() + (size_t)w4_tail0(Q) * kW9UnitHalfs,
-                    20 * kW9UnitHalfs * sizeof(uint16_t));
-    }
     const Tab tb = make_tab(g.F, Q);
     p.tables.assign((size_t)tb.total, 0.f);
     float *T = p.tables.data();

@@ -29,7 +29,6 @@ struct PackedNet {
     std::vector<float> whh_lat;  // recurrent weights gate by gate in W_ih's block order [gate][kg 8][row block 8][lane][4] (kernel_front_lat.hip, fused step)
     std::vector<float> whh_rows; // recurrent weights row by row in the MFMA chain's summation order (layout.hpp "whh_rows", kernel_rec_small.hip)
     std::vector<uint16_t> whh_b9;    // recurrent image as three bf16 pieces per weight (layout.hpp "bf16 x 9 recurrent image")
-    std::vector<uint16_t> front_b9w; // the same weights in the order of the wide program (layout.hpp "bf16 x 9 frontend image, WIDE program")
     std::vector<uint16_t> front_b9;  // the F(4,3) program as three bf16 pieces per weight, 24 KiB units (layout.hpp "bf16 x 9 frontend image")
     std::vector<float> tables;   // biases, head, window, twiddles, Nyquist-bin weights
 };

@@ -18,7 +18,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
-HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_front_b9p.hip", "kernel_rec.hip", "kernel_rec_small.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
+HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_rec.hip", "kernel_rec_small.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
        "kernel_ingest.hip"]
 CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
 
@@ -50,9 +50,6 @@ VARIANTS = {
     "nopk_all": [],                                     # every knob unit without packed fp32 (the bf16 x 9 recurrence beside plain VALU only)
     "b9_w4": ["-DVAD_B9_WAVES=4"],                     # bf16 x 9 frontend: two 4-wave workgroups per CU (default: one 8-wave workgroup)
     "pk_b9": [],
-    # pair-form bf16 x 9 frontend: timing-only ablations (tools/b9_time.py bf16x9_pair)
-    "abl_p_nofft": ["-DVAD_ABLATE=2"], "abl_p_nofft_noload": ["-DVAD_ABLATE=6"], "abl_p_nosplit": ["-DVAD_ABLATE=64"], "abl_p_nofrag": ["-DVAD_ABLATE=128"],
-    "abl_p_nobar_noring": ["-DVAD_ABLATE=9"], "abl_p_noslotread": ["-DVAD_ABLATE=256"], "abl_p_mfma_only": ["-DVAD_ABLATE=463"],
 }
 
 
@@ -64,7 +61,7 @@ def build(names):
     shared.mkdir(exist_ok=True)
     procs = []
     # translation units without knobs are compiled once
-    knob_units = {"kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_front_b9p.hip", "kernel_rec.hip", "kernel_rec_b9.hip"}
+    knob_units = {"kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_rec.hip", "kernel_rec_b9.hip"}
     if os.environ.get("VAD_VARIANT_UNITS"):      # only these translation units carry the knobs (the others come from the shared build)
         knob_units = set(os.environ["VAD_VARIANT_UNITS"].split(","))
     for src in HIP + CPP:
@@ -79,7 +76,7 @@ def build(names):
         d = OUT / ("obj_" + name)
         d.mkdir(exist_ok=True)
         for src in knob_units:
-            extra = nopk if (name.startswith("nopk") or (src in ("kernel_front_b9.hip", "kernel_front_b9p.hip") and not name.startswith("pk_"))) else []
+            extra = nopk if (name.startswith("nopk") or (src == "kernel_front_b9.hip" and not name.startswith("pk_"))) else []
             procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950"] + common + extra + VARIANTS[name]
                                           + ["-c", str(CSRC / src), "-o", str(d / (src + ".o"))]))
     for p in procs:
