@@ -36,6 +36,22 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned &p0, unsigne
     }
     p0 = out[0]; p1 = out[1]; p2 = out[2];
 }
+#ifdef B9LOOP_TRUNC
+// pieces by TRUNCATION: p0 = the top 16 bits of x, p1 = the top 16 bits of x - p0, p2 = x - p0 - p1 (<= 8 significant bits: its top 16 bits
+// hold all of it); x = p0 + p1 + p2 exactly as with rounding, the chains are two levels shallower and need no conversion instruction
+__device__ __forceinline__ void split3(float x0, float x1, unsigned &p0, unsigned &p1, unsigned &p2);
+__device__ __forceinline__ void split3t(float x0, float x1, unsigned &p0, unsigned &p1, unsigned &p2) {
+#pragma clang fp contract(off)
+    const unsigned a0 = __float_as_uint(x0) & 0xffff0000u, b0 = __float_as_uint(x1) & 0xffff0000u;
+    const float ra = x0 - __uint_as_float(a0), rb = x1 - __uint_as_float(b0);
+    const unsigned a1 = __float_as_uint(ra) & 0xffff0000u, b1 = __float_as_uint(rb) & 0xffff0000u;
+    const float sa = ra - __uint_as_float(a1), sb = rb - __uint_as_float(b1);
+    p0 = __builtin_amdgcn_perm(b0, a0, 0x07060302u);          // (hi half of b0) : (hi half of a0)
+    p1 = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+#define split3 split3t
+#endif
 __device__ __forceinline__ void split_step(u32x4 (&bp)[3], const float (&v)[8]) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
