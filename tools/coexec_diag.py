@@ -10,7 +10,7 @@ eng = Engine(0)
 dev = torch.device("cuda", 0)
 sr, B, T, n = 16000, 4096, 256, 512
 x = 0.1 * torch.randn((B, T * n), device=dev)
-mma = sys.argv[1] if len(sys.argv) > 1 else "bf16x9_wide"
+mma = sys.argv[1] if len(sys.argv) > 1 else "bf16x9"
 eng.set_option("front_mma", mma)
 ctx = torch.zeros((B, n // 8), device=dev)
 gx = None
