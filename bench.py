@@ -799,7 +799,7 @@ def run_corpus(args, rank, world, local, dist, passes):
         def one(m):
             rec = PackedRecordings(src, (offs if src is base_i else offs_rand)[:m], lens[:m])
             if sched == "buckets":      # length-sorted buckets, one lock-step call each, device scan per bucket
-                return ragged_speech_segments(rec, model, sr, max_waste=0.1, max_bytes=1 << 30, as_arrays=True)
+                return ragged_speech_segments(rec, model, sr, max_waste=0.1, max_bytes=int(os.environ.get("VAD_BENCH_BUCKET_BYTES", 1 << 30)), as_arrays=True)
             segs = refill_speech_segments(rec, model, sr, slots=2048, slab_chunks=64)   # persistent slots, refilled at slab boundaries
             return np.asarray([len(x) for x in segs]), None
 
