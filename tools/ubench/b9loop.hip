@@ -79,6 +79,27 @@ __global__ void __launch_bounds__(256, 2) loop_kernel(int n, Rec *rec, float *si
     u32x4 c0 = frag[0], c1 = frag[64];
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < n; ++i) {
+        if (MODE == 10 || MODE == 11) {                   // the full step with issue priorities: high while multiplying (10) / while splitting (11)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], 0.999f, 1e-4f);
+            __builtin_amdgcn_s_setprio(MODE == 11 ? 3 : 0);
+            split_step(bp, v);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(MODE == 10 ? 3 : 0);
+#pragma unroll
+            for (int pa = 0; pa < 3; ++pa) {
+                const u32x4 n0 = frag[(2 * (pa + 1)) * 64], n1 = frag[(2 * (pa + 1) + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pb = 0; pb < 3; ++pb) {
+                    acc[0] = mfma_b(c0, bp[pb], acc[0]);
+                    acc[1] = mfma_b(c1, bp[pb], acc[1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = n0; c1 = n1;
+            }
+            continue;
+        }
         if (MODE == 0 || MODE == 2) {                     // the operand values change every step, as in the kernel
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], 0.999f, 1e-4f);
@@ -217,6 +238,8 @@ int main() {
         run<7>("roles: even slots MFMAs only, odd slots split only", wgs, n, d_rec, d_sink);
         run<8>("next split interleaved: [1 MFMA][3 VALU] x 18", wgs, n, d_rec, d_sink);
         run<9>("next split interleaved: [1 MFMA][2 VALU] x 18", wgs, n, d_rec, d_sink);
+        run<10>("full step, s_setprio 3 while multiplying", wgs, n, d_rec, d_sink);
+        run<11>("full step, s_setprio 3 while splitting", wgs, n, d_rec, d_sink);
     }
     return 0;
 }
