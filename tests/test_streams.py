@@ -411,3 +411,33 @@ def test_model_call_returns_a_tensor_where_the_input_lives(oracle):
     sig = torch.from_numpy(_wav()[:512 + 2 * 256])
     x = model._to_device(sig.unfold(0, 512, 256))
     assert x.shape == (3, 512) and x.stride(0) >= 512
+
+
+def test_iterator_feed_argument_errors_and_event_capacity(built):
+    """vad_iterator_feed (the C entry point behind BatchVADIterator): bad arguments are refused, and a too small event buffer is
+    reported by the return value (the number of events there were), never overrun."""
+    import ctypes
+    from silero_vad_amd import _lib
+    L = _lib.lib()
+    n = 6
+    probs = np.full(n, 0.9, np.float32)                   # every stream starts speaking on this tick
+    trig = np.zeros(n, np.uint8)
+    tend = np.zeros(n, np.int64)
+    cur = np.zeros(n, np.int64)
+    ev = (_lib.IterEvent * 2)()                           # room for two of the six events
+    ev[1].slot = -7
+    args = (probs.ctypes.data, None, n, 512, 0.5, 1600.0, 480.0, trig.ctypes.data, tend.ctypes.data, cur.ctypes.data)
+    m = L.vad_iterator_feed(*args, ev, 2)
+    assert m == n and [ev[0].slot, ev[1].slot] == [0, 1] and ev[0].kind == 0 and ev[0].sample == 0       # max(0, 512 - 480 - 512)
+    assert trig.all() and (cur == 512).all()
+    assert L.vad_iterator_feed(probs.ctypes.data, None, -1, 512, 0.5, 1600.0, 480.0, trig.ctypes.data, tend.ctypes.data, cur.ctypes.data, ev, 2) == -1
+    assert L.vad_iterator_feed(None, None, n, 512, 0.5, 1600.0, 480.0, trig.ctypes.data, tend.ctypes.data, cur.ctypes.data, ev, 2) == -1
+    assert L.vad_iterator_feed(probs.ctypes.data, None, n, 0, 0.5, 1600.0, 480.0, trig.ctypes.data, tend.ctypes.data, cur.ctypes.data, ev, 2) == -1
+    assert L.vad_iterator_feed(probs.ctypes.data, None, n, 512, 0.5, 1600.0, 480.0, trig.ctypes.data, tend.ctypes.data, cur.ctypes.data, None, 2) == -1
+    # the Python wrapper checks its own arguments
+    from silero_vad_amd import BatchVADIterator
+    it = BatchVADIterator(4)
+    with pytest.raises(ValueError, match="expected 4 probabilities"):
+        it.feed(np.zeros(5, np.float32))
+    with pytest.raises(ValueError, match="expected 4 active flags"):
+        it.feed(np.zeros(4, np.float32), active=[True] * 3)
