@@ -115,6 +115,11 @@ void oracle_destroy(oracle_t *o) {
 }
 
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+/* torch.relu (JIT!/vad/utils/model_utils.py:19-25, head JIT!/torch/nn/modules/container/___torch_mangle_7.py:10-19) is
+ * clamp_min(0), which PROPAGATES NaN: one NaN / Inf sample makes the chunk's probability and the carried (h, c) NaN, and
+ * every later chunk of the stream stays NaN until reset_states() (tests/golden/make_golden.py, protocol "nonfinite").
+ * `x > 0 ? x : 0` would map NaN to 0 and hide that; this form keeps it. */
+static inline float relu_(float x) { return x <= 0.0f ? 0.0f : x; }
 
 /* ---- one stream, one step -------------------------------------------------------------------
  * x1    [C+N]   context followed by the chunk
@@ -159,7 +164,7 @@ static float step_one(const oracle_net *n, const float *x1, float *h, float *c, 
                     for (int i = 0; i < ci; ++i) a += w[i * 3 + tau] * in[i * T + v];
                     acc += a;
                 }
-                out[o * To + u] = acc > 0.f ? acc : 0.f;
+                out[o * To + u] = relu_(acc);
             }
         }
         if (stage) memcpy(stage + so, out, sizeof(float) * co * To);
@@ -185,7 +190,7 @@ static float step_one(const oracle_net *n, const float *x1, float *h, float *c, 
         const float cn = fg * c[j] + ig * gg;
         const float hn = og * tanhf(cn);
         c[j] = cn; h[j] = hn;
-        p += n->w_out[j] * (hn > 0.f ? hn : 0.f);
+        p += n->w_out[j] * relu_(hn);
     }
     return sigmoidf_(p);
 }

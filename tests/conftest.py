@@ -33,8 +33,11 @@ def golden():
         d = dict(np.load(GOLD / f"golden_{tag}.npz"))
         d["pcm_i16"] = np.load(GOLD / f"audio_{tag}.npz")["pcm"]
         d["wav"] = d["pcm_i16"].astype(np.float32) / 32768.0
+        d.update(np.load(GOLD / f"golden_ext_{tag}.npz"))       # round-5 protocols: nonfinite, gain (make_golden.py extended())
         out[tag] = d
     out["segments"] = json.loads((GOLD / "golden_segments.json").read_text())
+    out["ext"] = json.loads((GOLD / "golden_ext.json").read_text())
+    out["misc"] = dict(np.load(GOLD / "golden_ext_misc.npz"))    # decim (16 kHz fixture [::2] at 8 kHz), srswitch
     return out
 
 

@@ -17,6 +17,18 @@ Protocols (all trace to the reference):
   * stage    -- per-layer activations of 16 chunks (mag, enc0..3, h, c) for kernel bring-up
   * segments -- get_speech_timestamps / VADIterator outputs for several argument sets,
                and the examples/openvino/verify.py:116-127 segment-count KATs (29 / 79)
+Round-5 additions (golden_ext_{16k,8k}.npz + golden_ext.json; the files above are untouched and still reproduce bit for bit):
+  * nonfinite -- ``model(x[B, N], sr)`` on 6 speech streams: clean | NaN sample in chunk 3 | +Inf in chunk 5 | -Inf in the
+               last (context) samples of chunk 4 | 1e20 (finite, overflows the magnitude) in chunk 6 | clean; then
+               ``reset_states()`` and 4 clean chunks.  torch.relu / aten::lstm_cell propagate NaN
+               (JIT!/vad/utils/model_utils.py:19-25, JIT!/torch/nn/modules/rnn.py:69): the poisoned stream reads NaN from
+               that chunk until the reset.  Plus get_speech_timestamps on the fixture with one NaN sample inside speech
+               and inside silence (utils_vad.py:328,352-361: a NaN probability passes neither threshold test).
+  * gain      -- the wav protocol at gain 0.1 and 0.01 (quiet speech), probabilities + final state + default segments
+  * decim     -- (16 kHz fixture only) test.wav[::2] through the 8 kHz net, examples/onnx_sequence/README.md:61
+  * sr48000   -- get_speech_timestamps(np.repeat(wav, 3), sampling_rate=48000) (x[::3] front door, utils_vad.py:301-305)
+  * srswitch  -- a 4-stream batch whose calls switch sr 16000 -> 8000 -> 16000 (auto reset,
+               JIT!/vad/model/vad_annotator.py:37-57)
 """
 import json
 import sys
@@ -216,6 +228,109 @@ def main():
               len(it_out["default"]["events"]))
 
     (HERE / "golden_segments.json").write_text(json.dumps(seg_json, indent=1))
+    extended(model)
+
+
+NONFINITE = [  # (stream, chunk, sample position as a fraction of the chunk, value)
+    (1, 3, 0.20, float("nan")),
+    (2, 5, 0.50, float("inf")),
+    (3, 4, 0.98, float("-inf")),      # inside the last C samples: also part of chunk 5's context
+    (4, 6, 0.40, 1e20),               # finite; (w * 1e20)^2 overflows fp32 in the magnitude -> Inf -> NaN in encoder 0
+]
+
+
+def first_gap(segs, lo, min_len):
+    """start of the first silence of at least min_len samples after sample lo (from the clean default segments)."""
+    for a, b in zip(segs[:-1], segs[1:]):
+        if a["end"] >= lo and b["start"] - a["end"] >= min_len:
+            return a["end"]
+    raise RuntimeError("no gap")
+
+
+def extended(model):
+    """Round-5 protocols (module docstring).  Everything is derived from the two committed audio fixtures."""
+    import warnings
+    ext_json = {}
+    wavs = {}
+    for sr in (16000, 8000):
+        n, ctx = CHUNK[sr], CTX[sr]
+        tag = "16k" if sr == 16000 else "8k"
+        wav = load_wav_i16(WAVS[sr], sr).astype(np.float32) / 32768.0
+        wavs[sr] = wav
+        wav_t = torch.from_numpy(wav)
+        out, js = {}, {}
+
+        # --- nonfinite --------------------------------------------------------------------------------
+        B, T, TR = 6, 12, 4
+        off = 40 * n
+        rows = np.stack([np.roll(wav, -b * 7919)[off: off + (T + TR) * n] for b in range(B)]).copy()
+        pos = []
+        for b, t, frac, val in NONFINITE:
+            i = t * n + int(frac * n)
+            rows[b, i] = val
+            pos.append([b, t, i])
+        model.reset_states()
+        probs = [model(torch.from_numpy(rows[:, t * n:(t + 1) * n]), sr).numpy()[:, 0] for t in range(T)]
+        out["nf_rows"], out["nf_pos"] = rows, np.asarray(pos, np.int64)
+        out["nf_probs"], out["nf_state"] = np.stack(probs, 1), model._state.numpy().copy()
+        model.reset_states()
+        probs = [model(torch.from_numpy(rows[:, t * n:(t + 1) * n]), sr).numpy()[:, 0] for t in range(T, T + TR)]
+        out["nf_probs_after_reset"], out["nf_state_after_reset"] = np.stack(probs, 1), model._state.numpy().copy()
+        nanmap = np.isnan(out["nf_probs"])
+        print(sr, "nonfinite: first NaN chunk per stream", [int(r.argmax()) if r.any() else -1 for r in nanmap],
+              "state NaN rows", np.isnan(out["nf_state"]).all(axis=(0, 2)).tolist())
+        clean = get_speech_timestamps(wav_t, model, sampling_rate=sr)
+        speech_at = (clean[3]["start"] + clean[3]["end"]) // 2
+        silence_at = first_gap(clean, clean[3]["end"], 3 * n) + n + n // 2
+        js["nonfinite_timestamps"] = {}
+        for name, at in (("nan_in_speech", speech_at), ("nan_in_silence", silence_at), ("inf_in_speech", speech_at)):
+            w2 = wav.copy()
+            w2[at] = np.inf if name.startswith("inf") else np.nan
+            js["nonfinite_timestamps"][name] = {
+                "at": int(at), "value": "inf" if name.startswith("inf") else "nan",
+                "out": get_speech_timestamps(torch.from_numpy(w2), model, sampling_rate=sr)}
+        print(sr, "nonfinite segments", {k: len(v["out"]) for k, v in js["nonfinite_timestamps"].items()},
+              "clean", len(clean))
+
+        # --- gain ---------------------------------------------------------------------------------------
+        js["gain"] = {}
+        for g, gt in ((0.1, "g01"), (0.01, "g001")):
+            q = (wav * np.float32(g)).astype(np.float32)
+            p, st, _ = chained_probs(model, q, sr, pad_tail=True)
+            out[f"probs_{gt}"], out[f"state_{gt}"] = p, st
+            js["gain"][gt] = {"gain": g, "out": get_speech_timestamps(torch.from_numpy(q), model, sampling_rate=sr)}
+            print(sr, "gain", g, "mean prob", float(p.mean()), "segments", len(js["gain"][gt]["out"]))
+
+        # --- sr 48000 front door (16 kHz net only: 48000 % 16000 == 0) -----------------------------------
+        if sr == 16000:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                # np.repeat(wav, 3) is a 48 kHz signal whose x[::3] is the fixture itself: timestamps come back in 48 kHz samples
+                js["sr48000"] = {"out": get_speech_timestamps(torch.from_numpy(np.repeat(wav, 3)), model, sampling_rate=48000)}
+            print(sr, "sr48000 segments", len(js["sr48000"]["out"]))
+        np.savez_compressed(HERE / f"golden_ext_{tag}.npz", **out)
+        ext_json[tag] = js
+
+    # --- decim: the 16 kHz fixture decimated by 2 through the 8 kHz net -------------------------------------
+    dec = np.ascontiguousarray(wavs[16000][::2])
+    p, st, cx = chained_probs(model, dec, 8000, pad_tail=True)
+    segs = get_speech_timestamps(torch.from_numpy(dec), model, sampling_rate=8000)
+    print("decim chunks", len(p), "mean", float(p.mean()), "segments", len(segs), "kat", len(kat_segments(p)))
+    ext_json["decim_16k_to_8k"] = {"out": segs, "kat_segments_thr05_min8": len(kat_segments(p))}
+
+    # --- srswitch: 4 streams, calls alternate between the two nets ----------------------------------------
+    plan = [16000] * 3 + [8000] * 3 + [16000] * 2 + [8000] * 1
+    model.reset_states()
+    sw, cur = [], {16000: 40 * 512, 8000: 40 * 256}
+    for sr in plan:
+        n = CHUNK[sr]
+        x = np.stack([np.roll(wavs[sr], -b * 7919)[cur[sr]: cur[sr] + n] for b in range(4)])
+        cur[sr] += n
+        sw.append(model(torch.from_numpy(x), sr).numpy()[:, 0])
+    np.savez_compressed(HERE / "golden_ext_misc.npz", probs_decim=p, state_decim=st, ctx_decim=cx,
+                        srswitch_plan=np.asarray(plan, np.int64), srswitch_probs=np.stack(sw, 0),
+                        srswitch_state=model._state.numpy().copy())
+    (HERE / "golden_ext.json").write_text(json.dumps(ext_json, indent=1))
 
 
 if __name__ == "__main__":

@@ -70,6 +70,105 @@ def test_stages(oracle, golden, tag):
     assert state_err(state, g["stage_state_out"]) < TOL_STATE
 
 
+def check_nonfinite(g, probs, state, probs_after, tol_prob, tol_state):
+    """The reference's behaviour on NaN / Inf / overflowing samples (make_golden.py, protocol nonfinite): NaN exactly where the
+    reference is NaN (sticky from the poisoned chunk on, whole (h, c) rows), everything else within tolerance."""
+    want = g["nf_probs"]
+    assert np.array_equal(np.isnan(probs), np.isnan(want))
+    assert np.isnan(want).sum() == 9 + 7 + 8 + 6                      # streams 1-4, from chunks 3, 5, 4, 6 of 12
+    ok = ~np.isnan(want)
+    assert np.abs(probs[ok] - want[ok]).max() < tol_prob
+    assert np.array_equal(np.isnan(state), np.isnan(g["nf_state"]))
+    rows = ~np.isnan(g["nf_state"]).any(axis=(0, 2))
+    assert rows.tolist() == [True, False, False, False, False, True]
+    assert state_err(state[:, rows], g["nf_state"][:, rows]) < tol_state
+    # after reset_states() the stream is clean again
+    assert not np.isnan(probs_after).any()
+    assert np.abs(probs_after - g["nf_probs_after_reset"]).max() < tol_prob
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_nonfinite_protocol(oracle, golden, tag):
+    g, sr = golden[tag], SRS[tag]
+    n = 512 if sr == 16000 else 256
+    rows, T = g["nf_rows"], g["nf_probs"].shape[1]
+    oracle.reset_states()
+    probs = np.stack([oracle(rows[:, t * n:(t + 1) * n], sr)[:, 0] for t in range(T)], 1)
+    state = oracle._state.copy()
+    oracle.reset_states()
+    after = np.stack([oracle(rows[:, t * n:(t + 1) * n], sr)[:, 0] for t in range(T, rows.shape[1] // n)], 1)
+    check_nonfinite(g, probs, state, after, TOL_PROB, TOL_STATE)
+    # the time-loop entry agrees with the per-chunk one
+    p2, _, s2 = oracle.forward_audio(rows[:, :T * n], sr)
+    assert np.array_equal(np.isnan(p2), np.isnan(probs)) and np.array_equal(np.isnan(s2), np.isnan(state))
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_any_single_overflowing_bin_is_nan(oracle, golden, tag):
+    """The HIP path's rule is 'any non-finite STFT magnitude => the chunk is NaN' (csrc/front_common.hpp poison()); in the
+    reference an Inf magnitude becomes NaN through Inf - Inf in the encoder sums, which depends on the weights' signs.
+    With these weights it always does: every single (bin, frame) set to +Inf alone gives a NaN probability."""
+    sr = SRS[tag]
+    from oracle.oracle import load_weights_blob
+    from oracle.weights import read_container
+    g = golden[tag]
+    w = read_container(load_weights_blob())
+    pre = "_model" if sr == 16000 else "_model_8k"
+    w0, b0 = w[f"{pre}.encoder.0.reparam_conv.weight"], w[f"{pre}.encoder.0.reparam_conv.bias"]     # [128, K, 3]
+    w1, b1 = w[f"{pre}.encoder.1.reparam_conv.weight"], w[f"{pre}.encoder.1.reparam_conv.bias"]     # [64, 128, 3]
+    K = w0.shape[1]
+    mag0 = g["stage_mag"][0]                                            # [K, 4], a real frame set
+    relu = lambda v: np.where(v <= 0, np.float32(0), v)                 # NaN-propagating, like torch.relu
+    with np.errstate(invalid="ignore"):
+        for m in range(4):
+            for k in range(K):
+                mag = np.pad(mag0, ((0, 0), (1, 1)))
+                mag[k, m + 1] = np.inf
+                e0 = relu(b0[:, None] + sum(w0[:, :, t] @ mag[:, t:t + 4] for t in range(3)))           # [128, 4]
+                e0 = np.pad(e0, ((0, 0), (1, 1)))
+                e1 = relu(b1[:, None] + sum(w1[:, :, t] @ e0[:, t:t + 4:2] for t in range(3)))          # [64, 2]
+                # encoder 2 (T 2 -> 1) sums both positions of every channel: one NaN there is NaN everywhere after it
+                assert np.isnan(e1).any(), (m, k)
+    # and end to end through the oracle: a sample of 1e20 anywhere in the chunk
+    n = 512 if sr == 16000 else 256
+    base = g["nf_rows"][0, : n].copy()
+    xs = np.tile(base, (n, 1))
+    xs[np.arange(n), np.arange(n)] = 1e20
+    oracle.reset_states()
+    assert np.isnan(oracle(xs, sr)).all()
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_gain_protocol(oracle, golden, tag):
+    """Quiet speech (gain 0.1 / 0.01): small magnitudes, probabilities in the sigmoid's steep part."""
+    g, sr = golden[tag], SRS[tag]
+    for gt, gain in (("g01", 0.1), ("g001", 0.01)):
+        q = (g["wav"] * np.float32(gain)).astype(np.float32)
+        probs, _, state = oracle.forward_audio(q[None], sr)
+        assert np.abs(probs[0] - g[f"probs_{gt}"]).max() < 5e-5, gt
+        assert state_err(state, g[f"state_{gt}"]) < TOL_STATE, gt
+
+
+def test_decim_and_srswitch(oracle, golden):
+    """test.wav[::2] through the 8 kHz net (examples/onnx_sequence/README.md:61) and calls that alternate between the nets
+    (auto reset, JIT!/vad/model/vad_annotator.py:37-57)."""
+    mz = golden["misc"]
+    dec = np.ascontiguousarray(golden["16k"]["wav"][::2])
+    probs, ctx, state = oracle.forward_audio(dec[None], 8000)
+    assert np.abs(probs[0] - mz["probs_decim"]).max() < TOL_PROB
+    assert state_err(state, mz["state_decim"]) < TOL_STATE and np.array_equal(ctx, mz["ctx_decim"])
+    assert len(kat_segments(probs[0])) == golden["ext"]["decim_16k_to_8k"]["kat_segments_thr05_min8"]
+    oracle.reset_states()
+    cur = {16000: 40 * 512, 8000: 40 * 256}
+    for i, sr in enumerate(int(v) for v in mz["srswitch_plan"]):
+        n = 512 if sr == 16000 else 256
+        wav = golden["16k" if sr == 16000 else "8k"]["wav"]
+        x = np.stack([np.roll(wav, -b * 7919)[cur[sr]: cur[sr] + n] for b in range(4)])
+        cur[sr] += n
+        assert np.abs(oracle(x, sr)[:, 0] - mz["srswitch_probs"][i]).max() < TOL_PROB, i
+    assert state_err(oracle._state, mz["srswitch_state"]) < TOL_STATE
+
+
 def test_edge_cases(oracle):
     # empty batch / empty audio
     p, c, s = oracle.forward_audio(np.zeros((0, 1024), np.float32), 16000)
