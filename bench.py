@@ -22,10 +22,10 @@ The same JSON line also carries, for the record (none of them is the headline `v
   other_configs    8k           configs[2]: 8 kHz, 256-sample chunks, 4096 streams x 256 chunks (the 8 kHz net)            [N = 1]
                    stream       configs[4], KERNEL ONLY: 8192 live streams per GPU (65 536 per 8-GPU node), persistent state in
                                 HBM, one hipGraph-captured vad_step per 32 ms tick from a device-side audio ring           [any N]
-                   stream_host  configs[4] END TO END: int16 chunks in a page-locked ingest ring -> ONE hipGraph per tick (H2D,
-                                fused step, D2H) -> the VADIterator logic of every stream on the host (native) -> events: tick
-                                latency host-to-events, and sustained chunks/s (sub-pools, two ticks in flight) against the int16
-                                PCIe ceiling                                                                               [any N]
+                   stream_host  configs[4] END TO END through the native pump (vad_pump_*, csrc/pump.hip; no Python on the tick path):
+                                a source thread writes every tick's int16 chunks into a page-locked ring slot -> H2D copies and
+                                fused step kernels on two streams ordered by events -> VADIterator logic of every stream -> events:
+                                tick latency (slot written -> events) and sustained chunks/s against the int16 PCIe ceiling    [any N]
                    corpus       configs[3]: every rank runs a FULL per-GPU shard of the 10 000 h corpus (1 250 h =
                                 151 552 ragged recordings, 37 passes of 4096 over fresh offsets) from pinned host
                                 memory -> device batch (no host copy) -> probs -> segmenter on the GPU -> segment
@@ -38,6 +38,7 @@ The same JSON line also carries, for the record (none of them is the headline `v
   roofline         dominant kernel (frontend: STFT + encoder + W_ih GEMM): EXECUTED fp32 MFMA flops per launch /
                    average launch duration (hipEvents recorded by the engine around that kernel on the launch
                    stream during the timed steps) against the dense fp32 MFMA peak; always <= 1
+  legs             LAST key: every leg's value, its fraction of the bound that applies, its own parity figure and max probability
   cpu_baseline     the reference's own ATen CPU operators (oracle/aten_port.py, kind "aten-port") timed on this
                    box's host cores under BASELINE.md section 3 protocols R1-R5 (rank 0, N = 1 only; R5 = get_speech_timestamps
                    on the fixture through the per-chunk protocol, the CPU figure beside `plumbing`)
@@ -291,6 +292,19 @@ def synth_pcm(B, L, sr, dev, seed):
     return pcm
 
 
+def speech_rows(sr, streams, L, dev):
+    """Real speech for the streams a leg checks itself on (the reference's fixtures, tests/golden/audio_*.npz, as float32 / 32768;
+    stream i reads circularly from offset 40 chunks + i * 7919).  Synthetic noise keeps the oracle's probability under 0.05
+    ("a saturated sigmoid that hides error"); timing does not depend on sample values, so the CHECKED
+    streams carry speech and their probabilities span [0, 1]."""
+    import numpy as np
+    import torch
+    pcm = np.load(ROOT / "tests" / "golden" / f"audio_{'16k' if sr == 16000 else '8k'}.npz")["pcm"]
+    n = WORK[sr]["chunk"]
+    idx = (40 * n + np.arange(streams, dtype=np.int64)[:, None] * 7919 + np.arange(L, dtype=np.int64)[None, :]) % len(pcm)
+    return torch.from_numpy(pcm[idx].astype(np.float32) / 32768.0).to(dev)
+
+
 def issue_pipe(w, chunks_per_launch, front_ms_avg):
     """Second reading of the same launch time.  On gfx950 fp32 MFMA and VALU instructions of all waves of a SIMD serialise
     on one issue pipe (profiles/r02d_issue_pipes.md), so the kernel's floor is its MFMA cycles PLUS its VALU cycles; the
@@ -392,6 +406,9 @@ def run_batch(args, sr, rank, world, local, dist, steps, with_other=False):
     n = WORK[sr]["chunk"]
     B, T = args.streams, args.chunks
     pcm = synth_pcm(B, T * n, sr, dev, 17 + sr + rank)
+    sel = list(range(min(16, B))) + list(range(max(16, B - 16), B))          # the streams the leg checks itself on: real speech
+    if not args.no_parity:
+        pcm[torch.tensor(sel, device=dev)] = speech_rows(sr, len(sel), T * n, dev)
     ctx = torch.zeros((B, n // 8), device=dev)
     state = torch.zeros((2, B, 128), device=dev)
     probs = torch.empty((B, T), device=dev)
@@ -405,11 +422,11 @@ def run_batch(args, sr, rank, world, local, dist, steps, with_other=False):
     elapsed, front_ms, rec_ms, ok = time_batch(eng, step, probs, world, dist, dev, steps, args.warmup)
     parity = None
     if not args.no_parity:
-        # self-certification: streams 0..15 and the last 16, all T chunks, of the PCM that was just timed
-        sel = list(range(min(16, B))) + list(range(max(16, B - 16), B))
+        # self-certification: streams 0..15 and the last 16 (speech), all T chunks, of the PCM that was just timed
         idx = torch.tensor(sel, device=dev)
         parity = certify(pcm[idx].cpu().numpy(), probs[idx].cpu().numpy(), state[:, idx].cpu().numpy(), sr,
-                         f"streams 0..15 and {B - 16}..{B - 1} of {B}, all {T} chunks")
+                         f"streams 0..15 and {B - 16}..{B - 1} of {B} (real speech from the reference's fixture; the other streams carry "
+                         f"synthetic noise), all {T} chunks")
     other = None
     if with_other and world == 1:
         # for the record, never the headline: the same workload with the recurrence's W_hh * h as exact bf16 x 9 piece products on
@@ -497,7 +514,10 @@ def run_stream(args, rank, world, local, dist, steps, sr=16000):
     pool = StreamPool(eng, sr, capacity=cap, graph=True)
     pool.open_all()
     ring = 8                                                   # device-side audio source, 8 ticks long
-    src = synth_pcm(cap, ring * n, sr, dev, 23 + rank).view(cap, ring, n).transpose(0, 1).contiguous()
+    flat = synth_pcm(cap, ring * n, sr, dev, 23 + rank)
+    if not args.no_parity:
+        flat[:16] = speech_rows(sr, 16, ring * n, dev)          # the checked streams carry speech
+    src = flat.view(cap, ring, n).transpose(0, 1).contiguous()
     k = [0]
 
     def tick():
@@ -587,112 +607,81 @@ def h2d_rate_GBps(dev, nbytes=256 << 20, reps=5):
 
 
 def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
-    """configs[4] END TO END, the shape of the reference's streaming caller (src/silero_vad/utils_vad.py:507-549: host chunk in,
-    event out): int16 chunks lie in a page-locked ingest ring (what the audio sources write into), ONE hipGraph per ring slot
-    does H2D -> the fused step -> D2H of the probabilities, the host runs the iterator logic of every stream (native
-    vad_iterator_feed) and holds the events.  Two measurements:
-      latency    ONE pool of all `cap` streams, one tick at a time: submit -> probabilities on the host -> events (median / p95)
-      sustained  the same streams as `parts` sub-pools on their own streams (clones of the engine), submitted natively
-                 (vad_step_host), two ticks in flight: one sub-pool's H2D runs beside another's kernel and the host's event pass;
-                 chunks/s against the PCIe ceiling"""
+    """configs[4] END TO END through the native pump (include/silero_vad_hip.h "live streams: the pump", csrc/pump.hip; the shape of
+    the reference's native streaming loop, examples/cpp/silero-vad-onnx.cpp:335-390): NO Python and no torch on the tick path.  Per
+    tick a source thread WRITES the int16 chunks of all streams into a page-locked ring slot (host memory traffic included: this is
+    what an audio server's receive threads do), the server thread submits the tick -- H2D copies on the copy stream, step kernels on
+    the compute stream, ordered by events, probabilities stored by the kernels straight into host memory -- and retires it with the
+    VADIterator logic of every stream (events).  Two measurements, both inside vad_pump_play:
+      latency    one tick at a time (depth 1): slot written -> events on the host, median / p95
+      sustained  ticks in flight (depth 2 and 3, the better one is the value): chunks/s against the int16 PCIe ceiling of this box"""
     import numpy as np
     import torch
-    from silero_vad_amd import BatchVADIterator, Engine, StreamPool
+    from silero_vad_amd import Engine, StreamPump
     dev = torch.device("cuda", local)
     n = WORK[sr]["chunk"]
     cap = args.live
-    R = 8                                                       # ingest ring: 8 ticks of audio per stream
+    R = 4
+    period = 32                                                 # chunks of audio per stream the sources cycle through (268 MB at 16 kHz)
     parts = max(1, int(os.environ.get("VAD_BENCH_STREAM_PARTS", "2")))
-    rows = fixture_rows_i16(sr, cap, R * n)                     # real speech: the iterators do produce events
+    rows = np.ascontiguousarray(fixture_rows_i16(sr, cap, period * n))     # real speech: the iterators do produce events
     eng = Engine(device=local)
+    pump = StreamPump(eng, sr, streams=cap, parts=parts, ring_slots=R)
+    tick0 = [0]
 
-    def make(lo, hi, graph=True):
-        pool = StreamPool(eng.clone(), sr, capacity=hi - lo, graph=graph, dtype=torch.int16, host_slots=R)
-        pool.open_all()
-        ring = pool.host_pcm.numpy()
-        for r in range(R):
-            ring[r][:] = rows[lo:hi, r * n:(r + 1) * n]
-        return pool
+    def play(nt, depth):
+        ev, st = pump.play(rows, nt, first_tick=tick0[0], depth=depth)
+        tick0[0] += nt
+        return st
 
-    # -- latency: one pool, one tick at a time --------------------------------------------------------------------------------
-    whole = make(0, cap)
-    it = BatchVADIterator(cap, sampling_rate=sr)
-    n_events = 0
-    for k in range(300):                                        # warm-up + clock ramp
-        whole.tick_host(k % R)
-    lat, lat_gpu = [], []
-    for k in range(400):
-        t0 = time.perf_counter()
-        p = whole.tick_host(k % R)
-        t1 = time.perf_counter()
-        n_events += len(it.feed(p.numpy()))
-        t2 = time.perf_counter()
-        lat.append((t2 - t0) * 1e3)
-        lat_gpu.append((t1 - t0) * 1e3)
-    lat.sort()
-    lat_gpu.sort()
+    play(600, 2)                                                # warm-up + clock ramp
+    lat = play(400, 1)
+    # how many ticks to keep in flight: tried untimed, the better one is used for the timed region
+    trial = {d: play(300, d) for d in (2, 3)}
+    depth = min(trial, key=lambda d: trial[d]["wall_ms"])
+    runs = {f"depth{d}": {"ticks": 300, "wall_ms": round(st["wall_ms"], 2), "tick_ms_p50": round(st["tick_ms_p50"], 4),
+                          "tick_ms_p95": round(st["tick_ms_p95"], 4)} for d, st in trial.items()}
+    best = {}
+    elapsed = timed(world, dist, dev, 1, lambda: best.update(play(ticks, depth)), gpu_sync)
+    link = h2d_rate_GBps(dev)
     parity = None
     if not args.no_parity:
-        def feed(j):
-            return whole.tick_host(j % R).clone(), rows[:16, (j % R) * n:(j % R + 1) * n].astype(np.float32) / 32768.0
-        parity = certify_pool(whole, feed, 3 * R, sr, f"streams 0..15 of {cap}, {3 * R} ticks of int16 speech from zero state: ingest ring "
-                                                       "-> H2D + step + D2H graph -> host")
-    del whole
-    # -- sustained: sub-pools, two ring slots in flight ------------------------------------------------------------------------
-    cuts = [cap * i // parts for i in range(parts + 1)]
-    # (submitted natively, vad_step_host on each sub-pool's stream: on ROCm 7.2 a hipGraphLaunch of the 4-node tick graph costs ~0.1 ms
-    #  of host time against ~0.03 ms for the same operations issued directly -- tools/stream_host_diag.py; the graph is the latency leg's)
-    pools = [make(cuts[i], cuts[i + 1], graph=False) for i in range(parts)]
-    its = [BatchVADIterator(cuts[i + 1] - cuts[i], sampling_rate=sr) for i in range(parts)]
-    ev_count = [0]
-    state = {"k": 0}
-
-    def run(nt):
-        """nt ticks of all streams; tick k + 1 is submitted before tick k's probabilities are read."""
-        k0 = state["k"]
-        for k in range(k0, k0 + nt + 1):
-            if k < k0 + nt:
-                for q in pools:
-                    q.submit(k % R)
-            if k > k0:
-                for q, qi in zip(pools, its):
-                    ev_count[0] += len(qi.feed(q.wait((k - 1) % R).numpy()))
-        state["k"] = k0 + nt
-
-    run(600)                                                    # warm-up + clock ramp
-    lat_parts = []
-    for _ in range(200):                                        # the sub-pools one tick at a time: part 2's H2D beside part 1's kernel
-        t0 = time.perf_counter()
-        kk = state["k"]
-        for q in pools:
-            q.submit(kk % R)
-        for q, qi in zip(pools, its):
-            qi.feed(q.wait(kk % R).numpy())
-        state["k"] = kk + 1
-        lat_parts.append((time.perf_counter() - t0) * 1e3)
-    lat_parts.sort()
-    ev_count[0] = 0
-    elapsed = timed(world, dist, dev, 1, lambda: run(ticks), gpu_sync)
-    link = h2d_rate_GBps(dev)
+        # streams 0..15 restart from zero state, 24 ticks of the leg's own audio go through the pump; the oracle recomputes them
+        nt = 24
+        for b in range(16):
+            pump.open_stream(b)
+        got = np.zeros((16, nt), np.float32)
+        for t in range(nt):
+            r = t % R
+            pump.slot(r)[:] = rows[:, (t % period) * n:(t % period + 1) * n]
+            pump.submit(r)
+            pump.poll()
+            got[:, t] = pump.probs(r)[:16]
+        st16 = np.stack([np.stack(pump.state(b)[:2]) for b in range(16)], 1)       # [2, 16, 128]
+        parity = certify(rows[:16, :nt * n].astype(np.float32) / 32768.0, got, st16, sr,
+                         f"streams 0..15 of {cap}, {nt} ticks of int16 speech from zero state: ring slot -> pump (copies + kernels by events) -> host")
+    pump.close()
     if rank != 0:
         return None
     value = cap * world * ticks / elapsed
     out = base_line(args, world, sr, value, elapsed, ticks)
     out["ms_per_step"] = round(elapsed / ticks * 1e3, 4)
-    out["config"] = {"workload": f"configs[4] END TO END: {cap} live {sr // 1000} kHz streams/GPU ({cap * 8} per 8-GPU node), int16 chunks in a page-locked "
-                                 f"ingest ring -> ONE hipGraph per tick (H2D, fused vad_step, D2H of the probabilities) -> VADIterator logic of every "
-                                 "stream on the host (vad_iterator_feed) -> events; (h,c)+context persistent in HBM; real-speech fixture audio",
-                     "streams_per_gpu": cap, "sample_rate": sr, "step": "one tick (one chunk per stream)", "sub_pools": parts, "ring_slots": R,
+    out["config"] = {"workload": f"configs[4] END TO END: {cap} live {sr // 1000} kHz streams/GPU ({cap * 8} per 8-GPU node), native pump: a source "
+                                 f"thread writes every tick's int16 chunks into a page-locked ring slot -> H2D ({parts} parts, copy stream) -> fused "
+                                 "vad_step kernels (compute stream, ordered by events; probabilities stored straight into host memory) -> VADIterator "
+                                 "logic of every stream (vad_iterator_feed) -> events; (h,c)+context persistent in HBM; real-speech fixture audio; no "
+                                 "Python on the tick path",
+                     "streams_per_gpu": cap, "sample_rate": sr, "step": "one tick (one chunk per stream)", "parts": parts, "ring_slots": R,
                      "sharding": f"streams x{world}, no collectives"}
-    out["dtype"] = "f32"
+    out["dtype"] = "i16"
     out["realtime_factor"] = round(value * 0.032, 1)
-    out["events_emitted"] = {"latency_pass": n_events, "sustained_pass": ev_count[0]}
-    out["tick_latency_ms"] = {"median": round(lat[len(lat) // 2], 4), "p95": round(lat[int(len(lat) * 0.95)], 4),
-                              "to_probabilities_on_host_median": round(lat_gpu[len(lat_gpu) // 2], 4), "budget_ms": 32.0,
-                              "what": "ONE pool of all streams, one tick at a time: submit(ONE hipGraph: H2D -> step -> D2H) -> wait -> events",
-                              "as_sub_pools_median": round(lat_parts[len(lat_parts) // 2], 4),
-                              "as_sub_pools_what": f"the same tick as {parts} sub-pools submitted natively on their own streams (one sub-pool's "
-                                                   "H2D beside another's kernel), one tick at a time, to events"}
+    out["events_emitted"] = {"latency_pass": lat["events"], "sustained_pass": best["events"]}
+    out["tick_latency_ms"] = {"median": round(lat["tick_ms_p50"], 4), "p95": round(lat["tick_ms_p95"], 4), "max": round(lat["tick_ms_max"], 4),
+                              "budget_ms": 32.0, "what": "one tick at a time (depth 1): ring slot completely written -> its events on the host"}
+    out["sustained"] = {"depth": best["depth"], "fill_threads": best["fill_threads"], "tick_ms_p50": round(best["tick_ms_p50"], 4),
+                        "tick_ms_p95": round(best["tick_ms_p95"], 4), "host_ms_per_tick": {"source_writes_slot": round(best["fill_ms_mean"], 4),
+                        "submit": round(best["submit_ms_mean"], 4), "blocked_in_poll": round(best["wait_ms_mean"], 4)}, "untimed_depth_trials": runs,
+                        "native_wall_s": round(best["wall_ms"] / 1e3, 4)}
     ceiling = link * 1e9 / (n * 2) * world
     out["pcie"] = {"h2d_GBps_plain_copy": round(link, 2), "int16_ceiling_chunks_per_s": round(ceiling, 1),
                    "fraction_of_pcie_ceiling": round(value / ceiling, 3),
@@ -1010,15 +999,53 @@ def small(d):
         return None
     keep = ("value", "unit", "steps", "ms_per_step", "dtype", "kernel_ms", "tick_latency_ms", "legs", "wall_s", "n_gpus",
             "audio_hours_all_gpus", "ten_k_hours_at_this_rate_s", "parity_sample", "parity_sample_max_abs_dp",
-            "outputs_finite", "realtime_factor", "timed_region_s", "parity", "parity_max_abs_dp", "pcie", "events_emitted")
+            "outputs_finite", "realtime_factor", "timed_region_s", "parity", "parity_max_abs_dp", "pcie", "events_emitted", "sustained")
     out = {k: d[k] for k in keep if k in d}
     out["workload"] = d["config"]["workload"]
-    for k in ("sharding", "host_threads_per_rank", "numa_node_bound", "recordings_per_gpu", "audio_hours_per_gpu", "sub_pools", "ring_slots"):
+    for k in ("sharding", "host_threads_per_rank", "numa_node_bound", "recordings_per_gpu", "audio_hours_per_gpu", "parts", "ring_slots"):
         if k in d["config"]:
             out[k] = d["config"][k]
     if "roofline" in d:
         out["roofline"] = {k: d["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
     return out
+
+
+def compact_legs(out):
+    """Every leg of the line in one small object that is printed LAST (a reader that keeps only the tail of the line still sees all
+    of them): value in chunks/s, its fraction of what bounds it (fp32 MFMA peak for the kernels, this box's int16 PCIe ceiling for
+    the host-fed legs), the leg's own parity check (max |dp| against the oracle on the leg's own audio, and the largest probability
+    among the checked chunks: a check on probabilities that never leave 0 proves little)."""
+    def one(d):
+        if not isinstance(d, dict):
+            return None
+        if "error" in d:
+            return {"error": d["error"][:80]}
+        e = {"value": d.get("value")}
+        if isinstance(d.get("roofline"), dict) and "frac" in d["roofline"]:
+            e["of_mfma_peak"] = d["roofline"]["frac"]
+        if isinstance(d.get("pcie"), dict):
+            e["of_link"] = d["pcie"].get("fraction_of_pcie_ceiling")
+        if isinstance(d.get("tick_latency_ms"), dict):
+            e["tick_ms_p95"] = d["tick_latency_ms"].get("p95")
+        par = d.get("parity")
+        if isinstance(par, dict):
+            e["dp"] = float(f"{par.get('parity_max_abs_dp', 0):.2e}")
+            e["max_prob"] = par.get("max_prob")
+        elif "parity_sample_max_abs_dp" in d:
+            e["dp"] = float(f"{d['parity_sample_max_abs_dp']:.2e}")
+        return e
+    legs = {"c2": one(out)}
+    for name, d in (out.get("other_configs") or {}).items():
+        if name.startswith("plumbing"):
+            pc = (d or {}).get("per_call_latency_ms") or {}
+            legs[name] = {"call_ms": pc.get("eager_model_call_item"), "identical_segments": next((v.get("identical_segments") for k, v in (d or {}).items()
+                                                                                                    if k.startswith("get_speech_timestamps")), None)}
+            continue
+        legs[name] = one(d)
+        if name == "corpus" and isinstance(d, dict) and isinstance(d.get("legs"), dict):
+            legs[name]["of_link"] = d["legs"].get("main", {}).get("fraction_of_pcie_ceiling")
+            legs[name]["routes_of_link"] = {k: v.get("fraction_of_pcie_ceiling") for k, v in d["legs"].items() if k != "main"}
+    return legs
 
 
 def main():
@@ -1127,6 +1154,8 @@ def main():
             out["cpu_baseline"] = cpu
         if os.environ.get("VAD_BENCH_SHARE_GPU") and world > 1:
             out["data"] = "synthetic; FUNCTIONAL run of the multi-rank legs with all ranks on ONE GPU (gloo) -- not a measurement"
+        if not args.dry and args.config == "c2" and "legs" not in out:
+            out["legs"] = compact_legs(out)             # LAST key of the line
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

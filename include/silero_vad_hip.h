@@ -129,6 +129,14 @@ int  vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ct
 int  vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, void *dev_pcm, float *ctx, float *state,
                    float *dev_prob, float *host_prob, void *stream);
 
+/* vad_step with the two contexts apart and either PCM type, all on the device: reads ctx_in, writes the next context to ctx_out
+ * (a second buffer: the kernel may not write where other waves still read), so that a caller that alternates two context buffers
+ * pays no device-to-device copy per step.  The functional form once more -- the ONNX graph's inputs and outputs are distinct
+ * tensors too (src/silero_vad/utils_vad.py:80-83: `state` in, `stateN` out).
+ *   pcm  dev [B][N], elem_size 2 = int16 (scaled by 1/32768 in the kernel's loads) | 4 = fp32, row stride `ld` elements      */
+int  vad_step_split(vad_engine *e, int sr, int B, const void *pcm, size_t elem_size, long ld, const float *ctx_in, float *ctx_out,
+                    float *state, float *prob, void *stream);
+
 /* T = ceil(L / N) lock-step steps for B streams: VADRNNJITMerge.audio_forward
  * (JIT!/vad/model/vad_annotator.py:128-156; ONNX twin utils_vad.py:94-110) with the carried
  * state made explicit (pass zeroed ctx/state for the reference's reset-then-run behaviour).
@@ -225,6 +233,72 @@ typedef struct vad_iter_event { int32_t slot; int32_t kind; int64_t sample; } va
 long vad_iterator_feed(const float *probs, const uint8_t *active, long n, int window, double threshold,
                        double min_silence_samples, double speech_pad_samples, uint8_t *triggered,
                        int64_t *temp_end, int64_t *current_sample, vad_iter_event *out, long cap);
+
+/* ---- live streams: the pump --------------------------------------------------------------------------------------------
+ * BASELINE configs[4] as one native object: `streams` live streams on one GPU advance in lock step, one tick = one 32 ms chunk of
+ * every stream, host int16 audio in, VADIterator events out -- the loop the reference's native streaming clients run around
+ * their runtime, one session.run per chunk with explicit state and the iterator logic inline
+ * (examples/cpp/silero-vad-onnx.cpp:335-390; Python: src/silero_vad/utils_vad.py:507-549 VADIterator.__call__), for thousands of
+ * streams at once.  The pump owns: a page-locked ingest ring [ring_slots][streams][N] int16 that the audio sources write
+ * into, the device batch (double-buffered), the carried (h, c) and context of every stream in HBM, the iterator state of every
+ * stream, two HIP streams (copies / kernels) and the events that order them (csrc/pump.hip has the schedule: part k + 1's H2D
+ * runs beside part k's kernel BY EVENT, tick t + 1's copies behind tick t's, nothing left to hardware-queue assignment).
+ * One caller thread drives submit / poll; any thread may write a ring slot that is not in flight.                          */
+typedef struct vad_pump vad_pump;
+typedef struct vad_pump_params {
+    int    sampling_rate;            /* 8000 | 16000                                                                         */
+    int    streams;                  /* live streams (slots) on this GPU                                                     */
+    int    parts;                    /* sub-batches per tick (<= 0: 2)                                                       */
+    int    ring_slots;               /* ticks of audio the ingest ring holds (<= 0: 4; at least 2)                           */
+    double threshold;                /* VADIterator arguments and defaults (utils_vad.py:477-498): 0.5                       */
+    int    min_silence_duration_ms;  /* 100                                                                                  */
+    int    speech_pad_ms;            /* 30                                                                                   */
+} vad_pump_params;
+typedef struct vad_pump_stats {
+    long   ticks, events;
+    double wall_ms;
+    double tick_ms_p50, tick_ms_p95, tick_ms_max;     /* slot written -> its events on the host, per tick                    */
+    double fill_ms_mean, submit_ms_mean, wait_ms_mean;/* host time per tick: writing the slot, issuing the tick, blocked     */
+    int    fill_threads, depth;
+} vad_pump_stats;
+enum { VAD_PUMP_IDLE = -1,   /* vad_pump_poll: nothing submitted                                                             */
+       VAD_PUMP_BUSY = -2,   /* vad_pump_poll(block = 0): the oldest tick has not finished                                   */
+       VAD_PUMP_ERROR = -3 };/* see vad_pump_last_error                                                                      */
+
+void vad_pump_params_default(vad_pump_params *p, int sampling_rate, int streams);
+/* The pump works on a clone of `e` (vad_clone): the caller's engine stays free for other calls.  Every stream starts open, from
+ * zero state (VADIterator.reset_states, utils_vad.py:500-505).                                                             */
+int  vad_pump_create(vad_engine *e, const vad_pump_params *p, vad_pump **out);
+void vad_pump_destroy(vad_pump *p);
+const char *vad_pump_last_error(const vad_pump *p);
+int  vad_pump_geometry(const vad_pump *p, int *streams, int *chunk, int *ring_slots, int *parts);
+/* Ring slot r: [streams][N] int16, page-locked; the sources write stream b's next chunk at slot + b * N.                   */
+int16_t *vad_pump_slot(vad_pump *p, int r);
+/* Start one tick over ring slot r: asynchronous (copies and kernels are queued; returns at once).  VAD_ERR_ARG while the slot's
+ * previous tick is in flight.  Ticks execute in submission order.                                                          */
+int  vad_pump_submit(vad_pump *p, int r);
+/* Retire the OLDEST submitted tick: wait for it (block != 0) or return VAD_PUMP_BUSY, run the iterator logic of every open
+ * stream over its probabilities and write the tick's events (stream order; at most `cap`, the return value is how many there
+ * were, <= streams).  *slot = the ring slot that is free again.  The probabilities stay readable in vad_pump_probs(p, slot)
+ * until that slot's next tick.                                                                                             */
+long vad_pump_poll(vad_pump *p, int block, vad_iter_event *out, long cap, int *slot);
+const float *vad_pump_probs(const vad_pump *p, int r);   /* [streams] */
+/* A new stream takes slot `stream`: zero (h, c), context and iterator state, ordered behind the ticks already submitted
+ * (reset_states, JIT!/vad/model/vad_annotator.py:157-162 + utils_vad.py:500-505).  close: the slot is still computed (lock-step
+ * batch) but emits no events.                                                                                              */
+int  vad_pump_open(vad_pump *p, int stream);
+int  vad_pump_close(vad_pump *p, int stream);
+/* Test / migration hook: copy stream's carried h[128], c[128], ctx[C] to the host (any may be NULL).  Synchronises.        */
+int  vad_pump_state(vad_pump *p, int stream, float *h, float *c, float *ctx);
+/* The whole loop in one native call -- for tests, benchmarks and file-fed servers: stream b plays rows[b * ld ...] circularly with
+ * period `period` samples (a multiple of N): at tick t its chunk is rows[b * ld + (t * N) % period ...].  For t = first_tick ...
+ * first_tick + n_ticks - 1: a source thread WRITES the chunks into ring slot t % ring_slots as soon as that slot is free (split
+ * over `fill_threads` host threads, <= 0: vad_host_threads() - 1; what the receive threads of an audio server would do), the
+ * calling thread submits the tick once it is written, and once `depth` ticks are in flight (clamped to 1 ... ring_slots - 1;
+ * 1 = one tick at a time) retires the oldest.  All events are appended to `out` (at most cap; the return value is their
+ * number) and `st` (may be NULL) is filled in.                                                                              */
+long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long first_tick, long n_ticks, int depth, int fill_threads,
+                   vad_iter_event *out, long cap, vad_pump_stats *st);
 
 /* ---- host-side ingest ---------------------------------------------------------------------------------
  * Pack n recordings of different lengths (lens[i] samples of elem_size 2 = int16 or 4 = float32 at

@@ -37,6 +37,17 @@ class IterEvent(Structure):
     _fields_ = [("slot", ctypes.c_int32), ("kind", ctypes.c_int32), ("sample", c_int64)]
 
 
+class PumpParams(Structure):
+    _fields_ = [("sampling_rate", c_int), ("streams", c_int), ("parts", c_int), ("ring_slots", c_int), ("threshold", c_double),
+                ("min_silence_duration_ms", c_int), ("speech_pad_ms", c_int)]
+
+
+class PumpStats(Structure):
+    _fields_ = [("ticks", c_long), ("events", c_long), ("wall_ms", c_double), ("tick_ms_p50", c_double), ("tick_ms_p95", c_double),
+                ("tick_ms_max", c_double), ("fill_ms_mean", c_double), ("submit_ms_mean", c_double), ("wait_ms_mean", c_double),
+                ("fill_threads", c_int), ("depth", c_int)]
+
+
 # every symbol include/silero_vad_hip.h declares: name -> (restype, argtypes)
 f32p, i16p = POINTER(c_float), POINTER(c_int16)
 SYMBOLS = {
@@ -50,6 +61,20 @@ SYMBOLS = {
     "vad_set_option": (c_int, [c_void_p, c_char_p, c_char_p]),
     "vad_step": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vad_step_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vad_step_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vad_pump_params_default": (None, [POINTER(PumpParams), c_int, c_int]),
+    "vad_pump_create": (c_int, [c_void_p, POINTER(PumpParams), POINTER(c_void_p)]),
+    "vad_pump_destroy": (None, [c_void_p]),
+    "vad_pump_last_error": (c_char_p, [c_void_p]),
+    "vad_pump_geometry": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "vad_pump_slot": (c_void_p, [c_void_p, c_int]),
+    "vad_pump_submit": (c_int, [c_void_p, c_int]),
+    "vad_pump_poll": (c_long, [c_void_p, c_int, c_void_p, c_long, POINTER(c_int)]),
+    "vad_pump_probs": (c_void_p, [c_void_p, c_int]),
+    "vad_pump_open": (c_int, [c_void_p, c_int]),
+    "vad_pump_close": (c_int, [c_void_p, c_int]),
+    "vad_pump_state": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "vad_pump_play": (c_long, [c_void_p, c_void_p, c_long, c_long, c_long, c_long, c_int, c_int, c_void_p, c_long, POINTER(PumpStats)]),
     "vad_forward_audio": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                   c_void_p, c_long, c_void_p]),
     "vad_forward_audio_i16": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_void_p,

@@ -18,4 +18,15 @@ __device__ __forceinline__ float tanh_f(float x) {
     return fmaf(2.0f, sigmoid_f(2.0f * x), -1.0f);
 }
 
+// The head's ReLU.  torch.relu is clamp_min(0) and PROPAGATES NaN (v_max_f32 / fmaxf would return the other operand): a stream
+// whose carried (h, c) is NaN -- one NaN / Inf sample is enough, see fft_wave.hpp "non-finite input" -- must read NaN until it is
+// reset, exactly as the reference does (JIT!/torch/nn/modules/container/___torch_mangle_7.py:10-19; goldens: tests/golden/
+// make_golden.py protocol "nonfinite").
+//   relu_f:  the plain form (compare + select).
+//   relu2_f: 2 * relu(x) = x + |x| -- ONE v_add_f32 (the |.| is a source modifier), the price of the v_max_f32 it replaces, NaN in ->
+// NaN out; x + |x| is exactly 2x for x > 0 and exactly +0 otherwise.  The recurrent kernels use it with HALVED head weights:
+// fmaf(0.5 w, 2 relu(h), acc) has the same product and therefore the same bits as fmaf(w, relu(h), acc) (scaling by two is exact).
+__device__ __forceinline__ float relu_f(float x) { return x <= 0.0f ? 0.0f : x; }
+__device__ __forceinline__ float relu2_f(float x) { return x + __builtin_fabsf(x); }
+
 }  // namespace vad

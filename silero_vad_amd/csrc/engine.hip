@@ -198,7 +198,7 @@ int grow(vad_engine *e, void **buf, size_t *have, size_t need, hipStream_t strea
 // folded into the load; fp32 frontend).
 template <typename PcmT>
 int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm, long ld, float *ctx,
-                 float *state, float *probs, long ldp, hipStream_t stream) {
+                 float *state, float *probs, long ldp, hipStream_t stream, float *ctx_next = nullptr) {
     const int ni = net_index(sr);
     const int N = sr == 16000 ? 512 : 256, C = N / 8;
     const long Ld = (L + dec - 1) / dec;                 // samples per row at the net's rate
@@ -249,7 +249,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         fa.tail = tail;
         fa.ld = ld; fa.L = Ld; fa.T = T; fa.t0 = t0; fa.nt = nt;
         fa.ctx_in = ctx;
-        fa.ctx_out = e->d_ctx_new;
+        fa.ctx_out = ctx_next ? ctx_next : e->d_ctx_new;     // (the kernel may not write where other waves of the tile still read)
         fa.gx = e->d_gx;
         fa.B = B;
         fa.dec = dec;
@@ -308,7 +308,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         } else HIP_TRY(e, vad::launch_rec(sr, ra, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[2], stream));
     }
-    HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (!ctx_next) HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return VAD_OK;
 }
 
@@ -593,6 +593,25 @@ int vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ctx
              float *prob, void *stream) {
     const int N = (sr > 16000 && sr % 16000 == 0) ? 512 * (sr / 16000) : sr == 16000 ? 512 : 256;
     return forward_impl<float>(e, sr, B, N, pcm, ld, ctx, state, prob, 1, stream);
+}
+
+int vad_step_split(vad_engine *e, int sr, int B, const void *pcm, size_t elem_size, long ld, const float *ctx_in, float *ctx_out,
+                   float *state, float *prob, void *stream) {
+    if (!e) return VAD_ERR_ARG;
+    if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    const int ni = net_index(sr);
+    if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000]");
+    const int N = sr == 16000 ? 512 : 256;
+    if (B < 0 || (elem_size != 2 && elem_size != 4) || ld < N || (B > 0 && (!pcm || !ctx_in || !ctx_out || !state || !prob)))
+        return fail(e, VAD_ERR_ARG, "bad argument");
+    if (ctx_in == ctx_out || ((size_t)ctx_out & 15)) return fail(e, VAD_ERR_ARG, "vad_step_split: ctx_out must be a second, 16-byte aligned buffer");
+    if (e->impl_reference) return fail(e, VAD_ERR_OPTION, "vad_step_split: impl=reference has no split-context form");
+    if (B == 0) return VAD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    float *ci = const_cast<float *>(ctx_in);
+    return elem_size == 2
+        ? forward_core<int16_t>(e, sr, 1, B, N, static_cast<const int16_t *>(pcm), ld, ci, state, prob, 1, (hipStream_t)stream, ctx_out)
+        : forward_core<float>(e, sr, 1, B, N, static_cast<const float *>(pcm), ld, ci, state, prob, 1, (hipStream_t)stream, ctx_out);
 }
 
 int vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, void *dev_pcm, float *ctx, float *state,

@@ -384,6 +384,40 @@ __device__ __forceinline__ void fft_math(float (&X)[Q + 1], const float (&s)[2 *
     X[Q] = ln.g == 0 ? fabsf(z[0].x - z[0].y) : 0.f;           // Nyquist: Re Z0 - Im Z0
 }
 
+// ---- non-finite input -------------------------------------------------------------------------------------------------------
+// The reference propagates NaN: torch.relu is clamp_min(0), aten::lstm_cell is plain arithmetic, so ONE NaN or Inf sample (or a
+// finite one so large that |Y|^2 overflows) makes the chunk's probability NaN and leaves NaN in the carried (h, c), i.e. in
+// every later chunk of that stream until reset_states() (JIT!/vad/utils/model_utils.py:19-25, JIT!/torch/nn/modules/rnn.py:69;
+// recorded from the reference: tests/golden/make_golden.py protocol "nonfinite").  The ReLUs here are v_max_f32, which returns
+// the operand that is NOT NaN, so the frontends carry the fact explicitly: RULE -- a chunk with ANY non-finite STFT magnitude
+// is NaN.  (A NaN / Inf sample makes every bin of its frame non-finite, in the DFT as in the FFT.  An Inf magnitude alone --
+// overflow -- reaches NaN in the reference through Inf - Inf in the encoder sums, which formally depends on the weights' signs;
+// with these weights it always does: tests/test_oracle.py::test_any_single_overflowing_bin_is_nan.)
+//   poison_acc: p stays +0 while every value is finite, becomes NaN at the first one that is not (x * 0 is NaN for NaN and
+// +-Inf, +-0 otherwise; +-0 + +0 = +0).  One VALU instruction per value, two independent chains.  E = x3 - x1 and F = x2 - x0 are
+// non-finite whenever one of their frames is, so the kernels feed it the 2 Q transformed values instead of the 4 Q magnitudes.
+//   poison_into: ORs p's bits into ONE B operand of the W_ih GEMM, behind the last ReLU.  +0 changes nothing (bit-identical
+// results for clean chunks); NaN in B[k][j] makes column j -- this chunk, and only this chunk -- NaN in all 512 rows of gx.  From
+// there the recurrence carries it in (h, c) by itself; its head uses relu_f (activations.hpp).
+template <int Q>
+__device__ __forceinline__ void poison_acc(float &p0, float &p1, const float (&X)[Q + 1]) {
+#pragma unroll
+    for (int k = 0; k < Q; k += 2) {
+        p0 = fmaf(X[k], 0.f, p0);
+        p1 = fmaf(X[k + 1], 0.f, p1);
+    }
+}
+__device__ __forceinline__ float poison_nyq(float p0, float p1, float xn0, float xn1, float xn2, float xn3) {
+    p0 = fmaf(xn0, 0.f, p0);
+    p1 = fmaf(xn1, 0.f, p1);
+    p0 = fmaf(xn2, 0.f, p0);
+    p1 = fmaf(xn3, 0.f, p1);
+    return p0 + p1;
+}
+__device__ __forceinline__ void poison_into(f32x4 &v, float p) {
+    v[0] = __uint_as_float(__float_as_uint(v[0]) | __float_as_uint(p));
+}
+
 template <int Q, int V, typename PcmT, int DEC = 1>
 __device__ __forceinline__ void fft_pass(float (&X)[Q + 1], const FrontArgs &a, const float *tab_lds, const Lane &ln) {
     fft_frame<Q, PcmT, DEC>(X, V, a, tab_lds, ln);

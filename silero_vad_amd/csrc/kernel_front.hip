@@ -396,11 +396,22 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
 
     float X0[Q + 1], X1[Q + 1], X2[Q + 1], X3[Q + 1];
     TRACE(1);
+    // non-finite input: fft_wave.hpp poison_acc (all four frames, raw).  This form has no register to spare: the running value
+    // lives in the thread's own LDS word between the passes (same thread reads and writes it: no barrier)
+    __shared__ float pz_lds[256];
+    auto pz_add = [&](const float (&X)[Q + 1], bool first) {
+        float p = first ? 0.f : pz_lds[threadIdx.x];
+        poison_acc<Q>(p, p, X);
+        pz_lds[threadIdx.x] = fmaf(X[Q], 0.f, p);            // (the Nyquist magnitude: lane group 0; B[k][j] of that lane is enough)
+    };
     fft_pass<Q, 0, PcmT, DEC>(X0, a, tab, ln);
+    pz_add(X0, true);
     TRACE(2);
     fft_pass<Q, 1, PcmT, DEC>(X1, a, tab, ln);
+    pz_add(X1, false);
     TRACE(3);
     fft_pass<Q, 2, PcmT, DEC>(X2, a, tab, ln);
+    pz_add(X2, false);
     TRACE(4);
 
     auto bX0 = [&](int s) { return X0[s]; };
@@ -447,6 +458,7 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
     ring.last = 0;
 #endif
     fft_pass<Q, 3, PcmT, DEC>(X3, a, tab, ln);
+    pz_add(X3, false);
     TRACE(6);
 
     // enc0 frame 2 -> enc1 out 1 tap 1
@@ -489,6 +501,7 @@ __global__ void __launch_bounds__(256, Q == 16 ? VAD_WG_PER_CU_8K : 2) front_ker
     init_bias<8>(Fe, tab + tb.b_e3, ln);
     gemm_seg<8, 16, FB_IH, true, true>(Fe, bV, ring, o_e3t1, seg_offset(IH0, Q), ln);
     relu<8>(Fe);
+    poison_into(Fe[0], pz_lds[threadIdx.x]);
     TRACE(8);
 
     // LSTM input-gate pre-activations, one gate (8 row blocks) at a time, stored in D-fragment order

@@ -292,6 +292,12 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) front_b9_kernel(const
         X3[k] = X3[k] - X1[k];
         X0[k] = X2[k] - X0[k];
     }
+    float poison;
+    {   float p0 = 0.f, p1 = 0.f;                         // non-finite input: fft_wave.hpp poison_acc
+        poison_acc<Q>(p0, p1, X3);
+        poison_acc<Q>(p0, p1, X0);
+        poison = poison_nyq(p0, p1, xn0, xn1, xn2, xn3);
+    }
     ring.c0 = lds4u(ring.a_cur);
     ring.c1 = lds4u(ring.a_cur + 1024);
 
@@ -399,6 +405,7 @@ __global__ void __launch_bounds__(64 * kWaves, 8 / kWaves) front_b9_kernel(const
     init_bias<8>(Fe, tab + tb.b_e3, ln);
     gemm_b<8, 4, 2>(Fe, bV, ring);
     relu<8>(Fe);
+    poison_into(Fe[0], poison);
     B9_TRACE(4);
 
     // LSTM input-gate pre-activations, one gate (8 row blocks) at a time, stored in D-fragment order: gates 0..2 share a

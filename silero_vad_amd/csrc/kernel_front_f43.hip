@@ -250,6 +250,21 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
         X3[k] = X3[k] - X1[k];
         X0[k] = X2[k] - X0[k];
     }
+    float poison;
+    {   float p0 = 0.f, p1 = 0.f;                         // non-finite input: fft_wave.hpp poison_acc
+        poison_acc<Q>(p0, p1, X3);
+        poison_acc<Q>(p0, p1, X0);
+        poison = poison_nyq(p0, p1, xn0, xn1, xn2, xn3);
+    }
+#else
+    float poison;
+    {   float p0 = 0.f, p1 = 0.f;
+        poison_acc<Q>(p0, p1, X0);
+        poison_acc<Q>(p0, p1, X1);
+        poison_acc<Q>(p0, p1, X2);
+        poison_acc<Q>(p0, p1, X3);
+        poison = poison_nyq(p0, p1, xn0, xn1, xn2, xn3);
+    }
 #endif
     ring.c0 = lds4(ring.a_cur);
     ring.c1 = lds4(ring.a_cur + 1024);
@@ -375,6 +390,7 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     init_bias<8>(Fe, tab + tb.b_e3, ln);
     gemm_r<8, 4, 2>(Fe, bV, ring);
     relu<8>(Fe);
+    poison_into(Fe[0], poison);
     VAD_WAVE_STAMP(ln, 11);
 
     // LSTM input-gate pre-activations, one gate (8 row blocks) at a time, stored in D-fragment order: gates 0..2 share a

@@ -239,6 +239,12 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
         X3[k] = X3[k] - X1[k];
         X0[k] = X2[k] - X0[k];
     }
+    float poison;
+    {   float p0 = 0.f, p1 = 0.f;                         // non-finite input: fft_wave.hpp poison_acc (every wave holds all four frames)
+        poison_acc<Q>(p0, p1, X3);
+        poison_acc<Q>(p0, p1, X0);
+        poison = poison_nyq(p0, p1, xn0, xn1, xn2, xn3);
+    }
 
     // ---- encoder 0, this wave's 32 rows: one F(4,3) tile (kernel_front_f43.hip has the algebra) -------------------------------
     {
@@ -363,6 +369,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     f32x4 Fe[8], G[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) Fe[m] = *reinterpret_cast<const f32x4 *>(&febuf[m][ln.lane * 4]);
+    poison_into(Fe[0], poison);
     init_bias<8>(G, tab + tb.b_g + 128 * w, ln);
     run_segment<S_IH, 64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
                              [&](auto kg) VAD_INLINE { return Fe[IC(kg)]; }, gload);
@@ -393,7 +400,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
             const f32x4 go = *reinterpret_cast<const f32x4 *>(&gbuf[3][rb][ln.lane * 4]);
             const size_t soff = (size_t)ln.b * 128 + 16 * rb + 4 * ln.g;
             f32x4 c = *reinterpret_cast<const f32x4 *>(cell.state + (size_t)a.B * 128 + soff);
-            const f32x4 wo = *reinterpret_cast<const f32x4 *>(tab + tb.w_out + 16 * rb + 4 * ln.g);
+            const f32x4 wo = 0.5f * *reinterpret_cast<const f32x4 *>(tab + tb.w_out + 16 * rb + 4 * ln.g);   // halved: relu2_f (activations.hpp)
             f32x4 h;
             float part = 0.f;
 #pragma unroll
@@ -402,7 +409,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
                 const float cn = fmaf(fg, c[r], ig * gt);
                 c[r] = cn;
                 h[r] = sigmoid_f(go[r]) * tanh_f(cn);
-                part = fmaf(wo[r], fmaxf(h[r], 0.f), part);
+                part = fmaf(wo[r], relu2_f(h[r]), part);
             }
             part += __shfl_xor(part, 16);
             part += __shfl_xor(part, 32);

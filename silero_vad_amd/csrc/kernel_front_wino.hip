@@ -237,9 +237,20 @@ __global__ void __launch_bounds__(256, 2) front_wino_kernel(const FrontArgs a) {
     __syncthreads();
 
     float X0[Q + 1], X1[Q + 1], X2[Q + 1], X3[Q + 1];
+    // non-finite input: fft_wave.hpp poison_acc (all four frames, raw).  No register to spare here either: the running value lives in the
+    // thread's own LDS word between the passes (same thread reads and writes it: no barrier)
+    __shared__ float pz_lds[256];
+    auto pz_add = [&](const float (&X)[Q + 1], bool first) VAD_INLINE {
+        float p = first ? 0.f : pz_lds[threadIdx.x];
+        poison_acc<Q>(p, p, X);
+        pz_lds[threadIdx.x] = fmaf(X[Q], 0.f, p);            // (the Nyquist magnitude: lane group 0; B[k][j] of that lane is enough)
+    };
     fft_pass<Q, 0, PcmT, DEC>(X0, a, tab, ln);
     fft_pass<Q, 1, PcmT, DEC>(X1, a, tab, ln);
     fft_pass<Q, 2, PcmT, DEC>(X2, a, tab, ln);
+    pz_add(X0, true);
+    pz_add(X1, false);
+    pz_add(X2, false);
 
     const float *wn = tab + tb.w_nyq;                  // [tap][row]
     // |Y_nyq| of chunk j lives in lane group 0 (X[Q]); every lane of the chunk needs it
@@ -288,6 +299,7 @@ __global__ void __launch_bounds__(256, 2) front_wino_kernel(const FrontArgs a) {
     });
 
     fft_pass<Q, 3, PcmT, DEC>(X3, a, tab, ln);
+    pz_add(X3, false);
 
     // ---- frame pair (2, 3): d = (x1, x2, x3, 0) -> y2 (enc1 out 1 tap 1), y3 (out 1 tap 2) ---------------------------
     static_for<0, 2>([&](auto hc) VAD_INLINE {
@@ -343,6 +355,7 @@ __global__ void __launch_bounds__(256, 2) front_wino_kernel(const FrontArgs a) {
     init_bias<8>(Fe, tab + tb.b_e3, ln);
     gemm_w<Q, T0 + 2, 8, 4, true, true>(Fe, bV, ring, ln);
     relu<8>(Fe);
+    poison_into(Fe[0], pz_lds[threadIdx.x]);
 
     // LSTM input-gate pre-activations, one gate (8 row blocks) at a time, stored in D-fragment order
     float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32) * 256 + ln.lane * 4;

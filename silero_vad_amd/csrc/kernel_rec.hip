@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) A[q][kg] = src[(q * 8 + kg) * 64];
     }
-    const f32x4 wo = *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * w + 4 * g);
+    const f32x4 wo = 0.5f * *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * w + 4 * g);   // halved: relu2_f (activations.hpp)
     const float bo = a.tables[NTAB_BOUT];
 
     // state: lane (g, j) holds units 16w + 4g + r of stream j
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             h[r] = sigmoid_f(acc[3][r]) * th[r];
-            part = fmaf(wo[r], fmaxf(h[r], 0.f), part);
+            part = fmaf(wo[r], relu2_f(h[r]), part);
         }
 #else
 #pragma unroll
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
             const float cn = fmaf(fg, c[r], ig * gg);
             c[r] = cn;
             h[r] = og * tanh_f(cn);
-            part = fmaf(wo[r], fmaxf(h[r], 0.f), part);
+            part = fmaf(wo[r], relu2_f(h[r]), part);
         }
 #endif
         part += __shfl_xor(part, 16);
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(512, 2) rec_skew_kernel(const RecArgs a) {
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) A[q][kg] = src[(q * 8 + kg) * 64];
     }
-    const f32x4 wo = *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * w + 4 * g);
+    const f32x4 wo = 0.5f * *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * w + 4 * g);   // halved: relu2_f (activations.hpp)
     const float bo = a.tables[NTAB_BOUT];
 
     const size_t soff = (size_t)bc * 128 + 16 * w + 4 * g;
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(512, 2) rec_skew_kernel(const RecArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             h[r] = sigmoid_f(acc[3][r]) * th[r];
-            part = fmaf(wo[r], fmaxf(h[r], 0.f), part);
+            part = fmaf(wo[r], relu2_f(h[r]), part);
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(512, 1) rec_b9_kernel(const RecArgs a) {
             A1[q][u] = img[(1 * 16 + q * 4 + u) * 64];
             *reinterpret_cast<u32x4 *>(&w2s[(((w * 4 + q) * 4 + u) * 64 + lane) * 4]) = img[(2 * 16 + q * 4 + u) * 64];
         }
-    const f32x4 wo = *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * w + 4 * g);
+    const f32x4 wo = 0.5f * *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * w + 4 * g);   // halved: relu2_f (activations.hpp)
     const float bo = a.tables[NTAB_BOUT];
 
     // state: lane (g, j) holds units 16w + 4g + r of stream j (the D layout of this wave's gate rows)
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(512, 1) rec_b9_kernel(const RecArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             h[r] = sigmoid_f(acc[3][r]) * th[r];
-            part = fmaf(wo[r], fmaxf(h[r], 0.f), part);
+            part = fmaf(wo[r], relu2_f(h[r]), part);
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);

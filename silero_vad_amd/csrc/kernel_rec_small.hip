@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(512, 1) rec_small_kernel(const RecArgs a) {
         soff = (size_t)pb * 128 + 16 * pw + 4 * pg;
         h = *reinterpret_cast<const f32x4 *>(a.state + soff);
         c = *reinterpret_cast<const f32x4 *>(a.state + (size_t)a.B * 128 + soff);
-        wo = *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * pw + 4 * pg);
+        wo = 0.5f * *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * pw + 4 * pg);   // halved: relu2_f (activations.hpp)
         bo = a.tables[NTAB_BOUT];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) hs[0][pj][16 * pw + 4 * rr + pg] = h[rr];
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(512, 1) rec_small_kernel(const RecArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 h[rr] = sigmoid_f(go[rr]) * th[rr];
-                part = fmaf(wo[rr], fmaxf(h[rr], 0.f), part);
+                part = fmaf(wo[rr], relu2_f(h[rr]), part);
             }
             part += __shfl_xor(part, 1);
             part += __shfl_xor(part, 2);

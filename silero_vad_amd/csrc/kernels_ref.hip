@@ -4,6 +4,7 @@
 // computes it (JIT!/vad/utils/pytorch_stft.py:17-34).
 #include <hip/hip_runtime.h>
 
+#include "activations.hpp"
 #include "device_api.hpp"
 
 namespace vad {
@@ -19,6 +20,10 @@ __device__ void ref_chunk(const RefNet &w, const float *xp, float *sm, float *h,
     float *a3 = a2 + 64;             // [128]
     float *gates = a3 + 128;         // [512]
     const int tid = threadIdx.x, nt = blockDim.x;
+    // non-finite input (fft_wave.hpp, "non-finite input"): a chunk with any non-finite magnitude is NaN, as in the MFMA path
+    __shared__ int poisoned;
+    if (tid == 0) poisoned = 0;
+    __syncthreads();
 
     for (int idx = tid; idx < K * 4; idx += nt) {
         const int k = idx >> 2, m = idx & 3;
@@ -29,7 +34,9 @@ __device__ void ref_chunk(const RefNet &w, const float *xp, float *sm, float *h,
             re = fmaf(br[n], v, re);
             im = fmaf(bi[n], v, im);
         }
-        mag[k * 4 + m] = sqrtf(re * re + im * im);
+        const float mg = sqrtf(re * re + im * im);
+        mag[k * 4 + m] = mg;
+        if (!(fabsf(mg) < __builtin_inff())) poisoned = 1;            // (benign race: every writer stores 1)
     }
     __syncthreads();
 
@@ -48,7 +55,7 @@ __device__ void ref_chunk(const RefNet &w, const float *xp, float *sm, float *h,
                 if (v < 0 || v >= T) continue;
                 for (int i = 0; i < cin[l]; ++i) acc = fmaf(wr[i * 3 + tau], in[i * T + v], acc);
             }
-            outs[l][o * To + u] = fmaxf(acc, 0.f);
+            outs[l][o * To + u] = relu_f(acc);
         }
         __syncthreads();
         in = outs[l];
@@ -62,7 +69,7 @@ __device__ void ref_chunk(const RefNet &w, const float *xp, float *sm, float *h,
             a = fmaf(wi[j], a3[j], a);
             b = fmaf(wh[j], h[j], b);
         }
-        gates[r] = (a + w.b_ih[r]) + (b + w.b_hh[r]);
+        gates[r] = poisoned ? __builtin_nanf("") : (a + w.b_ih[r]) + (b + w.b_hh[r]);
     }
     __syncthreads();
     if (tid < 128) {
@@ -76,7 +83,7 @@ __device__ void ref_chunk(const RefNet &w, const float *xp, float *sm, float *h,
     __syncthreads();
     if (tid == 0) {
         float p = w.b_out[0];
-        for (int j = 0; j < 128; ++j) p = fmaf(w.w_out[j], fmaxf(h[j], 0.f), p);
+        for (int j = 0; j < 128; ++j) p = fmaf(w.w_out[j], relu_f(h[j]), p);
         *prob_out = 1.f / (1.f + expf(-p));
     }
     __syncthreads();

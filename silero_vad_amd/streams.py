@@ -1049,6 +1049,7 @@ class StreamPool:
             torch.cuda.synchronize(self.device)
             self.ctx.copy_(keep_ctx)                       # the warm-up step advanced them
             self.state.copy_(keep_state)
+            torch.cuda.synchronize(self.device)            # (a host-mode replay on self.stream may follow at once)
             self._graph_gen = self.engine.scratch_generation()
 
     # -- slots ---------------------------------------------------------------------------------------
@@ -1057,15 +1058,17 @@ class StreamPool:
         if not self._free:
             raise RuntimeError("StreamPool is full")
         s = self._free.pop()
-        self.ctx[s].zero_()
-        self.state[:, s].zero_()
+        with self._state_stream():
+            self.ctx[s].zero_()
+            self.state[:, s].zero_()
         self.open_mask[s] = True
         return s
 
     def open_all(self):
         """Admit `capacity` streams at once (every slot from zero state)."""
-        self.ctx.zero_()
-        self.state.zero_()
+        with self._state_stream():
+            self.ctx.zero_()
+            self.state.zero_()
         self.open_mask[:] = True
         self._free = []
 
@@ -1076,8 +1079,16 @@ class StreamPool:
         self._free.append(int(slot))
 
     def reset(self, slot: int):
-        self.ctx[slot].zero_()
-        self.state[:, slot].zero_()
+        with self._state_stream():
+            self.ctx[slot].zero_()
+            self.state[:, slot].zero_()
+
+    def _state_stream(self):
+        """Where writes to the carried state are issued.  A host-mode pool (host_slots > 0) runs its ticks on its own
+        non-blocking stream: the zeroing of a slot must be ordered on THAT stream, or a tick submitted right behind
+        open()/reset() could read the state before the zeroing has landed.  Device-mode pools tick on torch's current
+        stream, where the writes already are.  (tick() and submit() must not be mixed on one pool.)"""
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     # -- the tick --------------------------------------------------------------------------------------
     def tick(self, chunks: torch.Tensor) -> torch.Tensor:
@@ -1177,3 +1188,100 @@ class BatchVADIterator:
             raise ValueError("vad_iterator_feed: bad arguments")
         ev = self._events
         return [(ev[i].slot, {"end" if ev[i].kind else "start": ev[i].sample}) for i in range(m)]
+
+
+class StreamPump:
+    """BASELINE configs[4] through the native pump (include/silero_vad_hip.h "live streams: the pump", csrc/pump.hip): `streams`
+    live streams on one GPU, host int16 chunks in, VADIterator events out, with no Python and no torch on the per-tick path
+    (the reference's native streaming loop, examples/cpp/silero-vad-onnx.cpp:335-390, for thousands of streams in lock step).
+
+        pump = StreamPump(engine, 16000, streams=8192)
+        pump.slot(r)[b] = next int16 chunk of stream b          # numpy view of the page-locked ingest ring, [streams, N]
+        pump.submit(r)                                           # asynchronous: H2D -> step kernels -> probabilities on the host
+        events, r = pump.poll()                                  # retire the oldest tick: [(stream, {'start' | 'end': sample}), ...]
+        pump.probs(r)                                            # its probabilities, [streams] float32 (page-locked)
+
+    `play(rows, ...)` runs the whole loop natively over memory-resident recordings (tests, benchmarks, file-fed servers)."""
+
+    def __init__(self, engine, sampling_rate: int = 16000, streams: int = 8192, parts: int = 0, ring_slots: int = 0,
+                 threshold: float = 0.5, min_silence_duration_ms: int = 100, speech_pad_ms: int = 30):
+        if sampling_rate not in (8000, 16000):
+            raise ValueError("VADIterator does not support sampling rates other than [8000, 16000]")
+        self._L = engine._L
+        prm = _lib.PumpParams()
+        self._L.vad_pump_params_default(ctypes.byref(prm), int(sampling_rate), int(streams))
+        prm.parts, prm.ring_slots = int(parts), int(ring_slots)
+        prm.threshold, prm.min_silence_duration_ms, prm.speech_pad_ms = float(threshold), int(min_silence_duration_ms), int(speech_pad_ms)
+        h = ctypes.c_void_p()
+        rc = self._L.vad_pump_create(engine._h, ctypes.byref(prm), ctypes.byref(h))
+        if rc:
+            raise _lib.VadError(rc, "vad_pump_create")
+        self._h = h
+        g = [ctypes.c_int() for _ in range(4)]
+        self._L.vad_pump_geometry(h, *[ctypes.byref(x) for x in g])
+        self.streams, self.n, self.ring_slots, self.parts = (x.value for x in g)
+        self.sr = int(sampling_rate)
+        self._events = (_lib.IterEvent * self.streams)()
+        self._slots = [np.ctypeslib.as_array(ctypes.cast(self._L.vad_pump_slot(h, r), ctypes.POINTER(ctypes.c_int16)),
+                                             shape=(self.streams, self.n)) for r in range(self.ring_slots)]
+        self._probs = [np.ctypeslib.as_array(ctypes.cast(self._L.vad_pump_probs(h, r), ctypes.POINTER(ctypes.c_float)),
+                                             shape=(self.streams,)) for r in range(self.ring_slots)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._slots = self._probs = None
+            self._L.vad_pump_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc:
+            raise _lib.VadError(rc, self._L.vad_pump_last_error(self._h).decode())
+
+    def slot(self, r: int) -> np.ndarray:
+        return self._slots[r]
+
+    def probs(self, r: int) -> np.ndarray:
+        return self._probs[r]
+
+    def submit(self, r: int):
+        self._check(self._L.vad_pump_submit(self._h, int(r)))
+
+    def poll(self, block: bool = True):
+        """-> (events, ring slot) of the oldest submitted tick; (None, None) if nothing is in flight or (block=False) it has not finished."""
+        r = ctypes.c_int(-1)
+        m = self._L.vad_pump_poll(self._h, 1 if block else 0, self._events, self.streams, ctypes.byref(r))
+        if m in (-1, -2):
+            return None, None
+        if m < 0:
+            raise RuntimeError("vad_pump_poll: " + self._L.vad_pump_last_error(self._h).decode())
+        ev = self._events
+        return [(ev[i].slot, {"end" if ev[i].kind else "start": ev[i].sample}) for i in range(m)], r.value
+
+    def open_stream(self, stream: int):
+        self._check(self._L.vad_pump_open(self._h, int(stream)))
+
+    def close_stream(self, stream: int):
+        self._check(self._L.vad_pump_close(self._h, int(stream)))
+
+    def state(self, stream: int):
+        """(h[128], c[128], ctx[C]) of one stream (synchronises; tests)."""
+        h, c, x = np.empty(128, np.float32), np.empty(128, np.float32), np.empty(self.n // 8, np.float32)
+        self._check(self._L.vad_pump_state(self._h, int(stream), h.ctypes.data, c.ctypes.data, x.ctypes.data))
+        return h, c, x
+
+    def play(self, rows: np.ndarray, n_ticks: int, first_tick: int = 0, depth: int = 2, fill_threads: int = 0, max_events: int = 0):
+        """vad_pump_play: stream b plays rows[b] (int16, length a multiple of the chunk) circularly, chunk by chunk.
+        -> (events [(stream, {...}), ...] (the first max_events of them), stats dict)."""
+        if rows.dtype != np.int16 or rows.ndim != 2 or rows.shape[0] != self.streams or not rows.flags.c_contiguous:
+            raise ValueError(f"rows must be C-contiguous int16 [{self.streams}, period]")
+        cap = int(max_events)
+        buf = (_lib.IterEvent * max(cap, 1))()
+        st = _lib.PumpStats()
+        m = self._L.vad_pump_play(self._h, rows.ctypes.data, rows.shape[1], rows.shape[1], int(first_tick), int(n_ticks), int(depth),
+                                  int(fill_threads), buf if cap else None, cap, ctypes.byref(st))
+        if m < 0:
+            raise RuntimeError("vad_pump_play: " + self._L.vad_pump_last_error(self._h).decode())
+        ev = [(buf[i].slot, {"end" if buf[i].kind else "start": buf[i].sample}) for i in range(min(m, cap))]
+        return ev, {k: getattr(st, k) for k, _ in _lib.PumpStats._fields_}

@@ -4,7 +4,10 @@
  * header must be valid C and every entry point it uses must resolve); on a GPU box tests/test_gpu_parity.py also runs it: it streams
  * int16 chunks of `pcm_file` through vad_step_host (page-locked buffers from vad_host_register) and vad_iterator_feed and prints the
  * probabilities and events, which the test compares with the Python path's.
- *     client <weights> <pcm_int16_file> <sr> <streams>                                                                          */
+ *     client <weights> <pcm_int16_file> <sr> <streams> [pump]
+ * With `pump` the same loop runs on the native pump (vad_pump_create / slot / submit / poll / probs): the client writes the chunks into
+ * the pump's page-locked ring, keeps two ticks in flight and prints each tick's probabilities and events as it is retired -- no HIP
+ * call of its own at all.                                                                                                       */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,6 +27,55 @@ static void *dev_zeros(size_t bytes) {
         exit(2);
     }
     return p;
+}
+
+/* the pump route: stream b plays the recording from offset b * 7919 (circular), two ticks in flight */
+static int run_pump(vad_engine *e, const int16_t *pcm, long samples, int sr, int B, int N, long T) {
+    vad_pump_params prm;
+    vad_pump *p = NULL;
+    vad_iter_event *ev = (vad_iter_event *)calloc((size_t)B, sizeof(vad_iter_event));
+    long t, done = 0;
+    int rc, R = 0;
+    vad_pump_params_default(&prm, sr, B);
+    prm.parts = 2;
+    prm.ring_slots = 3;
+    if ((rc = vad_pump_create(e, &prm, &p)) != VAD_OK) {
+        fprintf(stderr, "vad_pump_create: %s\n", vad_strerror(rc));
+        return 1;
+    }
+    vad_pump_geometry(p, NULL, NULL, &R, NULL);
+    for (t = 0; t <= T; ++t) {
+        if (t < T) {
+            int16_t *slot = vad_pump_slot(p, (int)(t % R));
+            int b, i;
+            for (b = 0; b < B; ++b)
+                for (i = 0; i < N; ++i) slot[(size_t)b * N + i] = pcm[((long)b * 7919 + t * N + i) % samples];
+            if ((rc = vad_pump_submit(p, (int)(t % R))) != VAD_OK) {
+                fprintf(stderr, "vad_pump_submit: %s\n", vad_pump_last_error(p));
+                return 1;
+            }
+        }
+        if (t > 0) {                                  /* retire tick t - 1 while tick t runs */
+            int r = -1, b;
+            const long m = vad_pump_poll(p, 1, ev, B, &r);
+            const float *prob;
+            long k;
+            if (m < 0 || r != (int)((t - 1) % R)) {
+                fprintf(stderr, "vad_pump_poll: %ld (%s)\n", m, vad_pump_last_error(p));
+                return 1;
+            }
+            prob = vad_pump_probs(p, r);
+            printf("P %ld", done);
+            for (b = 0; b < B; ++b) printf(" %.9g", prob[b]);
+            printf("\n");
+            for (k = 0; k < m; ++k) printf("E %ld %d %s %lld\n", done, (int)ev[k].slot, ev[k].kind ? "end" : "start", (long long)ev[k].sample);
+            ++done;
+        }
+    }
+    if (vad_pump_poll(p, 1, ev, B, NULL) != VAD_PUMP_IDLE) return 1;
+    vad_pump_destroy(p);
+    free(ev);
+    return 0;
 }
 
 int main(int argc, char **argv) {
@@ -59,6 +111,11 @@ int main(int argc, char **argv) {
     if (fread(pcm, 2, (size_t)samples, f) != (size_t)samples) return 66;
     fclose(f);
     const long T = samples / N;
+    if (argc > 5 && strcmp(argv[5], "pump") == 0) {
+        rc = run_pump(e, pcm, samples, sr, B, N, T);
+        vad_destroy(e);
+        return rc;
+    }
 
     /* page-locked ingest buffer and probability buffer (what an audio server's network threads would write / read) */
     int16_t *host_pcm = (int16_t *)calloc((size_t)B * N, 2);

@@ -88,3 +88,20 @@ def state_err(a, b):
     (up to ~50 on the fixtures), so its tolerance is relative; h in [-1, 1] stays absolute."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max()) if a.size else 0.0
+
+
+def check_nonfinite(g, probs, state, probs_after, tol_prob, tol_state):
+    """The reference's behaviour on NaN / Inf / overflowing samples (make_golden.py, protocol nonfinite): NaN exactly where the
+    reference is NaN (sticky from the poisoned chunk on, whole (h, c) rows), everything else within tolerance."""
+    want = g["nf_probs"]
+    assert np.array_equal(np.isnan(probs), np.isnan(want))
+    assert np.isnan(want).sum() == 9 + 7 + 8 + 6                      # streams 1-4, from chunks 3, 5, 4, 6 of 12
+    ok = ~np.isnan(want)
+    assert np.abs(probs[ok] - want[ok]).max() < tol_prob
+    assert np.array_equal(np.isnan(state), np.isnan(g["nf_state"]))
+    rows = ~np.isnan(g["nf_state"]).any(axis=(0, 2))
+    assert rows.tolist() == [True, False, False, False, False, True]
+    assert state_err(state[:, rows], g["nf_state"][:, rows]) < tol_state
+    # after reset_states() the stream is clean again
+    assert not np.isnan(probs_after).any()
+    assert np.abs(probs_after - g["nf_probs_after_reset"]).max() < tol_prob

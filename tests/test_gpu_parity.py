@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import SRS, kat_segments, state_err, synthetic_audio
+from conftest import SRS, check_nonfinite, kat_segments, state_err, synthetic_audio
 
 pytestmark = pytest.mark.gpu
 
@@ -524,12 +524,14 @@ def test_stream_pool_host_int16_chunks_in_events_out(model, golden, tag):
         again.tick(torch.zeros((cap, n)))                 # a float chunk handed to an int16 pool
 
 
+@pytest.mark.parametrize("route", ["step_host", "pump"])
 @pytest.mark.parametrize("tag", ["16k", "8k"])
-def test_plain_c_client_streams_chunks_to_events(model, golden, tag, tmp_path):
+def test_plain_c_client_streams_chunks_to_events(model, golden, tag, route, tmp_path):
     """A non-Python client (tests/c_client/client.c: C99 against include/silero_vad_hip.h, the shape of the reference's ONNX Runtime
-    clients, examples/cpp/silero-vad-onnx.cpp:103-142) streams the fixture through vad_step_host + vad_iterator_feed: stream 0's
-    probabilities equal the reference model's (golden) and its events EQUAL the reference VADIterator's; the other streams equal the
-    Python path bit for bit."""
+    clients, examples/cpp/silero-vad-onnx.cpp:103-142) streams the fixture through vad_step_host + vad_iterator_feed -- or, route
+    "pump", through the native pump (vad_pump_*: ring slot writes, submit, poll; two ticks in flight, no HIP call in the client):
+    stream 0's probabilities equal the reference model's (golden) and its events EQUAL the reference VADIterator's; the other
+    streams equal the Python path bit for bit."""
     import subprocess
     from test_abi import build_c_client
     from silero_vad_amd import _lib
@@ -541,7 +543,8 @@ def test_plain_c_client_streams_chunks_to_events(model, golden, tag, tmp_path):
     pcm.tofile(raw)
     exe = build_c_client(tmp_path)
     full = len(pcm) // n
-    r = subprocess.run([str(exe), str(_lib.WEIGHTS_PATH), str(raw), str(sr), "3"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([str(exe), str(_lib.WEIGHTS_PATH), str(raw), str(sr), "3"] + (["pump"] if route == "pump" else []),
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-500:]
     probs = np.array([[float(v) for v in l.split()[2:]] for l in r.stdout.splitlines() if l.startswith("P ")], dtype=np.float32)
     assert probs.shape == (full, 3)
@@ -1974,3 +1977,213 @@ def test_small_batch_recurrence_serves_single_files(model, golden):
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump({"one_recording_60s": times}, open("gpurun_out/small_batch_recurrence.json", "w"), indent=1)
     assert times["auto"]["rec_ms"] < 0.6 * times["mfma"]["rec_ms"], times
+
+
+# ---- (24) non-finite input: NaN / Inf / overflowing samples behave as in the reference ---------------------------------------------------
+def _nf_forms(model):
+    """(label, option settings) of every way the product library can evaluate a [B, T] call."""
+    return [("throughput+rec", {"front": "throughput", "rec_form": "mfma"}),
+            ("latency+rec_small", {"front": "latency", "rec_form": "auto"}),
+            ("reference kernels", {"impl": "reference"}),
+            ("bf16x9", {"front_mma": "bf16x9", "rec": "bf16x9"})]
+
+
+_NF_DEFAULTS = {"front": "auto", "rec_form": "auto", "impl": "mfma", "front_mma": "fp32", "rec": "fp32", "enc0": "winograd"}
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_nonfinite_input_matches_reference(model, model_ab, oracle, golden, tag):
+    """The reference propagates NaN: one NaN / +-Inf sample -- or a finite one whose spectrum overflows -- makes that chunk's
+    probability NaN and leaves NaN in the carried (h, c), so every later chunk of the stream is NaN until reset_states()
+    (torch.relu, aten::lstm_cell; goldens recorded from the reference: make_golden.py protocol nonfinite).  Every form of the HIP
+    path must give NaN in exactly those places, leave the OTHER streams of the same 16-stream tile bit-identical to a clean run,
+    and get_speech_timestamps must return the reference's segments for a recording with one poisoned sample."""
+    from silero_vad_amd import get_speech_timestamps
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    rows, T = g["nf_rows"], g["nf_probs"].shape[1]
+    x = torch.from_numpy(rows)
+    # (a) the model object's per-chunk protocol (B = 6: the fused one-kernel step), reset, clean again
+    model.reset_states()
+    probs = torch.cat([model(x[:, t * n:(t + 1) * n], sr) for t in range(T)], 1).cpu().numpy()
+    state = model._state.cpu().numpy()
+    model.reset_states()
+    after = torch.cat([model(x[:, t * n:(t + 1) * n], sr) for t in range(T, rows.shape[1] // n)], 1).cpu().numpy()
+    check_nonfinite(g, probs, state, after, TIGHT, TOL)
+    # (b) every form of the [B, T] entry; clean streams and clean prefixes bit-identical to a run without the bad samples
+    clean = rows[:, :T * n].copy()
+    clean[~np.isfinite(clean) | (np.abs(clean) > 1e10)] = 0.0
+    pos = g["nf_pos"]
+    for eng_model, forms in ((model, _nf_forms(model)),
+                             (model_ab, [("enc0 direct", {"enc0": "direct"}), ("enc0 winograd2", {"enc0": "winograd2"})])):
+        for label, opts in forms:
+            for k, v in opts.items():
+                eng_model.engine.set_option(k, v)
+            try:
+                p, _, st = run_engine(eng_model, rows[:, :T * n], sr)
+                pc, _, stc = run_engine(eng_model, clean, sr)
+            finally:
+                for k in opts:
+                    eng_model.engine.set_option(k, _NF_DEFAULTS[k])
+            tol = (1e-4, 3e-4) if label == "bf16x9" else (TIGHT, TOL)
+            check_nonfinite(g, p, st, after, *tol)
+            assert not np.isnan(pc).any() and not np.isnan(stc).any(), label
+            for b in (0, 5):
+                assert np.array_equal(p[b], pc[b]) and np.array_equal(st[:, b], stc[:, b]), (label, b)
+            for b, t, _ in pos:
+                assert np.array_equal(p[b, :t], pc[b, :t]), (label, b)
+    # (c) a poisoned stream in the middle of a corpus-sized batch (throughput frontend + the full recurrence kernel), vs the oracle
+    B, Tb = 1100, 9
+    big = rolled_rows(g["wav"], B, Tb * n, 4001)
+    big[37, 5 * n + 17] = np.nan
+    big[38, 2 * n + n - 3] = -np.inf                                    # inside the context of chunk 3
+    big[1099, 0] = np.inf
+    p, _, st = run_engine(model, big, sr)
+    want, _, wst = oracle.forward_audio(big, sr)
+    assert np.array_equal(np.isnan(p), np.isnan(want)) and np.isnan(want).sum() == 4 + 7 + 9
+    assert np.array_equal(np.isnan(st), np.isnan(wst))
+    ok = ~np.isnan(want)
+    assert np.abs(p[ok] - want[ok]).max() < TIGHT
+    fin = ~np.isnan(wst).any(axis=(0, 2))
+    assert fin.sum() == B - 3 and state_err(st[:, fin], wst[:, fin]) < TOL
+    # (d) get_speech_timestamps over a recording with one poisoned sample: a NaN probability passes neither threshold test
+    # (utils_vad.py:352-361,404), so an open segment runs to the end of the audio and nothing opens after it
+    for name, rec in golden["ext"][tag]["nonfinite_timestamps"].items():
+        w2 = g["wav"].copy()
+        w2[rec["at"]] = np.inf if rec["value"] == "inf" else np.nan
+        assert get_speech_timestamps(torch.from_numpy(w2), model, sampling_rate=sr) == rec["out"], name
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_nonfinite_through_the_stream_pool(model, golden, tag):
+    """Live streams (hipGraph step of a StreamPool + the native iterator): a slot whose audio contained a NaN stays NaN -- no
+    further events from it -- until the slot is re-opened; its neighbours in the tile are untouched."""
+    from silero_vad_amd.streams import StreamPool
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    rows, T = g["nf_rows"], g["nf_probs"].shape[1]
+    pool = StreamPool(model.engine, sr, capacity=16)
+    slots = [pool.open() for _ in range(6)]
+    buf = torch.zeros((16, n), device=model.device)
+    got = []
+    for t in range(T):
+        buf[:6] = torch.from_numpy(rows[:, t * n:(t + 1) * n]).to(model.device)
+        got.append(pool.tick(buf).clone())
+    torch.cuda.synchronize()
+    p = torch.stack(got, 1).cpu().numpy()[:6]
+    assert np.array_equal(np.isnan(p), np.isnan(g["nf_probs"]))
+    ok = ~np.isnan(g["nf_probs"])
+    assert np.abs(p[ok] - g["nf_probs"][ok]).max() < TIGHT
+    # re-open the poisoned slots: clean state, the reference's after-reset probabilities
+    for s in slots[1:5]:
+        pool.close(s)
+    assert sorted(pool.open() for _ in range(4)) == sorted(slots[1:5])
+    for s in (0, 5):
+        pool.reset(s)
+    got = []
+    for t in range(T, rows.shape[1] // n):
+        buf[:6] = torch.from_numpy(rows[:, t * n:(t + 1) * n]).to(model.device)
+        got.append(pool.tick(buf).clone())
+    torch.cuda.synchronize()
+    p = torch.stack(got, 1).cpu().numpy()
+    assert not np.isnan(p[:6]).any()
+
+
+# ---- (25) the native pump: configs[4] without Python on the tick path -----------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_pump_int16_chunks_in_events_out(model, golden, tag):
+    """vad_pump (csrc/pump.hip; the reference's native streaming loop, examples/cpp/silero-vad-onnx.cpp:335-390, for a lock-step batch):
+    int16 chunks written into the page-locked ring -> copies and step kernels on two streams ordered by events -> probabilities in
+    host memory -> iterator logic -> events.  Stream 0 plays the fixture from its start: probabilities equal the reference model's
+    (golden), events EQUAL the reference VADIterator's; the other streams equal the engine's [B, T] entry bit for bit and our
+    per-stream VADIterator; vad_pump_play (the whole loop natively, one or two ticks in flight) gives the same events; a stream that
+    is re-opened mid-run restarts from zero state; a slot in flight is refused."""
+    from silero_vad_amd import StreamPump, VADIterator, _lib
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    pcm = g["pcm_i16"]
+    T = len(pcm) // n
+    cap = 100                                             # not a multiple of 16; 3 parts of 32 + 32 + 36 streams
+    rows = np.ascontiguousarray(np.stack([np.roll(pcm, -s * 7919)[:T * n] for s in range(cap)]))
+    rec = golden["segments"][tag]["iterator"]["default"]
+    pump = StreamPump(model.engine, sr, streams=cap, parts=3, ring_slots=3, **rec["init"])
+    assert (pump.streams, pump.n, pump.ring_slots, pump.parts) == (cap, n, 3, 3)
+    events = {s: [] for s in range(cap)}
+    probs = np.zeros((cap, T), np.float32)
+    for t in range(T + 1):                                # tick t is submitted while tick t - 1 is retired
+        if t < T:
+            pump.slot(t % 3)[:] = rows[:, t * n:(t + 1) * n]
+            pump.submit(t % 3)
+            if t == 7:
+                with pytest.raises(_lib.VadError, match="not been retired"):
+                    pump.submit(t % 3)
+        if t > 0:
+            ev, r = pump.poll()
+            assert r == (t - 1) % 3
+            probs[:, t - 1] = pump.probs(r)
+            for s, e in ev:
+                events[s].append(e)
+    assert pump.poll() == (None, None)
+    assert events[0] == rec["events"], tag                # the reference's own events (39 / 92)
+    assert np.abs(probs[0] - np.asarray(g["probs_wav"]).reshape(-1)[:T]).max() < TIGHT
+    # the engine's [B, T] entry on the same int16 audio: identical bits (a stream's result does not depend on the batch it is in)
+    Tb = 300
+    st = torch.zeros((2, cap, 128), device=model.device)
+    ctx = torch.zeros((cap, n // 8), device=model.device)
+    want = model.engine.forward_audio(torch.from_numpy(rows[:, :Tb * n]).to(model.device), sr, ctx, st).cpu().numpy()
+    assert np.array_equal(probs[:, :Tb], want)
+    for s in (1, 37, 99):
+        model.reset_states()
+        one = VADIterator(model, sampling_rate=sr, **rec["init"])
+        ref = [e for t in range(T) if (e := one(torch.from_numpy(rows[s, t * n:(t + 1) * n].copy())))]
+        assert events[s] == ref and len(ref) > 4, s
+    h, c, x = pump.state(37)
+    assert np.isfinite(h).all() and np.abs(c).max() > 0 and np.array_equal(x, rows[37, T * n - n // 8:T * n].astype(np.float32) / 32768.0)
+    pump.close()
+    # the whole loop natively
+    flat = sorted((s, k, v) for s in range(cap) for e in events[s] for k, v in e.items())
+    for depth in (1, 2):
+        pump = StreamPump(model.engine, sr, streams=cap, parts=2, ring_slots=4, **rec["init"])
+        ev, stats = pump.play(rows, T, depth=depth, fill_threads=2, max_events=100000)
+        assert stats["ticks"] == T and stats["events"] == len(flat) == len(ev) and stats["depth"] == depth
+        assert sorted((s, k, v) for s, e in ev for k, v in e.items()) == flat, depth
+        assert 0 < stats["tick_ms_p50"] <= stats["tick_ms_p95"] <= stats["tick_ms_max"]
+        pump.close()
+    # re-opening a stream: zero state, iterator restarted, the other streams untouched
+    pump = StreamPump(model.engine, sr, streams=cap, parts=2, ring_slots=2, **rec["init"])
+    K = 60
+    got = np.zeros((cap, 2 * K), np.float32)
+    for t in range(2 * K):
+        if t == K:
+            pump.open_stream(5)
+            pump.close_stream(6)
+        src = rows[:, t * n:(t + 1) * n].copy()
+        if t >= K:
+            src[5] = rows[5, (t - K) * n:(t - K + 1) * n]      # the new stream in slot 5 plays the recording from its start
+        pump.slot(t % 2)[:] = src
+        pump.submit(t % 2)
+        ev, r = pump.poll()
+        got[:, t] = pump.probs(r)
+        assert all(s != 6 for s, _ in ev) or t < K            # a closed slot emits nothing
+    assert np.array_equal(got[5, K:], probs[5, :K]) and np.array_equal(got[7], probs[7, :2 * K]) and np.array_equal(got[5, :K], probs[5, :K])
+    pump.close()
+
+
+def test_pump_rejects_bad_arguments(model):
+    from silero_vad_amd import StreamPump, _lib
+    L = _lib.lib()
+    with pytest.raises(ValueError):
+        StreamPump(model.engine, 44100, streams=4)
+    with pytest.raises(_lib.VadError):
+        StreamPump(model.engine, 16000, streams=0)
+    pump = StreamPump(model.engine, 16000, streams=20, parts=7, ring_slots=1)
+    assert pump.parts == 2 and pump.ring_slots == 2            # 20 streams are two tiles; a ring has at least two slots
+    with pytest.raises(_lib.VadError, match="no such ring slot"):
+        pump.submit(2)
+    with pytest.raises(_lib.VadError, match="no such stream"):
+        pump.open_stream(20)
+    with pytest.raises(ValueError):
+        pump.play(np.zeros((20, 512), np.float32), 1)
+    assert L.vad_pump_poll(pump._h, 1, None, 0, None) == -1    # VAD_PUMP_IDLE
+    assert L.vad_pump_slot(pump._h, 5) is None and L.vad_pump_probs(pump._h, -1) is None
+    pump.close()

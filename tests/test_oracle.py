@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import SRS, kat_segments, state_err, synthetic_audio
+from conftest import SRS, check_nonfinite, kat_segments, state_err, synthetic_audio
 
 # fp32 restatement vs ATen fp32 kernels: summation order differs, nothing else
 TOL_PROB = 2e-5
@@ -68,23 +68,6 @@ def test_stages(oracle, golden, tag):
         assert np.abs(st[f"enc{i}"] - ref).max() < 3e-5 * max(1.0, np.abs(ref).max())
     assert np.abs(prob - g["stage_prob"][:, 0]).max() < TOL_PROB
     assert state_err(state, g["stage_state_out"]) < TOL_STATE
-
-
-def check_nonfinite(g, probs, state, probs_after, tol_prob, tol_state):
-    """The reference's behaviour on NaN / Inf / overflowing samples (make_golden.py, protocol nonfinite): NaN exactly where the
-    reference is NaN (sticky from the poisoned chunk on, whole (h, c) rows), everything else within tolerance."""
-    want = g["nf_probs"]
-    assert np.array_equal(np.isnan(probs), np.isnan(want))
-    assert np.isnan(want).sum() == 9 + 7 + 8 + 6                      # streams 1-4, from chunks 3, 5, 4, 6 of 12
-    ok = ~np.isnan(want)
-    assert np.abs(probs[ok] - want[ok]).max() < tol_prob
-    assert np.array_equal(np.isnan(state), np.isnan(g["nf_state"]))
-    rows = ~np.isnan(g["nf_state"]).any(axis=(0, 2))
-    assert rows.tolist() == [True, False, False, False, False, True]
-    assert state_err(state[:, rows], g["nf_state"][:, rows]) < tol_state
-    # after reset_states() the stream is clean again
-    assert not np.isnan(probs_after).any()
-    assert np.abs(probs_after - g["nf_probs_after_reset"]).max() < tol_prob
 
 
 @pytest.mark.parametrize("tag", ["16k", "8k"])
