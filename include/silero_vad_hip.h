@@ -291,12 +291,13 @@ int  vad_pump_close(vad_pump *p, int stream);
 /* Test / migration hook: copy stream's carried h[128], c[128], ctx[C] to the host (any may be NULL).  Synchronises.        */
 int  vad_pump_state(vad_pump *p, int stream, float *h, float *c, float *ctx);
 /* The whole loop in one native call -- for tests, benchmarks and file-fed servers: stream b plays rows[b * ld ...] circularly with
- * period `period` samples (a multiple of N): at tick t its chunk is rows[b * ld + (t * N) % period ...].  For t = first_tick ...
- * first_tick + n_ticks - 1: a source thread WRITES the chunks into ring slot t % ring_slots as soon as that slot is free (split
- * over `fill_threads` host threads, <= 0: vad_host_threads() - 1; what the receive threads of an audio server would do), the
- * calling thread submits the tick once it is written, and once `depth` ticks are in flight (clamped to 1 ... ring_slots - 1;
- * 1 = one tick at a time) retires the oldest.  All events are appended to `out` (at most cap; the return value is their
- * number) and `st` (may be NULL) is filled in.                                                                              */
+ * period `period` samples (a multiple of N): at tick t its chunk is rows[b * ld + (t * N) % period ...].  `fill_threads` SOURCE
+ * threads (0: min(8, vad_host_threads() - 2); < 0: the sources are silent, the slots keep their content -- isolates the device
+ * side) each own a range of streams and WRITE their chunks into ring slot t % ring_slots for t = first_tick ... first_tick +
+ * n_ticks - 1, at most `depth` ticks ahead of the retired ones; the calling thread submits a tick once it is completely written
+ * and, once `depth` ticks are in flight (clamped to 1 ... ring_slots - 1), retires the oldest.  depth 1 = strictly one tick at a
+ * time: tick_ms_* is then the latency of one tick, slot written -> events on the host.  All events are appended to `out` (at most
+ * cap; the return value is their number) and `st` (may be NULL) is filled in (fill_ms_mean: per source thread and tick).          */
 long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long first_tick, long n_ticks, int depth, int fill_threads,
                    vad_iter_event *out, long cap, vad_pump_stats *st);
 

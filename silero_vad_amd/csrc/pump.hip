@@ -19,6 +19,7 @@
 //   * a ring slot may be rewritten by its sources as soon as the tick that read it has been retired (vad_pump_poll), and is refused
 //     (VAD_ERR_ARG) while that tick is in flight.
 #include <hip/hip_runtime.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -310,11 +311,13 @@ int vad_pump_state(vad_pump *p, int stream, float *h, float *c, float *ctx) {
     return VAD_OK;
 }
 
-// The whole loop, natively.  A SOURCE thread plays the part of the audio sources: for every tick it WRITES the chunks of all streams
-// into the tick's ring slot (rows -> slot, split over `fill_threads` host threads: the memory traffic an audio server's receive
-// threads would cause) as soon as the slot is free again, running ahead of the GPU by up to the ring's depth.  The calling thread is
-// the server loop: wait until the slot is written, submit the tick, and once `depth` ticks are in flight retire the oldest (wait,
-// iterator logic, events).  Tick latency = slot completely written -> its events on the host.
+// The whole loop, natively.  SOURCE threads play the part of the audio sources: thread k owns a range of streams and, for every tick,
+// WRITES their chunks into the tick's ring slot (rows -> slot; streaming stores: the data is bound for the DMA engine, not for this
+// core's cache) as soon as the server has room for the tick -- the memory traffic an audio server's receive path causes.  The
+// calling thread is the server loop: wait until the slot is completely written, submit the tick, and once `depth` ticks are in
+// flight retire the oldest (wait, iterator logic, events).  The sources run at most `depth` ticks ahead of the retired ones
+// (depth 1: strictly one tick at a time -- the next chunks are written after the previous tick's events are out, so "written ->
+// events" is the latency of ONE tick; depth >= 2: tick t + 1 is written and copied while tick t computes).
 long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long first_tick, long n_ticks, int depth, int fill_threads,
                    vad_iter_event *out, long cap, vad_pump_stats *st) {
     if (!p) return VAD_PUMP_ERROR;
@@ -328,36 +331,42 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
         return VAD_PUMP_ERROR;
     }
     depth = std::max(1, std::min(depth, p->R - 1));
-    const int nthreads = fill_threads > 0 ? fill_threads : std::max(1, vad::default_host_threads(32) - 1);
-    const int blocks = std::max(1, std::min(p->streams / 64, 4 * nthreads));
-    const long per = (p->streams + blocks - 1) / blocks;
+    const bool silent = fill_threads < 0;        // diagnostic: the sources write nothing (the slots keep their content): device side only
+    int nsrc = fill_threads > 0 ? fill_threads : std::max(1, std::min(8, vad::default_host_threads(32) - 2));
+    nsrc = std::max(1, std::min(nsrc, (p->streams + 63) / 64));
+    const long per = ((p->streams + nsrc - 1) / nsrc + 15) / 16 * 16;          // whole tiles per source thread
     const long last = first_tick + n_ticks;
-    std::atomic<long> filled{first_tick}, retired{first_tick};
+    std::atomic<long> retired{first_tick};
+    std::vector<std::atomic<int>> written(p->R);
+    for (auto &w : written) w.store(0);
     std::atomic<bool> stop{false};
-    std::vector<double> t_filled(p->R, 0.0), lat;
-    lat.reserve((size_t)n_ticks);
-    double fill_ms = 0.0;
-    std::thread source([&] {
-        for (long t = first_tick; t < last && !stop.load(std::memory_order_relaxed); ++t) {
-            // run ahead of the retired ticks by at most `depth` (<= R - 1: the slot's previous tick has been retired long since): a
-            // chunk is written when the server is about to have room for it, so that "written -> events" does not count ring queueing
+    std::atomic<long> fill_ns{0};
+    auto source = [&](int k) {
+        const long b0 = std::min<long>(p->streams, k * per), b1 = std::min<long>(p->streams, b0 + per);
+        for (long t = first_tick; t < last; ++t) {
             while (t - retired.load(std::memory_order_acquire) >= depth) {
                 if (stop.load(std::memory_order_relaxed)) return;
                 std::this_thread::yield();
             }
-            int16_t *slot = p->h_pcm + (size_t)(t % p->R) * p->streams * N;
-            const long off = (t * N) % period;
-            const double f0 = now_ms();
-            vad::HostPool::get().run(nthreads, blocks, [&](int k) {
-                const long b0 = k * per, b1 = std::min<long>(p->streams, b0 + per);
-                for (long b = b0; b < b1; ++b) std::memcpy(slot + b * N, rows + b * ld + off, (size_t)N * sizeof(int16_t));
-            });
-            const double f1 = now_ms();
-            fill_ms += f1 - f0;
-            t_filled[t % p->R] = f1;
-            filled.store(t + 1, std::memory_order_release);
+            if (!silent && b1 > b0) {
+                const double f0 = now_ms();
+                int16_t *slot = p->h_pcm + (size_t)(t % p->R) * p->streams * N;
+                const long off = (t * N) % period;
+                for (long b = b0; b < b1; ++b) {
+                    const __m128i *src = reinterpret_cast<const __m128i *>(rows + b * ld + off);
+                    __m128i *dst = reinterpret_cast<__m128i *>(slot + b * N);
+                    for (long i = 0; i < N / 8; ++i) _mm_stream_si128(dst + i, _mm_loadu_si128(src + i));
+                }
+                _mm_sfence();
+                fill_ns.fetch_add((long)((now_ms() - f0) * 1e6), std::memory_order_relaxed);
+            }
+            written[t % p->R].fetch_add(1, std::memory_order_release);
         }
-    });
+    };
+    std::vector<std::thread> sources;
+    for (int k = 0; k < nsrc; ++k) sources.emplace_back(source, k);
+    std::vector<double> t_written(p->R, 0.0), lat;
+    lat.reserve((size_t)n_ticks);
     std::vector<vad_iter_event> scratch((size_t)p->streams);
     long n_events = 0;
     double wait_ms = 0.0, submit_ms = 0.0;
@@ -369,7 +378,7 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
         const double w1 = now_ms();
         if (m < 0) return false;
         wait_ms += w1 - w0;
-        lat.push_back(w1 - t_filled[r]);
+        lat.push_back(w1 - t_written[r]);
         for (long i = 0; i < m; ++i, ++n_events)
             if (n_events < cap) out[n_events] = scratch[i];
         retired.fetch_add(1, std::memory_order_release);
@@ -377,16 +386,19 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
     };
     const double t0 = now_ms();
     for (long t = first_tick; t < last && ok; ++t) {
-        while (filled.load(std::memory_order_acquire) <= t) __builtin_ia32_pause();
+        const int r = (int)(t % p->R);
+        while (written[r].load(std::memory_order_acquire) < nsrc) std::this_thread::yield();
+        written[r].store(0, std::memory_order_relaxed);          // (the slot's next writers wait for this tick's retirement)
         const double s0 = now_ms();
-        ok = vad_pump_submit(p, (int)(t % p->R)) == VAD_OK;
+        t_written[r] = s0;
+        ok = vad_pump_submit(p, r) == VAD_OK;
         submit_ms += now_ms() - s0;
         if (ok && (int)p->inflight.size() >= depth) ok = retire();
     }
     while (ok && !p->inflight.empty()) ok = retire();
     const double t1 = now_ms();
     stop.store(true);
-    source.join();
+    for (auto &th : sources) th.join();
     if (!ok) {
         (void)hipStreamSynchronize(p->compute);                                  // leave nothing in flight behind an error
         while (!p->inflight.empty()) {
@@ -404,10 +416,10 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
         st->tick_ms_p50 = n ? lat[n / 2] : 0.0;
         st->tick_ms_p95 = n ? lat[std::min(n - 1, (size_t)(n * 0.95))] : 0.0;
         st->tick_ms_max = n ? lat[n - 1] : 0.0;
-        st->fill_ms_mean = n_ticks ? fill_ms / n_ticks : 0.0;
+        st->fill_ms_mean = n_ticks ? (double)fill_ns.load() * 1e-6 / nsrc / n_ticks : 0.0;
         st->submit_ms_mean = n_ticks ? submit_ms / n_ticks : 0.0;
         st->wait_ms_mean = n_ticks ? wait_ms / n_ticks : 0.0;
-        st->fill_threads = nthreads;
+        st->fill_threads = silent ? 0 : nsrc;
         st->depth = depth;
     }
     return n_events;
