@@ -623,7 +623,7 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
     cap = args.live
     R = 4
     period = 32                                                 # chunks of audio per stream the sources cycle through (268 MB at 16 kHz)
-    parts = max(1, int(os.environ.get("VAD_BENCH_STREAM_PARTS", "2")))
+    parts = max(1, int(os.environ.get("VAD_BENCH_STREAM_PARTS", "1")))
     rows = np.ascontiguousarray(fixture_rows_i16(sr, cap, period * n))     # real speech: the iterators do produce events
     eng = Engine(device=local)
     pump = StreamPump(eng, sr, streams=cap, parts=parts, ring_slots=R)
@@ -784,6 +784,12 @@ def run_corpus(args, rank, world, local, dist, passes):
         kernels of bucket k, two compute lanes, scan on the device) fills once and drains once."""
         os.environ["SILERO_VAD_AMD_UPLOAD"] = mode
         res = {}
+        nonlocal model
+        if os.environ.get("VAD_BENCH_CORPUS_FRESH"):            # diagnostic: every leg on a fresh model (new lanes, streams, staging pool)
+            model = load_silero_vad(device=local)
+        if os.environ.get("VAD_BENCH_CORPUS_EMPTY_CACHE"):      # diagnostic: hand the previous leg's device blocks back to the driver
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
 
         def one(m):
             rec = PackedRecordings(src, (offs if src is base_i else offs_rand)[:m], lens[:m])
@@ -830,11 +836,14 @@ def run_corpus(args, rank, world, local, dist, passes):
 
     legs = {}
     main_mode = os.environ.get("VAD_BENCH_CORPUS_UPLOAD", "window")
+    short = min(len(lens), 3 * R)
+    if os.environ.get("VAD_BENCH_CORPUS_PRELEG"):               # diagnostic: one short leg BEFORE the main one (order dependence)
+        pre = os.environ["VAD_BENCH_CORPUS_PRELEG"]
+        legs[f"pre_{pre}"], _ = run_leg(base_i, "buckets", pre, short, False)
     legs["main"], res = run_leg(base_i, "buckets", main_mode, len(lens), True)
     parity = None
     if not args.no_parity:
         parity = corpus_parity_sample(model, gids, lens, offs, base_i, res["counts"], res["segs"], sr)
-    short = min(len(lens), 3 * R)
     if not args.corpus_main_only:                               # the other ingest routes on 3 passes' worth, for comparison
         for other in ("window", "gather", "dma"):
             if other != main_mode:

@@ -241,14 +241,14 @@ long vad_iterator_feed(const float *probs, const uint8_t *active, long n, int wi
  * (examples/cpp/silero-vad-onnx.cpp:335-390; Python: src/silero_vad/utils_vad.py:507-549 VADIterator.__call__), for thousands of
  * streams at once.  The pump owns: a page-locked ingest ring [ring_slots][streams][N] int16 that the audio sources write
  * into, the device batch (double-buffered), the carried (h, c) and context of every stream in HBM, the iterator state of every
- * stream, two HIP streams (copies / kernels) and the events that order them (csrc/pump.hip has the schedule: part k + 1's H2D
- * runs beside part k's kernel BY EVENT, tick t + 1's copies behind tick t's, nothing left to hardware-queue assignment).
+ * stream, three HIP streams (copies of even / odd ticks, kernels) and the events that order them (csrc/pump.hip has the schedule:
+ * tick t + 1's H2D runs beside tick t's kernel BY EVENT, nothing left to hardware-queue assignment).
  * One caller thread drives submit / poll; any thread may write a ring slot that is not in flight.                          */
 typedef struct vad_pump vad_pump;
 typedef struct vad_pump_params {
     int    sampling_rate;            /* 8000 | 16000                                                                         */
     int    streams;                  /* live streams (slots) on this GPU                                                     */
-    int    parts;                    /* sub-batches per tick (<= 0: 2)                                                       */
+    int    parts;                    /* sub-batches per tick, each its own copy and kernel (<= 0: 1)                         */
     int    ring_slots;               /* ticks of audio the ingest ring holds (<= 0: 4; at least 2)                           */
     double threshold;                /* VADIterator arguments and defaults (utils_vad.py:477-498): 0.5                       */
     int    min_silence_duration_ms;  /* 100                                                                                  */
@@ -294,9 +294,10 @@ int  vad_pump_state(vad_pump *p, int stream, float *h, float *c, float *ctx);
  * period `period` samples (a multiple of N): at tick t its chunk is rows[b * ld + (t * N) % period ...].  `fill_threads` SOURCE
  * threads (0: min(8, vad_host_threads() - 2); < 0: the sources are silent, the slots keep their content -- isolates the device
  * side) each own a range of streams and WRITE their chunks into ring slot t % ring_slots for t = first_tick ... first_tick +
- * n_ticks - 1, at most `depth` ticks ahead of the retired ones; the calling thread submits a tick once it is completely written
- * and, once `depth` ticks are in flight (clamped to 1 ... ring_slots - 1), retires the oldest.  depth 1 = strictly one tick at a
- * time: tick_ms_* is then the latency of one tick, slot written -> events on the host.  All events are appended to `out` (at most
+ * n_ticks - 1; the calling thread submits a tick once it is completely written and, once `depth` ticks are in flight (clamped to
+ * 1 ... ring_slots - 1), retires the oldest.  depth 1 = strictly one tick at a time (the next chunks are written after the
+ * previous tick's events are out): tick_ms_* is then the latency of one tick, slot written -> events on the host; depth >= 2: the
+ * sources write the next tick while `depth` ticks are in flight.  All events are appended to `out` (at most
  * cap; the return value is their number) and `st` (may be NULL) is filled in (fill_ms_mean: per source thread and tick).          */
 long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long first_tick, long n_ticks, int depth, int fill_threads,
                    vad_iter_event *out, long cap, vad_pump_stats *st);

@@ -6,12 +6,15 @@
 // src/silero_vad/utils_vad.py:507-549) -- for thousands of streams in lock step.
 //
 // Overlap is EXPLICIT, not left to which hardware queue the runtime hands a stream:
-//   * two named HIP streams.  `copy` carries nothing but the H2D copies of the ticks, back to back, in tick order -- the link is the
-//     scarce resource (8.4 MB per tick of 8 192 16 kHz streams, 146 us at 57 GB/s, against ~80 us of kernel).  `compute` carries
-//     nothing but the step kernels, in tick order (the carried state demands that order anyway);
-//   * a tick is cut into `parts` sub-batches of whole 16-stream tiles.  Part k's kernel waits for part k's copy BY EVENT
-//     (h2d_done[buffer][k]); part k + 1's copy is already running beside it.  Across ticks the same: tick t + 1's first copy starts
-//     as soon as tick t's last copy has left the link;
+//   * three named HIP streams.  `copy[0]` / `copy[1]` carry nothing but the H2D copies of the even / odd ticks -- the link is the
+//     scarce resource (8.4 MB per tick of 8 192 16 kHz streams, 146 us at 57 GB/s, against ~66 us of kernel).  `compute` carries
+//     nothing but the step kernels, in tick order (the carried state demands that order anyway).  Two copy streams because a copy
+//     engine leaves the link idle for ~17 us between two dependent copies of ONE stream (measured: profiles/r05_pump.md, 0.80 of the
+//     link with two copies per tick on one stream); copies of consecutive ticks have no dependence on each other, and with two or more
+//     ticks in flight the second engine's copy is already moving while the first one's successor is being set up;
+//   * a tick may be cut into `parts` sub-batches of whole 16-stream tiles.  Part k's kernel waits for part k's copy BY EVENT
+//     (h2d_done[buffer][k]); part k + 1's copy is already running beside it.  One part is the default: a second copy costs another
+//     setup gap and buys ~15 us of latency;
 //   * the device batch is double-buffered ([2][streams][N] int16): tick t + 2's copies wait BY EVENT for tick t's kernels
 //     (batch_free[buffer]) before they overwrite what those read;
 //   * the context is ping-ponged between two device buffers (vad_step_split: the kernel writes the next context beside the one it
@@ -46,7 +49,7 @@ struct vad_pump {
     int16_t *d_pcm = nullptr;                    // [2][streams][N]   device batch, double-buffered
     float *d_ctx[2] = {nullptr, nullptr};        // [streams][C]      ping-pong
     std::vector<float *> d_state;                // per part: [2][hi - lo][128]
-    hipStream_t copy = nullptr, compute = nullptr;
+    hipStream_t copy[2] = {nullptr, nullptr}, compute = nullptr;    // copy[t & 1]: the copies of tick t
     std::vector<hipEvent_t> h2d_done[2];         // [buffer][part]
     hipEvent_t batch_free[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> tick_done;           // [R]
@@ -97,7 +100,8 @@ const char *vad_pump_last_error(const vad_pump *p) { return p ? p->err.c_str() :
 void vad_pump_destroy(vad_pump *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    if (p->copy) (void)hipStreamSynchronize(p->copy);
+    for (hipStream_t cs : p->copy)
+        if (cs) (void)hipStreamSynchronize(cs);
     if (p->compute) (void)hipStreamSynchronize(p->compute);
     for (int b = 0; b < 2; ++b) {
         for (hipEvent_t ev : p->h2d_done[b]) (void)hipEventDestroy(ev);
@@ -109,7 +113,8 @@ void vad_pump_destroy(vad_pump *p) {
     if (p->d_pcm) (void)hipFree(p->d_pcm);
     if (p->h_pcm) (void)hipHostFree(p->h_pcm);
     if (p->h_prob) (void)hipHostFree(p->h_prob);
-    if (p->copy) (void)hipStreamDestroy(p->copy);
+    for (hipStream_t cs : p->copy)
+        if (cs) (void)hipStreamDestroy(cs);
     if (p->compute) (void)hipStreamDestroy(p->compute);
     if (p->eng) vad_destroy(p->eng);
     delete p;
@@ -139,7 +144,7 @@ int vad_pump_create(vad_engine *e, const vad_pump_params *prm, vad_pump **out) {
     if (p->device < 0 || vad_clone(e, &p->eng) != VAD_OK) return bail(VAD_ERR_NO_DEVICE);
     // parts of whole 16-stream tiles (a tile is the kernels' unit; rows of a part start 16-byte aligned)
     const int tiles = (p->streams + 15) / 16;
-    const int parts = std::max(1, std::min(prm->parts > 0 ? prm->parts : 2, tiles));
+    const int parts = std::max(1, std::min(prm->parts > 0 ? prm->parts : 1, tiles));
     for (int k = 0; k < parts; ++k) {
         const int a = std::min(p->streams, (int)((long)tiles * k / parts) * 16), b = std::min(p->streams, (int)((long)tiles * (k + 1) / parts) * 16);
         if (b > a) {
@@ -172,7 +177,8 @@ int vad_pump_create(vad_engine *e, const vad_pump_params *prm, vad_pump **out) {
         if (hipMemset(st, 0, bytes) != hipSuccess) return bail(VAD_ERR_HIP);
         maxB = std::max(maxB, p->hi[k] - p->lo[k]);
     }
-    if (hipStreamCreateWithFlags(&p->copy, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&p->copy[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->copy[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->compute, hipStreamNonBlocking) != hipSuccess)
         return bail(VAD_ERR_HIP);
     auto mk = [&](hipEvent_t *ev) { return hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess; };
@@ -224,12 +230,13 @@ int vad_pump_submit(vad_pump *p, int r) {
     const int16_t *src = p->h_pcm + (size_t)r * S * N;
     const float *ctx_in = p->d_ctx[buf];
     float *ctx_out = p->d_ctx[buf ^ 1];
+    hipStream_t copy = p->copy[buf];
     // the copies may not overwrite the batch buffer before the kernels of two ticks ago have read it
-    if (p->batch_used[buf]) PUMP_TRY(p, hipStreamWaitEvent(p->copy, p->batch_free[buf], 0));
+    if (p->batch_used[buf]) PUMP_TRY(p, hipStreamWaitEvent(copy, p->batch_free[buf], 0));
     for (int k = 0; k < p->parts; ++k) {
         const size_t a = (size_t)p->lo[k], n = (size_t)(p->hi[k] - p->lo[k]);
-        PUMP_TRY(p, hipMemcpyAsync(batch + a * N, src + a * N, n * N * sizeof(int16_t), hipMemcpyHostToDevice, p->copy));
-        PUMP_TRY(p, hipEventRecord(p->h2d_done[buf][k], p->copy));
+        PUMP_TRY(p, hipMemcpyAsync(batch + a * N, src + a * N, n * N * sizeof(int16_t), hipMemcpyHostToDevice, copy));
+        PUMP_TRY(p, hipEventRecord(p->h2d_done[buf][k], copy));
     }
     for (int k = 0; k < p->parts; ++k) {
         const size_t a = (size_t)p->lo[k];
@@ -315,9 +322,9 @@ int vad_pump_state(vad_pump *p, int stream, float *h, float *c, float *ctx) {
 // WRITES their chunks into the tick's ring slot (rows -> slot; streaming stores: the data is bound for the DMA engine, not for this
 // core's cache) as soon as the server has room for the tick -- the memory traffic an audio server's receive path causes.  The
 // calling thread is the server loop: wait until the slot is completely written, submit the tick, and once `depth` ticks are in
-// flight retire the oldest (wait, iterator logic, events).  The sources run at most `depth` ticks ahead of the retired ones
-// (depth 1: strictly one tick at a time -- the next chunks are written after the previous tick's events are out, so "written ->
-// events" is the latency of ONE tick; depth >= 2: tick t + 1 is written and copied while tick t computes).
+// flight retire the oldest (wait, iterator logic, events).  depth 1: strictly one tick at a time -- the next chunks are written
+// after the previous tick's events are out, so "written -> events" is the latency of ONE tick.  depth >= 2: the sources write the
+// tick that comes next while `depth` ticks are in flight (they run depth + 1 ticks ahead of the retired ones).
 long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long first_tick, long n_ticks, int depth, int fill_threads,
                    vad_iter_event *out, long cap, vad_pump_stats *st) {
     if (!p) return VAD_PUMP_ERROR;
@@ -331,6 +338,7 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
         return VAD_PUMP_ERROR;
     }
     depth = std::max(1, std::min(depth, p->R - 1));
+    const long ahead = depth == 1 ? 1 : depth + 1;                             // <= R: the slot's previous tick has been retired by then
     const bool silent = fill_threads < 0;        // diagnostic: the sources write nothing (the slots keep their content): device side only
     int nsrc = fill_threads > 0 ? fill_threads : std::max(1, std::min(8, vad::default_host_threads(32) - 2));
     nsrc = std::max(1, std::min(nsrc, (p->streams + 63) / 64));
@@ -344,7 +352,7 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
     auto source = [&](int k) {
         const long b0 = std::min<long>(p->streams, k * per), b1 = std::min<long>(p->streams, b0 + per);
         for (long t = first_tick; t < last; ++t) {
-            while (t - retired.load(std::memory_order_acquire) >= depth) {
+            while (t - retired.load(std::memory_order_acquire) >= ahead) {
                 if (stop.load(std::memory_order_relaxed)) return;
                 std::this_thread::yield();
             }

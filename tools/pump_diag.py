@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--bind", action="store_true")
     ap.add_argument("--trace", action="store_true")
     ap.add_argument("--analyze")
-    ap.add_argument("--parts", type=int, nargs="*", default=[1, 2, 4])
+    ap.add_argument("--parts", type=int, nargs="*", default=[1, 2])
     ap.add_argument("--depths", type=int, nargs="*", default=[1, 2, 3])
     ap.add_argument("--fills", type=int, nargs="*", default=[-1, 4, 8])
     a = ap.parse_args()
