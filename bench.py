@@ -84,6 +84,8 @@ WORK = {
            "front_valu_cycles": 12_500,                # 1 280 packed x 5.4 + 2 144 other x 2.6 (profiles/r02k_8k_summary.md)
            "rec_mfma": 2 * 512 * 128, "front_kernel": "front_f43_kernel<16, float>"},
 }
+NUMA_NODE = {}           # run_corpus / run_stream_host: the NUMA node this rank bound its host side to (per_rank record)
+NATIVE_PINNED = {}       # bytes of page-locked memory held by native objects of this rank (the pump's ring)
 GX_BYTES = 2048          # engine-internal: fp32 LSTM input-gate pre-activations per chunk, written and read once
 
 
@@ -626,7 +628,10 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
     parts = max(1, int(os.environ.get("VAD_BENCH_STREAM_PARTS", "1")))
     rows = np.ascontiguousarray(fixture_rows_i16(sr, cap, period * n))     # real speech: the iterators do produce events
     eng = Engine(device=local)
+    from silero_vad_amd import _lib
+    NUMA_NODE["node"] = _lib.lib().vad_bind_host_to_device(local)   # the ring and the source threads on the GPU's NUMA node
     pump = StreamPump(eng, sr, streams=cap, parts=parts, ring_slots=R)
+    NATIVE_PINNED["bytes"] = max(NATIVE_PINNED.get("bytes", 0), R * cap * (n * 2 + 4))
     tick0 = [0]
 
     def play(nt, depth):
@@ -747,6 +752,7 @@ def run_corpus(args, rank, world, local, dist, passes):
     sr = 16000
     dev = torch.device("cuda", local)
     node = _lib.lib().vad_bind_host_to_device(local)            # staging threads + pinned buffers on the GPU's NUMA node
+    NUMA_NODE["node"] = node
     host_threads = _lib.lib().vad_host_threads()
     model = load_silero_vad(device=local)
     if os.environ.get("VAD_BENCH_REC_FORM"):                # A/B of the recurrence's form (results are bit-identical)
@@ -1158,6 +1164,20 @@ def main():
             else:
                 rl["traffic_note"] = f"live PMC pass unavailable ({why}); traffic_profiled is the committed profile's figure"
 
+    if world > 1 and not args.dry:
+        # what every rank of the node held and used, gathered on the host (for the N = 8 rehearsal and the scaling run's record)
+        import resource
+        from silero_vad_amd import _lib, gather_to_rank0
+        hs = torch.cuda.host_memory_stats() if hasattr(torch.cuda, "host_memory_stats") else {}
+        mine = {"rank": rank, "local_rank": local, "host_threads": _lib.lib().vad_host_threads(), "numa_node_bound": NUMA_NODE.get("node"),
+                "torch_pinned_peak_bytes": int(hs.get("allocated_bytes.peak", 0) or 0), "native_pinned_bytes": int(NATIVE_PINNED.get("bytes", 0)),
+                "device_peak_bytes_torch": int(torch.cuda.max_memory_allocated()), "max_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024}
+        per_rank = gather_to_rank0(mine)
+        if rank == 0:
+            out["per_rank"] = per_rank
+            out["node_totals"] = {"pinned_bytes": sum(r["torch_pinned_peak_bytes"] + r["native_pinned_bytes"] for r in per_rank),
+                                  "host_threads": sum(r["host_threads"] for r in per_rank),
+                                  "device_peak_bytes_torch": sum(r["device_peak_bytes_torch"] for r in per_rank)}
     if rank == 0:
         if cpu is not None:
             out["cpu_baseline"] = cpu

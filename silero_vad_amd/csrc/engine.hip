@@ -879,11 +879,29 @@ int vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, lo
         if (n < 2 * ways || (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)) ways = 1;
         if (ways > 1) {
             if (!e->dma_fork) {
-                HIP_TRY(e, hipEventCreateWithFlags(&e->dma_fork, hipEventDisableTiming));
-                for (int k = 0; k < vad_engine::kDmaStreams; ++k) {
-                    HIP_TRY(e, hipStreamCreateWithFlags(&e->dma_stream[k], hipStreamNonBlocking));
-                    HIP_TRY(e, hipEventCreateWithFlags(&e->dma_join[k], hipEventDisableTiming));
+                // everything is created into locals and published only when complete (dma_fork, the "ready" flag, last): a failure
+                // half way leaves the engine as it was -- the next call tries again -- instead of with null streams / events behind a
+                // set flag.  (The side streams and events are per engine: one thread per engine, like every other call.)
+                hipStream_t st[vad_engine::kDmaStreams] = {};
+                hipEvent_t join[vad_engine::kDmaStreams] = {}, fork = nullptr;
+                bool ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+                for (int k = 0; ok && k < vad_engine::kDmaStreams; ++k)
+                    ok = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) == hipSuccess &&
+                         hipEventCreateWithFlags(&join[k], hipEventDisableTiming) == hipSuccess;
+                if (!ok) {
+                    for (int k = 0; k < vad_engine::kDmaStreams; ++k) {
+                        if (st[k]) (void)hipStreamDestroy(st[k]);
+                        if (join[k]) (void)hipEventDestroy(join[k]);
+                    }
+                    if (fork) (void)hipEventDestroy(fork);
+                    (void)hipGetLastError();
+                    return fail(e, VAD_ERR_HIP, "vad_upload_rows: cannot create the side streams of the per-row DMA route");
                 }
+                for (int k = 0; k < vad_engine::kDmaStreams; ++k) {
+                    e->dma_stream[k] = st[k];
+                    e->dma_join[k] = join[k];
+                }
+                e->dma_fork = fork;
             }
             HIP_TRY(e, hipEventRecord(e->dma_fork, stream));         // behind the fill (and whatever the caller queued before)
             for (int k = 0; k < ways; ++k) HIP_TRY(e, hipStreamWaitEvent(e->dma_stream[k], e->dma_fork, 0));

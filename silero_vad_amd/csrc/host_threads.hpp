@@ -79,8 +79,11 @@ inline int default_host_threads(int cap) {
 // per engine, but the pool is process-wide).
 //
 // fork(): only the forking thread exists in the child, the workers do not.  pthread_atfork handlers take both mutexes around the
-// fork (so the child never inherits one held by a thread that is not there) and mark the child's copy of the pool; the child drops
-// the stale thread handles (detach: nothing to join) before its first run and in its destructor, and grows a pool of its own.
+// fork (so the child never inherits one held by a thread that is not there) and mark the child's copy of the pool; the child LEAKS
+// the stale thread handles (they name threads of the parent: joining or detaching them is undefined, forgetting them is not) before
+// its first run and in its destructor, and grows a pool of its own.  Consequences a host should know: a fork() issued while another
+// thread is inside a long run() waits for that run; and the handlers can never be unregistered, so the library must not be
+// dlclose()d -- it is linked with -z nodelete (__graft_entry__.build) so that a dlclose() leaves it mapped.
 class HostPool {
 public:
     static HostPool &get() {
@@ -152,7 +155,8 @@ private:
     }
     void drop_stale() {
         if (!forked_) return;
-        for (auto &t : threads_) t.detach();    // handles of threads that do not exist here: nothing to join
+        // handles of threads that do not exist in this process: moved into a heap object that is never destroyed
+        new std::vector<std::thread>(std::move(threads_));
         threads_.clear();
         forked_ = false;
     }

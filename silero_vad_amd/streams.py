@@ -436,20 +436,26 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     # kernel_rec.hip) beside the other lane's frontend.  The matrix-vector form of the recurrence (kernel_rec_small.hip) finishes a
     # bucket of a few hundred recordings 2-3 x sooner but spreads it over the whole chip, with nothing left to overlap with: the
     # pipelined corpus runs 4 % (window route) to 30 % (gather kernel) slower with it.  Lanes therefore pin the MFMA form.
-    rec_form_before = []
     import os as _os
     lane_form = _os.environ.get("SILERO_VAD_AMD_LANE_REC", "mfma")     # (A/B: "auto" lets the lanes take the matrix-vector form)
+    lane_engines = []
     if len(lane_list) > 1 and lane_form != "auto":
-        for lane_model, _ in lane_list:
-            eng_l = getattr(lane_model, "engine", None)
-            if eng_l is not None and hasattr(eng_l, "set_transient"):
-                rec_form_before.append((eng_l, eng_l.options.get("rec_form", "auto")))
+        lane_engines = [e for e in (getattr(m, "engine", None) for m, _ in lane_list) if e is not None and hasattr(e, "set_transient")]
+    pinned = {}                                            # engine -> the value it had when the pin was applied
 
     def pin_lanes(on):
         """The pin holds only while this generator runs: it is taken back before every `yield` (the caller's own engine is lane 0;
-        a consumer that never exhausts the generator must not be left with the slower form) and re-applied on resumption."""
-        for eng_l, form in rec_form_before:
-            eng_l.set_transient("rec_form", lane_form if on else form)
+        a consumer that never exhausts the generator must not be left with the slower form) and re-applied on resumption.  The
+        value to restore is sampled EVERY time the pin goes on (the consumer may have changed the option between two yields), and
+        it is restored only if the option still holds the pinned value (a change made while pinned is the consumer's and stays)."""
+        for eng_l in lane_engines:
+            if on:
+                pinned[id(eng_l)] = eng_l.options.get("rec_form", "auto")
+                eng_l.set_transient("rec_form", lane_form)
+            elif id(eng_l) in pinned:
+                before = pinned.pop(id(eng_l))
+                if eng_l.options.get("rec_form", "auto") == before:      # (set_transient does not touch .options)
+                    eng_l.set_transient("rec_form", before)
 
     pin_lanes(True)
 

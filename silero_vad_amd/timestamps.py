@@ -268,3 +268,16 @@ def read_audio(path: str, sampling_rate: int = 16000) -> torch.Tensor:
                              "(resampling is not available in this build)")
         pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).reshape(-1, w.getnchannels())
     return torch.from_numpy(pcm.astype(np.float32).mean(axis=1) / 32768.0)
+
+
+def save_audio(path: str, tensor: torch.Tensor, sampling_rate: int = 16000):
+    """float tensor in [-1, 1] -> PCM16 mono WAV (the reference writes through torchaudio, utils_vad.py:175-191; same file)."""
+    import wave
+
+    import numpy as np
+    pcm = (tensor.detach().cpu().reshape(-1).numpy() * 32768.0).clip(-32768, 32767).astype(np.int16)
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sampling_rate)
+        w.writeframes(pcm.tobytes())

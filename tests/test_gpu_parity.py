@@ -1011,9 +1011,11 @@ def test_enc0_winograd_and_direct_agree(model_ab, oracle, golden, tag):
     real speech at full level, on QUIET speech (x 1e-3: the level at which the Winograd transform loses most against the
     direct form, tests/study_winograd_numerics.py), on the synthetic mix and on the adversarial inputs; and they must
     agree with each other to fp32 round-off, gate pre-activations included.  The one input for which the state bound is
-    wider is the denormal-level row (|pcm| ~ 1e-39, outside anything a 16-bit source can produce): there two fp32
+    special is the denormal-level row (|pcm| ~ 1e-39, outside anything a 16-bit source can produce): there two fp32
     evaluations in different summation orders differ by up to ~1.1e-4 relative in the cell state, the direct form
-    included; it is held to 3e-4, stated here, and its probabilities to the TIGHT bound like everything else."""
+    included.  No wider constant is used for it: engine AND oracle are measured against a float64 evaluation of the network and
+    the engine must be inside 1e-4 of float64 or no further from it than the oracle is (state_vs_float64; figures in
+    gpurun_out/state_rows.json, kept as profiles/r05_state_rows.md); its probabilities are held to TIGHT like everything else."""
     model = model_ab
     sr = SRS[tag]
     n = chunk_of(sr)
@@ -1028,6 +1030,7 @@ def test_enc0_winograd_and_direct_agree(model_ab, oracle, golden, tag):
     contract[off + names.index("denormal_level")] = False
     want, wctx, wst = oracle.forward_audio(rows, sr)
     res = {}
+    rec64 = []
     for algo in ("winograd", "winograd2", "direct"):
         eng.set_option("enc0", algo)
         try:
@@ -1040,12 +1043,16 @@ def test_enc0_winograd_and_direct_agree(model_ab, oracle, golden, tag):
             eng.set_option("enc0", "winograd")
         assert np.abs(probs - want).max() < TIGHT, algo
         assert np.array_equal(ctx, wctx), algo
-        # the PRODUCT form is held to the 1e-4 state bound on every input inside the contract; the superseded A/B forms
-        # (test build only) to 3e-4: F(2,3) measures 1.4e-4 on the 1e-5-level noise row
-        bound = TOL if algo == "winograd" else 3e-4
-        assert state_err(st[:, contract], wst[:, contract]) < bound, (algo, "state, inputs inside the contract")
-        assert state_err(st[:, ~contract], wst[:, ~contract]) < 3e-4, (algo, "state, denormal-level row")
+        # the PRODUCT form is held to the 1e-4 state bound against the oracle on every input inside the contract; the superseded A/B forms
+        # (test build only) F(2,3) measures 1.4e-4 against the oracle on the 1e-5-level noise row: both are held against FLOAT64 instead
+        if algo == "winograd":
+            assert state_err(st[:, contract], wst[:, contract]) < TOL, (algo, "state, inputs inside the contract")
+        else:
+            state_vs_float64(model, rows[contract], sr, st[:, contract], wst[:, contract], label=f"{tag} {algo} contract rows", record=rec64)
+        # the denormal-level row: engine and oracle against float64 (no constant wider than the contract: state_vs_float64)
+        state_vs_float64(model, rows[~contract], sr, st[:, ~contract], wst[:, ~contract], label=f"{tag} {algo} denormal-level row", record=rec64)
         res[algo] = (probs, gx, gq)
+    _dump_state_rows(rec64, f"enc0_forms_{tag}")
     for algo in ("winograd", "winograd2"):
         dmax = np.abs(res[algo][0] - res["direct"][0]).max(1)          # (each form is within TIGHT of the oracle)
         assert dmax.max() < TIGHT, (algo, float(dmax.max()), int(dmax.argmax()))
@@ -1820,14 +1827,18 @@ class _F64Net:
             a = torch.relu(u.permute(0, 2, 1, 3).reshape(N, To, Cin * 3) @ wt.reshape(wt.shape[0], Cin * 3).T + bs).transpose(1, 2)
         return a[:, :, 0] @ self.w_ih.T + self.b
 
-    def audio_forward(self, rows, slab=16):
-        """rows [B, T n] float32 on the device -> (probs [B, T], state [2, B, 128]) in float64, zero initial state / context"""
+    def audio_forward(self, rows, slab=16, state=None, ctx=None):
+        """rows [B, T n] float32 on the device -> (probs [B, T], state [2, B, 128]) in float64; zero initial state / context unless given"""
         B, L = rows.shape
         n, C = self.n, self.n // 8
         T = L // n
-        x = torch.cat([torch.zeros((B, C), dtype=torch.float64, device=rows.device), rows.double()], 1)
+        c0 = torch.zeros((B, C), dtype=torch.float64, device=rows.device) if ctx is None else torch.as_tensor(ctx).to(rows.device).double()
+        x = torch.cat([c0, rows.double()], 1)
         h = torch.zeros((B, 128), dtype=torch.float64, device=rows.device)
         c = torch.zeros_like(h)
+        if state is not None:
+            st = torch.as_tensor(state).to(rows.device).double()
+            h, c = st[0].clone(), st[1].clone()
         probs = torch.empty((B, T), dtype=torch.float64, device=rows.device)
         for t0 in range(0, T, slab):
             nt = min(slab, T - t0)
@@ -1840,6 +1851,39 @@ class _F64Net:
                 h = o * torch.tanh(c)
                 probs[:, t0 + k] = torch.sigmoid(torch.relu(h) @ self.w_out + self.b_out)
         return probs, torch.stack([h, c])
+
+
+def state_vs_float64(model, rows, sr, got_state, oracle_state, state=None, ctx=None, label="", record=None):
+    """Which of the two fp32 evaluations is further from float64?  For the carried (h, c) of `rows` (whole chunks): the engine's and the
+    oracle's error against a float64 evaluation of the network (_F64Net), in the state_err metric.  The engine passes if it is inside
+    the 1e-4 contract against float64, or no further from float64 than 1.5 x the oracle is (two fp32 summation orders of an
+    ill-conditioned entry: neither is "the" answer; what must not happen is that the engine is the worse one by a margin).
+    Returns (engine_err, oracle_err) and appends the figures and the worst entry to `record`."""
+    n = chunk_of(sr)
+    x = torch.as_tensor(rows)[:, :(rows.shape[1] // n) * n].contiguous().to(model.device)
+    _, s64 = _F64Net(sr, model.device).audio_forward(x, state=state, ctx=ctx)
+    s64 = s64.cpu().numpy()
+    den = np.maximum(1.0, np.abs(s64))
+    e_eng, e_orc = np.abs(got_state - s64) / den, np.abs(oracle_state - s64) / den
+    k = np.unravel_index(int(e_eng.argmax()), e_eng.shape)
+    fig = {"label": label, "streams": int(rows.shape[0]), "engine_vs_f64": float(e_eng.max()), "oracle_vs_f64": float(e_orc.max()),
+           "engine_vs_oracle": float((np.abs(got_state - oracle_state) / np.maximum(1.0, np.abs(oracle_state))).max()),
+           "worst_engine_entry": {"hc": int(k[0]), "stream": int(k[1]), "unit": int(k[2]), "f64": float(s64[k]), "engine": float(got_state[k]),
+                                  "oracle": float(oracle_state[k]), "oracle_err_there": float(e_orc[k])}}
+    if record is not None:
+        record.append(fig)
+    assert fig["engine_vs_f64"] < TOL or fig["engine_vs_f64"] <= 1.5 * fig["oracle_vs_f64"], fig
+    return fig["engine_vs_f64"], fig["oracle_vs_f64"]
+
+
+def _dump_state_rows(record, name):
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = "gpurun_out/state_rows.json"
+    have = json.load(open(path)) if os.path.exists(path) else {}
+    have[name] = record
+    json.dump(have, open(path, "w"), indent=1)
 
 
 @pytest.mark.parametrize("tag", ["16k", "8k"])
@@ -1910,6 +1954,7 @@ def test_small_batch_recurrence_is_bit_identical(model, oracle, golden, tag):
     n = chunk_of(sr)
     eng = model.engine
     rng = np.random.default_rng(91)
+    rec64 = []
 
     def both(fn):
         out = []
@@ -1929,12 +1974,20 @@ def test_small_batch_recurrence_is_bit_identical(model, oracle, golden, tag):
         (p1, c1, s1), (p2, c2, s2) = both(lambda: run_engine(model, rows, sr, state=st0, ctx=ctx0))
         assert np.array_equal(p1, p2) and np.array_equal(c1, c2) and np.array_equal(s1, s2), (B, T, extra)
         want, wctx, wst = oracle.forward_audio(rows, sr, state=st0, ctx=ctx0)
-        # (random initial states of size 0.3 over up to 1 025 streams: the largest of 2.6e5 state entries sits a little above the
-        #  1e-4 the zero-state contract asks for, whichever form computed it -- the two forms agree to the bit)
-        assert np.abs(p2 - want).max() < TIGHT and np.array_equal(c2, wctx) and state_err(s2, wst) < (TOL if B <= 64 else 3e-4)
+        # (random initial states of size 0.3 over up to 1 025 streams: the largest of 2.6e5 state entries sits a little above 1e-4
+        #  AGAINST THE ORACLE -- so both are measured against float64, state_vs_float64: no constant above the contract)
+        assert np.abs(p2 - want).max() < TIGHT and np.array_equal(c2, wctx)
+        if B <= 64:
+            assert state_err(s2, wst) < TOL
+        elif extra == 0:
+            state_vs_float64(model, rows, sr, s2, wst, state=st0, ctx=ctx0, label=f"{tag} B={B} T={T} random carried state", record=rec64)
+        else:       # (a ragged tail: the float64 net takes whole chunks -- pad like the engine does)
+            padded = np.pad(rows, ((0, 0), (0, (T + 1) * n - rows.shape[1])))
+            state_vs_float64(model, padded, sr, s2, wst, state=st0, ctx=ctx0, label=f"{tag} B={B} T={T}+tail random carried state", record=rec64)
         x16 = torch.from_numpy((rows * 32768.0).clip(-32768, 32767).astype(np.int16))
         (q1, _, t1), (q2, _, t2) = both(lambda: run_engine(model, x16, sr))
         assert np.array_equal(q1, q2) and np.array_equal(t1, t2)
+    _dump_state_rows(rec64, f"small_batch_recurrence_{tag}")
     # time slabs (a scratch cap that cuts the 300 steps into pieces) are transparent to it too
     rows = rolled_rows(g["wav"], 1, 300 * n, 977)
     eng.set_option("gx_cap_mib", 1)
@@ -2025,7 +2078,7 @@ def test_nonfinite_input_matches_reference(model, model_ab, oracle, golden, tag)
             finally:
                 for k in opts:
                     eng_model.engine.set_option(k, _NF_DEFAULTS[k])
-            tol = (1e-4, 3e-4) if label == "bf16x9" else (TIGHT, TOL)
+            tol = (TOL, TOL) if label == "bf16x9" else (TIGHT, TOL)
             check_nonfinite(g, p, st, after, *tol)
             assert not np.isnan(pc).any() and not np.isnan(stc).any(), label
             for b in (0, 5):
@@ -2187,3 +2240,53 @@ def test_pump_rejects_bad_arguments(model):
     assert L.vad_pump_poll(pump._h, 1, None, 0, None) == -1    # VAD_PUMP_IDLE
     assert L.vad_pump_slot(pump._h, 5) is None and L.vad_pump_probs(pump._h, -1) is None
     pump.close()
+
+
+# ---- (26) the wider reference goldens (make_golden.py extended()): quiet speech, decimated fixture, 48 kHz front door, sr switching ------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_quiet_speech_goldens(model, golden, tag):
+    """The fixtures at gain 0.1 and 0.01 (small magnitudes, probabilities in the steep part of the sigmoid): probabilities, final
+    state and get_speech_timestamps against what the reference itself produced."""
+    from silero_vad_amd import get_speech_timestamps
+    sr, g = SRS[tag], golden[tag]
+    for gt, rec in golden["ext"][tag]["gain"].items():
+        q = torch.from_numpy((g["wav"] * np.float32(rec["gain"])).astype(np.float32))
+        probs = model.audio_forward(q, sr).numpy()[0]
+        err = np.abs(probs - g[f"probs_{gt}"]).max()
+        assert err < TIGHT, (gt, err)
+        assert state_err(model._state.cpu().numpy(), g[f"state_{gt}"]) < TOL, gt
+        assert get_speech_timestamps(q, model, sampling_rate=sr) == rec["out"], gt
+
+
+def test_decimated_fixture_and_48k_front_door(model, golden):
+    """test.wav[::2] through the 8 kHz net (the reference's own harness runs this input: examples/onnx_sequence/README.md:61), and
+    get_speech_timestamps(..., sampling_rate=48000) on the fixture repeated 3x (x[::3] is the fixture: utils_vad.py:301-305)."""
+    from silero_vad_amd import get_speech_timestamps
+    mz, wav = golden["misc"], golden["16k"]["wav"]
+    dec = torch.from_numpy(np.ascontiguousarray(wav[::2]))
+    probs = model.audio_forward(dec, 8000).numpy()[0]
+    assert np.abs(probs - mz["probs_decim"]).max() < TIGHT
+    assert state_err(model._state.cpu().numpy(), mz["state_decim"]) < TOL
+    assert np.array_equal(model._context.cpu().numpy(), mz["ctx_decim"])
+    assert len(kat_segments(probs)) == golden["ext"]["decim_16k_to_8k"]["kat_segments_thr05_min8"]
+    assert get_speech_timestamps(dec, model, sampling_rate=8000) == golden["ext"]["decim_16k_to_8k"]["out"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = get_speech_timestamps(torch.from_numpy(np.repeat(wav, 3)), model, sampling_rate=48000)
+    assert got == golden["ext"]["16k"]["sr48000"]["out"] and len(got) == 19
+
+
+def test_sample_rate_switch_resets_like_the_reference(model, golden):
+    """A 4-stream batch whose calls alternate between the nets: the reference resets state and context whenever sr changes between
+    calls (JIT!/vad/model/vad_annotator.py:37-57); every call's probabilities against the reference's."""
+    mz = golden["misc"]
+    model.reset_states()
+    cur = {16000: 40 * 512, 8000: 40 * 256}
+    for i, sr in enumerate(int(v) for v in mz["srswitch_plan"]):
+        n = chunk_of(sr)
+        wav = golden["16k" if sr == 16000 else "8k"]["wav"]
+        x = np.stack([np.roll(wav, -b * 7919)[cur[sr]: cur[sr] + n] for b in range(4)])
+        cur[sr] += n
+        got = model(torch.from_numpy(x), sr).cpu().numpy()[:, 0]
+        assert np.abs(got - mz["srswitch_probs"][i]).max() < TIGHT, (i, sr)
+    assert state_err(model._state.cpu().numpy(), mz["srswitch_state"]) < TOL

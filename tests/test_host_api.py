@@ -66,3 +66,28 @@ def test_get_speech_timestamps_argument_errors(built):
     assert get_speech_timestamps(torch.zeros(0), Dummy()) == []
 
 
+def test_hubconf_contract(built, tmp_path):
+    """torch.hub entry (reference hubconf.py:26-56): `silero_vad()` -> (model, utils) with the reference's five utils in its order;
+    without a GPU the model refuses loudly (no CPU fallback), the utils and the argument check work."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("hubconf", Path(__file__).resolve().parents[1] / "hubconf.py")
+    hub = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hub)
+    assert "torch" in hub.dependencies
+    with pytest.raises(Exception, match="Available ONNX opset_version"):
+        hub.silero_vad(onnx=True, opset_version=14)
+    if torch.cuda.is_available():
+        model, utils = hub.silero_vad()
+        assert model.sample_rates == [8000, 16000]
+    else:
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            hub.silero_vad()
+        from silero_vad_amd import VADIterator, collect_chunks, get_speech_timestamps, read_audio, save_audio
+        utils = (get_speech_timestamps, save_audio, read_audio, VADIterator, collect_chunks)
+    assert [u.__name__ for u in utils] == ["get_speech_timestamps", "save_audio", "read_audio", "VADIterator", "collect_chunks"]
+    x = 0.5 * torch.sin(torch.arange(8000) / 15.0)
+    utils[1](str(tmp_path / "a.wav"), x, 8000)
+    y = utils[2](str(tmp_path / "a.wav"), 8000)
+    assert y.shape == x.shape and (x - y).abs().max() < 1.0 / 16384
+    assert torch.equal(utils[4]([{"start": 10, "end": 20}, {"start": 100, "end": 130}], x), torch.cat([x[10:20], x[100:130]]))

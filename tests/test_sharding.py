@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: stream sharding + host-side gather with the gloo backend, world_size 2.
+"""N > 1 path on CPU: stream sharding + host-side gather with the gloo backend, world_size 2 and 8 (the node the scaling run uses).
 The per-rank engine is replaced by a stand-in built on the CPU oracle (tests may use the oracle;
 the product never does) -- what is under test is the partition/gather logic, which has no
 data-path collective."""
@@ -85,7 +85,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_world_size_2_gloo_matches_single_process(built):
+@pytest.mark.parametrize("world", [2, 8])
+def test_world_size_n_gloo_matches_single_process(built, world):
+    """(world 8 over 7 recordings: one rank owns nothing and still takes part in the gather.)"""
     from silero_vad_amd import batch_speech_timestamps, get_speech_timestamps
     audios = _audios()
     single = batch_speech_timestamps(audios, OracleModel(), threshold=0.4)
@@ -97,7 +99,7 @@ def test_world_size_2_gloo_matches_single_process(built):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
@@ -107,9 +109,9 @@ def test_world_size_2_gloo_matches_single_process(built):
     assert got == single
 
 
-@pytest.mark.parametrize("launcher", ["self", "torchrun"])
-def test_bench_multi_gpu_launch_plumbing(launcher):
-    """`bench.py --gpus 2` as the driver may start it -- plain (it re-executes itself under torch.distributed.run)
+@pytest.mark.parametrize("launcher,gpus", [("self", 2), ("torchrun", 2), ("torchrun", 8)])
+def test_bench_multi_gpu_launch_plumbing(launcher, gpus):
+    """`bench.py --gpus N` (N = 2, and 8 as the scaling run starts it) as the driver may start it -- plain (it re-executes itself under torch.distributed.run)
     and under an explicit torch.distributed.run -- with --dry: gloo, no GPU, no VAD work; checks rendezvous on
     127.0.0.1, barrier + MAX-reduce timing, and that exactly one JSON line with n_gpus = 2 comes out of rank 0."""
     import json
@@ -118,7 +120,7 @@ def test_bench_multi_gpu_launch_plumbing(launcher):
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
-    tail = [str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry"]
+    tail = [str(root / "bench.py"), "--gpus", str(gpus), "--steps", "4", "--warmup", "1", "--dry"]
     if launcher == "self":
         cmd = [sys.executable] + tail
     else:
@@ -126,7 +128,7 @@ def test_bench_multi_gpu_launch_plumbing(launcher):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
     env = {k: v for k, v in __import__("os").environ.items()
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -135,11 +137,11 @@ def test_bench_multi_gpu_launch_plumbing(launcher):
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["dry"] is True and d["scaling"] == "weak"
+    assert d["n_gpus"] == gpus and d["steps"] == 4 and d["dry"] is True and d["scaling"] == "weak"
 
 
-def test_bench_corpus_leg_shards_and_gathers_over_two_ranks():
-    """`bench.py --gpus 2 --config corpus --dry`: the corpus leg's multi-rank plumbing on gloo, no GPU -- every pass is dealt
+def test_bench_corpus_leg_shards_and_gathers_over_ranks():
+    """`bench.py --gpus 2 | 8 --config corpus --dry`: the corpus leg's multi-rank plumbing on gloo, no GPU -- every pass is dealt
     out by duration (shard_by_duration), each rank runs its share through the ragged scheduler + native scanner (with a
     stand-in model), rank 0 gathers every recording's segment list exactly once; one JSON line from rank 0."""
     import json
@@ -149,7 +151,7 @@ def test_bench_corpus_leg_shards_and_gathers_over_two_ranks():
     root = Path(__file__).resolve().parents[1]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     res = {}
-    for gpus in (2, 1):
+    for gpus in (8, 2, 1):
         r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(gpus), "--config", "corpus", "--dry"],
                            capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -162,3 +164,5 @@ def test_bench_corpus_leg_shards_and_gathers_over_two_ranks():
     # the corpus of a pass depends on the world size (world x per_pass recordings), so compare per recording: the first
     # rank-0-sized half is not the same set; what must hold is completeness on both and a plausible segment count
     assert res[1]["ids_complete"] is True and res[1]["recordings_gathered"] == 24
+    e = res[8]
+    assert e["n_gpus"] == 8 and e["ids_complete"] is True and e["recordings_gathered"] == e["recordings_total"] == 8 * 24
