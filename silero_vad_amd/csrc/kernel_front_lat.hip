@@ -373,12 +373,11 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     // ---- LSTM input-gate pre-activations of gate w (8 row blocks), stored in D-fragment order ------------------------------------------
     f32x4 Fe[8], G[8];
 #pragma unroll
-    // (read in the order the image wants them: k-group position m carries channels block 7 - m, its four k-steps reversed)
-    for (int m = 0; m < 8; ++m) Fe[m] = rev4(*reinterpret_cast<const f32x4 *>(&febuf[7 - m][ln.lane * 4]));
+    for (int m = 0; m < 8; ++m) Fe[m] = *reinterpret_cast<const f32x4 *>(&febuf[m][ln.lane * 4]);
     poison_into(Fe[0], poison);
     init_bias<8>(G, tab + tb.b_g + 128 * w, ln);
     run_segment<S_IH, 64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
-                             [&](auto kg) VAD_INLINE { return Fe[IC(kg)]; }, gload);
+                             [&](auto kg) VAD_INLINE { return rev4(Fe[7 - IC(kg)]); }, gload);
     if constexpr (!CELL) {
         float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32 + 8 * w) * 256 + ln.lane * 4;
 #pragma unroll
