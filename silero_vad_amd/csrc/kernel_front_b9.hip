@@ -149,7 +149,7 @@ __device__ __forceinline__ void gemm_b(f32x4 (&acc)[M], BF bfun, Ring &r) {
                 asm volatile("" ::: "memory");
                 if constexpr (after >= 2) ring_request(r);
             }
-            if constexpr (i % H == 0) split_step(bp, [&](int e) VAD_INLINE { return bfun(4 * KG - 1 - (kp * 8 + e)); });   // k-steps descending, as the image holds them
+            if constexpr (i % H == 0) split_step(bp, [&](int e) VAD_INLINE { return bfun(kp * 8 + e); });
             static_for<0, 3>([&](auto pc_) VAD_INLINE {
                 constexpr int pa = decltype(pc_)::value, q = st * 3 + pa;
                 u32x4 n0 = r.c0, n1 = r.c1;

@@ -76,8 +76,6 @@ __device__ __forceinline__ void ring_rotate(Ring &r) {
 
 // A segment of M row blocks x KG k-groups ([k-group][row block] blocks, whole units):
 //     acc[m] += A[m][:, k] * B[k][:]   for all 4 KG k-steps;  bfun(s) = B-operand register of k-step s (compile-time s).
-// The image holds a segment's k-steps in DESCENDING order (weights.cpp pack_segment_desc: the largest terms arrive last, the rounding
-// error of the one-accumulator fp32 chain is smallest that way): position i of the segment multiplies bfun(4 KG - 1 - i).
 // A step = 2 row blocks x 4 k-steps = 8 MFMAs; a unit = 8 steps.  The A fragments of step i+1 are read from LDS before
 // the MFMAs of step i are issued; in the middle of every unit the workgroup makes the NEXT unit visible (own share
 // landed -> barrier) and requests the one after it into the slot everyone has left.  AFTER = program units that follow
@@ -113,7 +111,7 @@ __device__ __forceinline__ void gemm_r(f32x4 (&acc)[M], BF bfun, Ring &r) {
             // form the step's four B operands first, then issue its 8 MFMAs back to back -- one switch per step instead of four
             float bv[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) bv[ks] = bfun(4 * KG - 1 - (kg * 4 + ks));       // the image holds the k-steps descending
+            for (int ks = 0; ks < 4; ++ks) bv[ks] = bfun(kg * 4 + ks);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -123,7 +121,7 @@ __device__ __forceinline__ void gemm_r(f32x4 (&acc)[M], BF bfun, Ring &r) {
 #else
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const float bv = bfun(4 * KG - 1 - (kg * 4 + ks));
+                const float bv = bfun(kg * 4 + ks);
                 acc[mp + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.c0[ks], bv, acc[mp + 0], 0, 0, 0);
                 acc[mp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.c1[ks], bv, acc[mp + 1], 0, 0, 0);
             }

@@ -44,8 +44,6 @@ constexpr int kD = VAD_LAT_DEPTH;        // A-fragment prefetch distance, in 1 K
 struct Pipe {
     f32x4 q[kD];
 };
-// the four k-steps of a B-operand register in the order the image holds them (descending: weights.cpp pack_segment_desc)
-__device__ __forceinline__ f32x4 rev4(const f32x4 v) { return f32x4{v[3], v[2], v[1], v[0]}; }
 
 #ifndef VAD_LAT_ABLATE
 #define VAD_LAT_ABLATE 0                 // timing experiments only (wrong results): 1 no A-fragment loads, 2 no FFT
@@ -89,22 +87,20 @@ struct E1Blk {
     int unit, kg, acc, frame, rbg;       // image unit, k-group, 0: out 0 (Z0) 1: out 1 (Z1), STFT frame and global row block of the B operand
 };
 constexpr E1Blk e1_blk(int Q, int idx) {
-    // (kg: the block's POSITION in its unit = its address; the image holds a segment's k-steps descending -- weights.cpp
-    //  pack_segment_desc --, so the k-group it carries, which decides the B operand, is kgo = 3 - kg)
-    const int n = idx / 4, kg = idx % 4, kgo = 3 - kg;
+    const int n = idx / 4, kg = idx % 4;
     if (Q == 32) {
         // per part: [tap1 <- y0 | tap2 <- y1] -> out 0, [tap0 <- y1 | tap1 <- y2] -> out 1, and after every odd part
         // [tap2 <- y3 of part p-1 | tap2 <- y3 of part p] -> out 1; k-groups 0, 1 carry the first tensor's two row blocks
         const int parts[10] = {0, 0, 1, 1, 1, 2, 2, 3, 3, 3}, us[10] = {0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
-        const int p = parts[n], u = us[n], first = kgo < 2;
+        const int p = parts[n], u = us[n], first = kg < 2;
         const int frame = u == 0 ? (first ? 0 : 1) : u == 1 ? (first ? 1 : 2) : 3;
         const int src = u == 2 ? (first ? p - 1 : p) : p;
-        return E1Blk{vadl::w4_e1(p, u, 32), kg, u == 0 ? 0 : 1, frame, 2 * src + (kgo & 1)};
+        return E1Blk{vadl::w4_e1(p, u, 32), kg, u == 0 ? 0 : 1, frame, 2 * src + (kg & 1)};
     }
     // 8 kHz: per part tap1 <- y0, tap2 <- y1 (out 0); tap0 <- y1, tap1 <- y2, tap2 <- y3 (out 1); k-group = the part's row block
     const int p = n / 5, u = n % 5;
     const int fr[5] = {0, 1, 1, 2, 3}, ac[5] = {0, 0, 1, 1, 1};
-    return E1Blk{vadl::w4_e1(p, u, 16), kg, ac[u], fr[u], 4 * p + kgo};
+    return E1Blk{vadl::w4_e1(p, u, 16), kg, ac[u], fr[u], 4 * p + kg};
 }
 
 #ifndef VAD_LAT_WG_PER_CU
@@ -261,9 +257,8 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
         zero<2>(Y3);
         auto seg0 = [&](auto jc, f32x4 (&Y)[2], auto bfun) VAD_INLINE {
             run_segment<IC(jc) * NB0, NB0, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Y[IC(i) & 1]; },
-                                              [&](auto kg) VAD_INLINE {           // position 4 kg + ks carries k-step 4 KG0 - 1 - (4 kg + ks)
-                                                  constexpr int s0 = 4 * KG0 - 1 - 4 * IC(kg);
-                                                  return f32x4{bfun(s0), bfun(s0 - 1), bfun(s0 - 2), bfun(s0 - 3)}; },
+                                              [&](auto kg) VAD_INLINE {
+                                                  return f32x4{bfun(4 * IC(kg)), bfun(4 * IC(kg) + 1), bfun(4 * IC(kg) + 2), bfun(4 * IC(kg) + 3)}; },
                                               gload);
         };
         {   const Coef k = opaque_coef<kF4, kFm3>();
@@ -328,7 +323,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     Z[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e1 + 16 * w + 4 * ln.g);
     Z[1] = Z[0];
     run_segment<S_E1, 40, 1>(pp, [&](auto i) VAD_INLINE -> f32x4 & { constexpr E1Blk eb = e1_blk(Q, IC(i)); return Z[eb.acc]; },
-                             [&](auto i) VAD_INLINE { constexpr E1Blk eb = e1_blk(Q, IC(i)); return rev4(Yall[eb.frame][eb.rbg]); },
+                             [&](auto i) VAD_INLINE { constexpr E1Blk eb = e1_blk(Q, IC(i)); return Yall[eb.frame][eb.rbg]; },
                              gload);
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -347,7 +342,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     f32x4 V1[1];
     V1[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e2 + 16 * w + 4 * ln.g);
     run_segment<S_E2, 8, 1>(pp, [&](auto) VAD_INLINE -> f32x4 & { return V1[0]; },
-                            [&](auto i) VAD_INLINE { return rev4(Zall[IC(i) / 4][3 - IC(i) % 4]); }, gload);
+                            [&](auto i) VAD_INLINE { return Zall[IC(i) / 4][IC(i) % 4]; }, gload);
 #pragma unroll
     for (int r = 0; r < 4; ++r) V1[0][r] = fmaxf(V1[0][r], 0.f);
     *reinterpret_cast<f32x4 *>(&vbuf[w][ln.lane * 4]) = V1[0];
@@ -361,7 +356,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     Fw[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e3 + 32 * w + 4 * ln.g);
     Fw[1] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e3 + 32 * w + 16 + 4 * ln.g);
     run_segment<S_E3, 8, 2>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return Fw[IC(i) & 1]; },
-                            [&](auto kg) VAD_INLINE { return rev4(Vall[3 - IC(kg)]); }, gload);
+                            [&](auto kg) VAD_INLINE { return Vall[IC(kg)]; }, gload);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -377,7 +372,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     poison_into(Fe[0], poison);
     init_bias<8>(G, tab + tb.b_g + 128 * w, ln);
     run_segment<S_IH, 64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
-                             [&](auto kg) VAD_INLINE { return rev4(Fe[7 - IC(kg)]); }, gload);
+                             [&](auto kg) VAD_INLINE { return Fe[IC(kg)]; }, gload);
     if constexpr (!CELL) {
         float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32 + 8 * w) * 256 + ln.lane * 4;
 #pragma unroll

@@ -70,17 +70,6 @@ void pack_segment(float *dst, int M, int KS, F w) {
                 }
 }
 
-// The same, with the segment's k-steps in DESCENDING order: position s of the image holds k-step KS - 1 - s.  The F(4,3) program uses
-// it for every segment: an fp32 MFMA chain rounds once per product-add into ONE accumulator, so the order in which a sum's terms
-// arrive decides its rounding error -- and with the k-steps ascending the terms that are largest for speech (the low-frequency
-// bins of encoder 0, the early channels behind them) come FIRST and every later, smaller term is added at their ulp.  Descending,
-// the gate pre-activations carry 0.5-0.65 of the rounding error (against float64: tools/gx_error_study.py, profiles/r05_state_rows.md;
-// same instructions, same image size).  The kernels index their B operands to match (gemm_r / gemm_b / run_segment providers).
-template <class F>
-void pack_segment_desc(float *dst, int M, int KS, F w) {
-    pack_segment(dst, M, KS, [&](int row, int s, int gg) { return w(row, KS - 1 - s, gg); });
-}
-
 // Winograd image (layout.hpp "Winograd frontend image"): whole units, enc0 as the 4 transformed matrices
 void pack_net_wino(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
     using namespace vadl;
@@ -125,7 +114,7 @@ void pack_net_wino4(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
     auto e1 = [&](int row, int chan, int tau) { return t.ew[1][((size_t)row * 128 + chan) * 3 + tau]; };
     for (int part = 0; part < P; ++part) {
         for (int j = 0; j < 6; ++j)
-            pack_segment_desc(unit(w4_e0(part, j, Q)), RB, Q, [&](int row, int s, int gg) {
+            pack_segment(unit(w4_e0(part, j, Q)), RB, Q, [&](int row, int s, int gg) {
                 const int r = 16 * RB * part + row, bin = 4 * s + kResidue[gg];
                 const double g0 = g_tap(r, bin, 0), g1 = g_tap(r, bin, 1), g2 = g_tap(r, bin, 2);
                 double v = 0;
@@ -143,34 +132,34 @@ void pack_net_wino4(const NetTensors &t, const vadl::Geo &g, PackedNet &p) {
         if (Q == 32) {
             // 8 k-steps per tap: k-steps 0..7 the first tap, 8..15 the second
             const int tapsA[2] = {1, 2}, tapsB[2] = {0, 1};
-            pack_segment_desc(unit(w4_e1(part, 0, Q)), 4, 16, [&](int row, int s, int gg) {
+            pack_segment(unit(w4_e1(part, 0, Q)), 4, 16, [&](int row, int s, int gg) {
                 return e1(row, c0 + chain_chan(s & 7, gg), tapsA[s >> 3]);
             });
-            pack_segment_desc(unit(w4_e1(part, 1, Q)), 4, 16, [&](int row, int s, int gg) {
+            pack_segment(unit(w4_e1(part, 1, Q)), 4, 16, [&](int row, int s, int gg) {
                 return e1(row, c0 + chain_chan(s & 7, gg), tapsB[s >> 3]);
             });
             if (part & 1)
-                pack_segment_desc(unit(w4_e1(part, 2, Q)), 4, 16, [&](int row, int s, int gg) {
+                pack_segment(unit(w4_e1(part, 2, Q)), 4, 16, [&](int row, int s, int gg) {
                     return e1(row, c0 - 32 * (1 - (s >> 3)) + chain_chan(s & 7, gg), 2);
                 });
         } else {
             const int taps[5] = {1, 2, 0, 1, 2};
             for (int i = 0; i < 5; ++i)
-                pack_segment_desc(unit(w4_e1(part, i, Q)), 4, 16, [&](int row, int s, int gg) {
+                pack_segment(unit(w4_e1(part, i, Q)), 4, 16, [&](int row, int s, int gg) {
                     return e1(row, c0 + chain_chan(s, gg), taps[i]);
                 });
         }
     }
     const int T0 = w4_tail0(Q);
     for (int i = 0; i < 2; ++i)
-        pack_segment_desc(unit(T0 + i), 4, 16, [&](int row, int s, int gg) {
+        pack_segment(unit(T0 + i), 4, 16, [&](int row, int s, int gg) {
             return t.ew[2][((size_t)row * 64 + chain_chan(s, gg)) * 3 + 1 + i];
         });
-    pack_segment_desc(unit(T0 + 2), 8, 16, [&](int row, int s, int gg) {           // 2 consecutive units
+    pack_segment(unit(T0 + 2), 8, 16, [&](int row, int s, int gg) {           // 2 consecutive units
         return t.ew[3][((size_t)row * 64 + chain_chan(s, gg)) * 3 + 1];
     });
     for (int q = 0; q < 4; ++q)
-        pack_segment_desc(unit(T0 + 4 + 4 * q), 8, 32, [&](int row, int s, int gg) {  // 4 consecutive units
+        pack_segment(unit(T0 + 4 + 4 * q), 8, 32, [&](int row, int s, int gg) {  // 4 consecutive units
             return t.w_ih[((size_t)(128 * q + row)) * 128 + chain_chan(s, gg)];
         });
 }

@@ -481,11 +481,6 @@ class FrontF43Emu(FrontWinoEmu):
         self.sched = list(range(w4_units(self.Q)))
         self.pu = 0
 
-    def gemm_w(self, acc, bfun, M, KG):
-        """The F(4,3) image holds a segment's k-steps in DESCENDING order (weights.cpp pack_segment_desc): position i multiplies
-        the B operand of k-step 4 KG - 1 - i, as gemm_r does."""
-        super().gemm_w(acc, lambda s: bfun(4 * KG - 1 - s), M, KG)
-
     def run(self, x):
         tb, Q = self.tb, self.Q
         RB, P, KG0 = w_rb(Q), w_parts(Q), Q // 4
