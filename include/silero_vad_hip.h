@@ -329,6 +329,15 @@ int  vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, l
 int  vad_host_register(void *p, size_t bytes);
 int  vad_host_unregister(void *p);
 
+/* Do two streams of the engine's device run BESIDE each other?  The HIP runtime maps streams onto a handful of hardware queues
+ * (GPU_MAX_HW_QUEUES, 4 by default; which stream lands where depends on the order in which the process' streams were first
+ * used), and two streams on one queue execute their kernels one after the other whatever the events say.  A pipeline that wants
+ * its upload kernel beside its compute kernels (vad_upload_rows how = 1 on one stream, vad_forward_audio on another) asks before
+ * it commits to a pair of streams, and takes another stream if the answer is 0 (silero_vad_amd/streams.py does).  Returns 1: a
+ * short kernel on b finished while a ~1 ms kernel on a was still running; 0: it waited for it; < 0: -vad_status.  Synchronises
+ * both streams; costs ~1 ms.                                                                                                */
+int  vad_streams_overlap(vad_engine *e, void *stream_a, void *stream_b);
+
 /* Host threads the native helpers (vad_stage_rows, vad_segment_probs_batch) use by default in THIS process:
  * min(CPU affinity, cgroup CPU quota) / LOCAL_WORLD_SIZE, i.e. the node's CPU budget divided among the one-process-per-GPU
  * ranks torchrun started (SILERO_VAD_AMD_HOST_THREADS overrides).                                                     */

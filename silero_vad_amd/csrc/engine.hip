@@ -745,6 +745,42 @@ int vad_debug_activation(vad_engine *e, int kind, const float *x, float *y, long
     return VAD_OK;
 }
 
+int vad_streams_overlap(vad_engine *e, void *stream_a, void *stream_b) {
+    if (!e) return -VAD_ERR_ARG;
+    if (e->host_only) return -fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    if (a == b) return 0;
+    auto bad = [&](hipError_t rc, const char *what) { return -fail(e, VAD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(rc)); };
+    hipError_t rc;
+    if ((rc = hipSetDevice(e->device)) != hipSuccess) return bad(rc, "hipSetDevice");
+    hipEvent_t t0 = nullptr, ta = nullptr, tb = nullptr;
+    if ((rc = hipEventCreate(&t0)) != hipSuccess || (rc = hipEventCreate(&ta)) != hipSuccess || (rc = hipEventCreate(&tb)) != hipSuccess) {
+        if (t0) (void)hipEventDestroy(t0);
+        if (ta) (void)hipEventDestroy(ta);
+        return bad(rc, "hipEventCreate");
+    }
+    int verdict = -VAD_ERR_HIP;
+    do {
+        if ((rc = hipStreamSynchronize(a)) != hipSuccess || (rc = hipStreamSynchronize(b)) != hipSuccess) break;
+        // ~1 ms of dependent fp32 FMAs in ONE wave on a; then one round of the same kernel on b.  If b has its own hardware queue its
+        // kernel is done long before a's; if the runtime put both streams on one queue, b's kernel starts when a's has ended.
+        if ((rc = hipEventRecord(t0, a)) != hipSuccess) break;
+        if ((rc = vad::launch_foreign_spin(e->img->d_tables[0], 1, 60000, 1, a)) != hipSuccess) break;
+        if ((rc = hipEventRecord(ta, a)) != hipSuccess) break;
+        if ((rc = vad::launch_foreign_spin(e->img->d_tables[0], 1, 1, 1, b)) != hipSuccess) break;
+        if ((rc = hipEventRecord(tb, b)) != hipSuccess) break;
+        if ((rc = hipEventSynchronize(ta)) != hipSuccess || (rc = hipEventSynchronize(tb)) != hipSuccess) break;
+        float ms_a = 0.f, ms_b = 0.f;
+        if ((rc = hipEventElapsedTime(&ms_a, t0, ta)) != hipSuccess || (rc = hipEventElapsedTime(&ms_b, t0, tb)) != hipSuccess) break;
+        verdict = ms_b < 0.5f * ms_a ? 1 : 0;
+    } while (false);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(ta);
+    (void)hipEventDestroy(tb);
+    if (verdict < 0) return bad(rc, "vad_streams_overlap");
+    return verdict;
+}
+
 int vad_debug_foreign_load(vad_engine *e, int kind, int blocks, long iters, void *stream) {
     if (!e || kind < 0 || kind > 1 || blocks < 0 || iters < 0) return VAD_ERR_ARG;
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");

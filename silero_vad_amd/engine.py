@@ -154,6 +154,13 @@ class Engine:
         (vad_upload_rows; how 0: copy engines, 1: gather kernel).  rows / lens: ctypes arrays."""
         self._check(self._L.vad_upload_rows(self._h, rows, lens, n, width, elem_size, dst.data_ptr(), how, self._stream()))
 
+    def streams_overlap(self, a, b) -> bool:
+        """vad_streams_overlap: do kernels on torch streams a and b run beside each other (distinct hardware queues)?"""
+        rc = self._L.vad_streams_overlap(self._h, a.cuda_stream, b.cuda_stream)
+        if rc < 0:
+            self._check(-rc)
+        return rc == 1
+
     def debug_frontend(self, pcm, sr, ctx):
         B, L = pcm.shape
         n = 512 if sr == 16000 else 256

@@ -126,6 +126,25 @@ class _StagePool:
         return i
 
 
+def _distinct_queue_stream(engine, device, others, tries=12):
+    """A torch stream whose kernels demonstrably run BESIDE those of every stream in `others` (vad_streams_overlap).  torch hands out
+    streams from a pool, the HIP runtime maps them onto ~4 hardware queues in the order of their first use, and two streams on one
+    queue serialise: an upload kernel that lands on a compute lane's queue alternates with the lane instead of overlapping it -- the
+    scattered-pinned routes then read half the link (profiles/r05_ingest_queues.md).  Candidates that collide are kept alive until the
+    search is over (a dropped one would be handed out again) and then returned to the pool."""
+    rejected = []
+    st = torch.cuda.Stream(device)
+    if engine is None or not hasattr(engine, "streams_overlap"):
+        return st
+    for _ in range(tries):
+        if all(engine.streams_overlap(o, st) for o in others):
+            break
+        rejected.append(st)
+        st = torch.cuda.Stream(device)
+    STATS["stream_retries"] += len(rejected)
+    return st
+
+
 def _compute_lanes(model, want):
     """[(model, stream)]: lane 0 is the caller's model on the caller's stream; further lanes are CLONES of its engine
     (vad_clone: the same weight images and options, their own scratch -- no second weight copy, no option drift) on
@@ -140,8 +159,8 @@ def _compute_lanes(model, want):
         if sibs is None or getattr(model, "_lane_options", None) != dict(eng.options):
             sibs = model._lane_siblings = []             # the primary's options changed: fresh clones carry the new ones
             model._lane_options = dict(eng.options)
-        while len(sibs) < want - 1:
-            sibs.append((type(model)(engine=eng.clone()), torch.cuda.Stream(model.device)))
+        while len(sibs) < want - 1:             # (each lane on a hardware queue of its own: _distinct_queue_stream)
+            sibs.append((type(model)(engine=eng.clone()), _distinct_queue_stream(eng, model.device, [cur] + [s for _, s in sibs])))
         lanes.extend(sibs[: want - 1])
     return lanes
 
@@ -377,6 +396,8 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     pool = getattr(model, "_stage_pool", None)
     if pool is None or pool.slots != len(lane_list) + 1:
         pool = model._stage_pool = _StagePool(dev, len(lane_list) + 1)
+        # the upload stream beside every compute lane, not in front of one of them
+        pool.stream = _distinct_queue_stream(getattr(model, "engine", None), dev, [st for _, st in lane_list])
     cur = torch.cuda.current_stream(dev)
     direct = src.pinned
     how = 0 if mode == "dma" else 1
@@ -849,9 +870,10 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
     with ctxm:
         if on_gpu:
             pool = getattr(model, "_stage_pool", None)
+            cur = torch.cuda.current_stream(dev)
             if pool is None:
                 pool = model._stage_pool = _StagePool(dev)
-            cur = torch.cuda.current_stream(dev)
+                pool.stream = _distinct_queue_stream(getattr(model, "engine", None), dev, [cur])    # the upload beside the slab's kernels
         STATS["padded"] += plan.padded_chunks() * n
         STATS["real"] += sum(m for m in lengths if m > 0)
 

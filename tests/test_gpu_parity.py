@@ -2303,3 +2303,17 @@ def test_sample_rate_switch_resets_like_the_reference(model, golden):
         got = model(torch.from_numpy(x), sr).cpu().numpy()[:, 0]
         assert np.abs(got - mz["srswitch_probs"][i]).max() < TIGHT, (i, sr)
     assert state_err(model._state.cpu().numpy(), mz["srswitch_state"]) < TOL
+
+
+def test_streams_overlap_probe(model):
+    """vad_streams_overlap: a stream does not overlap itself; among a handful of fresh streams most pairs do (four hardware queues),
+    and _distinct_queue_stream returns one that runs beside the given ones."""
+    from silero_vad_amd.streams import _distinct_queue_stream
+    eng = model.engine
+    cur = torch.cuda.current_stream(model.device)
+    a = torch.cuda.Stream(model.device)
+    assert eng.streams_overlap(a, a) is False
+    st = _distinct_queue_stream(eng, model.device, [cur, a])
+    assert eng.streams_overlap(cur, st) and eng.streams_overlap(a, st)
+    pairs = [(x, y) for x in [torch.cuda.Stream(model.device) for _ in range(6)] for y in [a]]
+    assert sum(eng.streams_overlap(x, y) for x, y in pairs) >= 3

@@ -31,6 +31,16 @@ def main():
         elif name in ("c2", "8k"):
             d = bench.run_batch(args, 16000 if name == "c2" else 8000, 0, 1, 0, dist, 50)
             print(name, d["value"], flush=True)
+        elif name.startswith("sleep"):
+            import time
+            time.sleep(float(name[5:]))
+            print(name, flush=True)
+        elif name == "gc":
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            print("gc + empty_cache", flush=True)
         elif name.startswith("plumbing"):
             bench.run_plumbing(args, 0, 8000 if name.endswith("8k") else 16000)
             print(name, "done", flush=True)
