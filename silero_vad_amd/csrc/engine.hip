@@ -762,11 +762,14 @@ int vad_streams_overlap(vad_engine *e, void *stream_a, void *stream_b) {
     int verdict = -VAD_ERR_HIP;
     do {
         if ((rc = hipStreamSynchronize(a)) != hipSuccess || (rc = hipStreamSynchronize(b)) != hipSuccess) break;
-        // ~1 ms of dependent fp32 FMAs in ONE wave on a; then one round of the same kernel on b.  If b has its own hardware queue its
-        // kernel is done long before a's; if the runtime put both streams on one queue, b's kernel starts when a's has ended.
+        // TWO kernels of ~1 ms of dependent fp32 FMAs in ONE wave each on a (the second carries the in-order barrier of its stream, as
+        // every kernel of a busy pipeline does); then one round of the same kernel on b.  If b has its own hardware queue its kernel is
+        // done long before a's first; if the runtime put both streams on one queue, b's packet sits behind a's second one, which waits
+        // for a's first: head-of-line blocking, exactly what makes an upload kernel alternate with a compute lane.
         if ((rc = hipEventRecord(t0, a)) != hipSuccess) break;
         if ((rc = vad::launch_foreign_spin(e->img->d_tables[0], 1, 60000, 1, a)) != hipSuccess) break;
         if ((rc = hipEventRecord(ta, a)) != hipSuccess) break;
+        if ((rc = vad::launch_foreign_spin(e->img->d_tables[0], 1, 60000, 1, a)) != hipSuccess) break;
         if ((rc = vad::launch_foreign_spin(e->img->d_tables[0], 1, 1, 1, b)) != hipSuccess) break;
         if ((rc = hipEventRecord(tb, b)) != hipSuccess) break;
         if ((rc = hipEventSynchronize(ta)) != hipSuccess || (rc = hipEventSynchronize(tb)) != hipSuccess) break;
