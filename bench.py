@@ -835,6 +835,8 @@ def run_corpus(args, rank, world, local, dist, passes):
              "host_stage_ms": round(st.get("stage_s", 0) * 1e3, 2),
              "host_upload_call_ms": round(st.get("upload_call_s", 0) * 1e3, 2),
              "host_segmenter_ms": round(st.get("scan_s", 0) * 1e3, 2),
+             "host_ms": {k[:-2]: round(st.get(k, 0) * 1e3, 2) for k in ("setup_s", "reserve_s", "slot_wait_s", "slot_alloc_s", "result_wait_s")},
+             "slot_allocs": int(st.get("slot_allocs", 0)), "stream_retries": int(st.get("stream_retries", 0)),
              "d2h_MB": round(st.get("d2h_bytes", 0) / 1e6, 3),
              "buckets": int(st.get("buckets", 0)),
              "padded_over_real_samples": round(st.get("padded", 0) / max(st.get("real", 1), 1), 4)}

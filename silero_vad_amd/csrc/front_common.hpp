@@ -51,6 +51,29 @@ __device__ __forceinline__ void init_bias(f32x4 (&acc)[M], const float *bias_lds
     for (int m = 0; m < M; ++m)
         acc[m] = *reinterpret_cast<const f32x4 *>(bias_lds + 16 * m + 4 * ln.g);
 }
+// acc += bias.  Encoders 0 and 1 start their accumulators from ZERO and take the bias here, behind the last product: a one-accumulator
+// fp32 chain rounds every product-add at the ulp of what the accumulator holds, and a bias of up to 19 held from the start makes that
+// ulp ~1e-6 for all 130-390 adds of the chain whatever the signal's size -- measured against float64 (tools/gx_error_study.py,
+// profiles/r05_state_rows.md), the gate pre-activations carry 5 x more rounding error on quiet speech that way and 1.4 x more on
+// full-level speech than the reference's evaluation order does; with the bias last both are level with it.  (Encoders 2, 3 and W_ih
+// gain nothing measurable and keep the bias in the accumulator's initial value.)
+// (Written like nyq_update below -- two row blocks per round, a scheduling barrier behind each: in any other shape the register
+//  allocator of the 16 kHz kernel, 8 registers under its budget, spills 160.)
+template <int M>
+__device__ __forceinline__ void add_bias(f32x4 (&acc)[M], const float *bias_lds, const Lane &ln) {
+    static_assert(M % 2 == 0, "row blocks in pairs");
+#pragma unroll
+    for (int m = 0; m < M; m += 2) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias_lds + 16 * m + 4 * ln.g);
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias_lds + 16 * (m + 1) + 4 * ln.g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[m][r] += b0[r];
+            acc[m + 1][r] += b1[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 template <int M>
 __device__ __forceinline__ void zero(f32x4 (&acc)[M]) {
 #pragma unroll

@@ -271,8 +271,8 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
 
     // ---- encoder 0 as one F(4,3) tile, encoder 1 fed part by part ----------------------------------------------------------
     f32x4 Z0[4], Z1[4];
-    init_bias<4>(Z0, tab + tb.b_e1, ln);
-    init_bias<4>(Z1, tab + tb.b_e1, ln);
+    zero<4>(Z0);                                           // (the bias comes last: front_common.hpp add_bias)
+    zero<4>(Z1);
 #pragma clang loop unroll(disable)
     for (int it = 0; it < P / PB; ++it) {
         f32x4 Ykeep[RB];                                   // 16 kHz: y3 of the even part waits for the odd part's
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
             const int row0 = 16 * RB * (it * PB + pb);
             const float *wn = tab + tb.w_nyq + row0;       // [tap][row]
             f32x4 Y0[RB], Y1[RB], Y2[RB], Y3[RB];          // m1, m2, m3, m4, then the four frame outputs
-            init_bias<RB>(Y0, tab + tb.b_e0 + row0, ln);
+            zero<RB>(Y0);
             zero<RB>(Y1);
             zero<RB>(Y2);
             zero<RB>(Y3);
@@ -345,6 +345,10 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
             nyq_update<RB>(Y2, xn3, wn + 256, ln);
             nyq_update<RB>(Y3, xn2, wn, ln);
             nyq_update<RB>(Y3, xn3, wn + 128, ln);
+            add_bias<RB>(Y0, tab + tb.b_e0 + row0, ln);
+            add_bias<RB>(Y1, tab + tb.b_e0 + row0, ln);
+            add_bias<RB>(Y2, tab + tb.b_e0 + row0, ln);
+            add_bias<RB>(Y3, tab + tb.b_e0 + row0, ln);
             relu<RB>(Y0);
             relu<RB>(Y1);
             relu<RB>(Y2);
@@ -372,6 +376,8 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
             }
         });
     }
+    add_bias<4>(Z0, tab + tb.b_e1, ln);
+    add_bias<4>(Z1, tab + tb.b_e1, ln);
     relu<4>(Z0);
     relu<4>(Z1);
     VAD_WAVE_STAMP(ln, 10);

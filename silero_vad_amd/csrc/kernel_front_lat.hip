@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
         const int row0 = 32 * w;
         const float *wn = tab + tb.w_nyq + row0;                 // [tap][row]
         f32x4 Y0[2], Y1[2], Y2[2], Y3[2];
-        init_bias<2>(Y0, tab + tb.b_e0 + row0, ln);
+        zero<2>(Y0);                                             // (the bias comes last: front_common.hpp add_bias)
         zero<2>(Y1);
         zero<2>(Y2);
         zero<2>(Y3);
@@ -297,6 +297,10 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
         nyq_update<2>(Y2, xn3, wn + 256, ln);
         nyq_update<2>(Y3, xn2, wn, ln);
         nyq_update<2>(Y3, xn3, wn + 128, ln);
+        add_bias<2>(Y0, tab + tb.b_e0 + row0, ln);
+        add_bias<2>(Y1, tab + tb.b_e0 + row0, ln);
+        add_bias<2>(Y2, tab + tb.b_e0 + row0, ln);
+        add_bias<2>(Y3, tab + tb.b_e0 + row0, ln);
         relu<2>(Y0);
         relu<2>(Y1);
         relu<2>(Y2);
@@ -320,13 +324,14 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
 #pragma unroll
         for (int m = 0; m < 8; ++m) Yall[f][m] = *reinterpret_cast<const f32x4 *>(&ybuf[f][m][ln.lane * 4]);
     f32x4 Z[2];
-    Z[0] = *reinterpret_cast<const f32x4 *>(tab + tb.b_e1 + 16 * w + 4 * ln.g);
+    Z[0] = f32x4{0.f, 0.f, 0.f, 0.f};                            // (the bias comes last: front_common.hpp add_bias)
     Z[1] = Z[0];
     run_segment<S_E1, 40, 1>(pp, [&](auto i) VAD_INLINE -> f32x4 & { constexpr E1Blk eb = e1_blk(Q, IC(i)); return Z[eb.acc]; },
                              [&](auto i) VAD_INLINE { constexpr E1Blk eb = e1_blk(Q, IC(i)); return Yall[eb.frame][eb.rbg]; },
                              gload);
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
+        Z[o] += *reinterpret_cast<const f32x4 *>(tab + tb.b_e1 + 16 * w + 4 * ln.g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Z[o][r] = fmaxf(Z[o][r], 0.f);
         *reinterpret_cast<f32x4 *>(&zbuf[o][w][ln.lane * 4]) = Z[o];

@@ -108,8 +108,11 @@ class _StagePool:
         `dev_bytes` (default: nbytes) of device buffer."""
         i = k % self.slots
         dev_bytes = nbytes if dev_bytes is None else dev_bytes
+        t0 = time.perf_counter()
         if self.done[i] is not None:
             self.done[i].synchronize()
+        STATS["slot_wait_s"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
         if nbytes and (self.host[i] is None or self.host[i].numel() < nbytes):
             self.host[i] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
         if self.dev[i] is None or self.dev[i].numel() < dev_bytes:
@@ -123,6 +126,8 @@ class _StagePool:
             with torch.cuda.stream(self.stream):
                 self.dev[i] = torch.empty(cap, dtype=torch.uint8, device=self.device)
             self.consumed[i] = None
+            STATS["slot_allocs"] += 1
+        STATS["slot_alloc_s"] += time.perf_counter() - t0
         return i
 
 
@@ -365,6 +370,7 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
 
     Ingest: recordings in pinned host memory go straight to the device batch (vad_upload_rows: no host copy);
     pageable ones are packed into pinned staging by the native threaded copy and copied from there."""
+    t_setup = time.perf_counter()
     n = chunk_size(sampling_rate)
     as_i16, lengths = _describe(audios)
     dtype = torch.int16 if as_i16 else torch.float32
@@ -447,9 +453,11 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         shapes = [(len(b), (max(plan.lengths[b[0]], n) + n - 1) // n) for b in plan.buckets]
         big = max(shapes, key=lambda bt: ((bt[0] + 15) // 16) * bt[1])
         wide = max(shapes, key=lambda bt: bt[0])
+        t_res = time.perf_counter()
         for lane_model, _ in lane_list:
             for bt in {big, wide}:
                 lane_model.engine.reserve(sampling_rate, bt[0], bt[1])
+        STATS["reserve_s"] += time.perf_counter() - t_res
     for _, st in lane_list[1:]:
         st.wait_stream(cur)                               # sibling lanes start behind whatever the caller has queued
     copies = []                                           # (start event, end event) of every H2D copy, for STATS
@@ -542,6 +550,7 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             return idxs, outs[0]
         return idxs, outs, probs_dev
 
+    STATS["setup_s"] += time.perf_counter() - t_setup
     try:
         staged = stage(0) if plan.buckets else None
         inflight = []                                     # buckets enqueued and not yet yielded, oldest first
@@ -569,12 +578,16 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             inflight.append((idxs, outs, done, probs))
             while len(inflight) > len(lane_list):
                 first = inflight.pop(0)
+                t_w = time.perf_counter()
                 first[2].synchronize()
+                STATS["result_wait_s"] += time.perf_counter() - t_w
                 pin_lanes(False)
                 yield finish(first)
                 pin_lanes(True)
         for first in inflight:
+            t_w = time.perf_counter()
             first[2].synchronize()
+            STATS["result_wait_s"] += time.perf_counter() - t_w
             pin_lanes(False)
             yield finish(first)
             pin_lanes(True)

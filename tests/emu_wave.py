@@ -491,13 +491,13 @@ class FrontF43Emu(FrontWinoEmu):
         relu = lambda A: np.maximum(A, 0)
         f = f32
         self.pu = 0
-        Z0 = self.init_bias(4, tb.b_e1)
-        Z1 = self.init_bias(4, tb.b_e1)
+        # encoders 0 and 1 accumulate from zero and take the bias behind the last product (front_common.hpp add_bias)
+        Z0 = np.zeros((4, 4, 64), f32)
+        Z1 = np.zeros((4, 4, 64), f32)
         keep = None
         for p in range(P):
             row0 = 16 * RB * p
-            m1 = self.init_bias(RB, tb.b_e0 + row0)
-            m2, m3, m4 = (np.zeros((RB, 4, 64), f32) for _ in range(3))
+            m1, m2, m3, m4 = (np.zeros((RB, 4, 64), f32) for _ in range(4))
             self.gemm_w(m1, lambda s: (X[2][s] + X[3][s]) - f(4) * (X[0][s] + X[1][s]), RB, KG0)
             self.gemm_w(m2, lambda s: (X[3][s] - X[2][s]) + f(4) * (X[0][s] - X[1][s]), RB, KG0)
             self.gemm_w(m3, lambda s: (X[3][s] - X[1][s]) + f(2) * (X[2][s] - X[0][s]), RB, KG0)
@@ -511,7 +511,7 @@ class FrontF43Emu(FrontWinoEmu):
                     src = fr + tau - 1
                     if 0 <= src < 4:
                         self.nyq(Y[fr], xn[src], tau, row0)
-            Y = [relu(y) for y in Y]
+            Y = [relu(y + self.init_bias(RB, tb.b_e0 + row0)) for y in Y]
             if Q == 32:
                 self.gemm_w(Z0, two(Y[0], Y[1]), 4, 4)
                 self.gemm_w(Z1, two(Y[1], Y[2]), 4, 4)
@@ -525,7 +525,7 @@ class FrontF43Emu(FrontWinoEmu):
                 self.gemm_w(Z1, chain(Y[1]), 4, 4)
                 self.gemm_w(Z1, chain(Y[2]), 4, 4)
                 self.gemm_w(Z1, chain(Y[3]), 4, 4)
-        Z0, Z1 = relu(Z0), relu(Z1)
+        Z0, Z1 = relu(Z0 + self.init_bias(4, tb.b_e1)), relu(Z1 + self.init_bias(4, tb.b_e1))
         V = self.init_bias(4, tb.b_e2)
         self.gemm_w(V, chain(Z0), 4, 4)
         self.gemm_w(V, chain(Z1), 4, 4)

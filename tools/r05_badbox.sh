@@ -8,6 +8,7 @@ show() { python - "$1" <<'PY'
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 print({k: (v["fraction_of_pcie_ceiling"], v["wall_s"], v["host_upload_call_ms"]) for k, v in d["legs"].items()})
+print("   gather leg host ms:", d["legs"].get("pinned_gather", {}).get("host_ms"), "slot allocs", d["legs"].get("pinned_gather", {}).get("slot_allocs"))
 PY
 }
 run() { name=$1; shift; env "$@" python bench.py --config corpus --corpus-passes 3 --no-cpu-baseline --no-parity > $out/$name.log 2> $out/$name.err || tail -3 $out/$name.err; echo "$name:"; show $out/$name.log; }
