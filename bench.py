@@ -805,6 +805,12 @@ def run_corpus(args, rank, world, local, dist, passes):
             return np.asarray([len(x) for x in segs]), None
 
         one(min(nrec, 2 * R))                                   # warm-up: pinned buffers, scratch, lanes
+        if sched == "buckets":
+            # ... and everything the FULL plan needs, allocated before the timed region (ragged_reserve: the lanes' scratch for the
+            # largest bucket of all nrec recordings, the staging slots): a scratch growth inside the run is a device synchronisation plus a
+            # multi-GB hipFree / hipMalloc, 1 ms on most boxes and 120-180 ms on others (profiles/r05_ingest_routes.md)
+            S.ragged_reserve(PackedRecordings(src, (offs if src is base_i else offs_rand)[:nrec], lens[:nrec]), model, sr, max_waste=0.1,
+                             max_bytes=int(os.environ.get("VAD_BENCH_BUCKET_BYTES", 1 << 30)))
         S.STATS.clear()
         nseg = []
 

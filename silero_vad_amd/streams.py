@@ -357,7 +357,7 @@ def _stage_into(src: "_Sources", idxs, width, dst: torch.Tensor):
 
 
 def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,
-                   max_bytes: int = 256 << 20, plan: RaggedPlan = None, post=None, meta=None, lanes: int = 2):
+                   max_bytes: int = 256 << 20, plan: RaggedPlan = None, post=None, meta=None, lanes: int = 2, prepare_only: bool = False):
     """Generator over the plan's buckets: yields (indices, probs[len(indices), T_bucket] on the CPU).
     Recording i of a bucket owns the first ceil(len_i / N) entries of its row.
 
@@ -366,7 +366,9 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     the probabilities themselves never leave the GPU (ragged_speech_segments scans them there).  `meta` (indices ->
     small CPU int64 tensor) rides to the GPU with the bucket's PCM on the copy stream (pinned, asynchronous), so that
     nothing in the loop blocks the host on the compute stream.  `lanes`: buckets are issued round-robin to this many
-    engines on their own streams (_compute_lanes); results are yielded in bucket order.
+    engines on their own streams (_compute_lanes); results are yielded in bucket order.  `prepare_only`: plan the run, create the lanes
+    and their streams, size every lane's scratch and the staging slots for the plan's largest bucket -- everything that allocates --
+    and stop (ragged_reserve): a run over the same recordings then allocates nothing.
 
     Ingest: recordings in pinned host memory go straight to the device batch (vad_upload_rows: no host copy);
     pageable ones are packed into pinned staging by the native threaded copy and copied from there."""
@@ -458,6 +460,19 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             for bt in {big, wide}:
                 lane_model.engine.reserve(sampling_rate, bt[0], bt[1])
         STATS["reserve_s"] += time.perf_counter() - t_res
+    if prepare_only:
+        if plan.buckets:
+            big_b = max(plan.buckets, key=lambda b: len(b) * ((max(plan.lengths[b[0]], n) + align - 1) // align * align))
+            nb = len(big_b) * ((max(plan.lengths[big_b[0]], n) + align - 1) // align * align) * esz
+            for k in range(pool.slots):
+                pool.get(k, nb if not direct else 0, nb)
+            if windowed:                                   # the three window buffers: warm torch's allocator with blocks of the largest window
+                wb = max((b - a) * esz for a, b in plan.span)
+                with torch.cuda.stream(win["stream"]):
+                    warm = [torch.empty(max(wb, 1 << 20), dtype=torch.uint8, device=dev) for _ in range(3)]
+                del warm
+        torch.cuda.synchronize(dev)
+        return
     for _, st in lane_list[1:]:
         st.wait_stream(cur)                               # sibling lanes start behind whatever the caller has queued
     copies = []                                           # (start event, end event) of every H2D copy, for STATS
@@ -604,6 +619,16 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         for a, b in copies:
             b.synchronize()
             STATS["h2d_s"] += a.elapsed_time(b) / 1e3
+
+
+def ragged_reserve(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15, max_bytes: int = 256 << 20,
+                   lanes: int = 2):
+    """Everything a `ragged_probs` / `ragged_speech_segments` run over these recordings would allocate -- the compute lanes and their
+    streams, every lane's scratch (vad_reserve: a later growth synchronises the device and, on some boxes, costs 0.1-0.2 s of
+    hipFree / hipMalloc for the multi-GB gx scratch: profiles/r05_ingest_routes.md), the staging slots -- sized for the plan's
+    largest bucket, up front.  Call it once before a corpus run (or a timed region); the run itself then allocates nothing."""
+    for _ in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes, lanes=lanes, prepare_only=True):
+        pass
 
 
 def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste: float = 0.15,

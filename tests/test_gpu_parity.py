@@ -2322,3 +2322,22 @@ def test_streams_overlap_probe(model):
     assert eng.streams_overlap(cur, st) and eng.streams_overlap(a, st)
     pairs = [(x, y) for x in [torch.cuda.Stream(model.device) for _ in range(6)] for y in [a]]
     assert sum(eng.streams_overlap(x, y) for x, y in pairs) >= 3
+
+
+def test_ragged_reserve_makes_the_run_allocation_free(golden):
+    """ragged_reserve sizes the lanes' scratch and the staging slots for the plan's largest bucket up front: the run that follows
+    leaves every lane's scratch generation where it was (no growth = no device synchronisation, no multi-GB hipFree / hipMalloc in the
+    middle of a corpus run) and returns what an unprepared run returns."""
+    from silero_vad_amd import load_silero_vad, ragged_probs, ragged_reserve
+    from silero_vad_amd.streams import _compute_lanes
+    wav = golden["16k"]["wav"]
+    rng = np.random.default_rng(4)
+    lens = rng.integers(3000, 90000, size=60)
+    audios = [torch.from_numpy(wav[i * 9000: i * 9000 + int(m)].copy()) for i, m in enumerate(lens)]
+    m1 = load_silero_vad(device=0)
+    ragged_reserve(audios, m1, 16000, max_bytes=1 << 20)
+    gens = [lm.engine.scratch_generation() for lm, _ in _compute_lanes(m1, 2)]
+    got = ragged_probs(audios, m1, 16000, max_bytes=1 << 20)
+    assert [lm.engine.scratch_generation() for lm, _ in _compute_lanes(m1, 2)] == gens
+    want = ragged_probs(audios, load_silero_vad(device=0), 16000, max_bytes=1 << 20)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
