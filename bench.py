@@ -627,6 +627,14 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
     period = 32                                                 # chunks of audio per stream the sources cycle through (268 MB at 16 kHz)
     parts = max(1, int(os.environ.get("VAD_BENCH_STREAM_PARTS", "1")))
     rows = np.ascontiguousarray(fixture_rows_i16(sr, cap, period * n))     # real speech: the iterators do produce events
+    # Let the device settle behind the previous leg: what that leg freed (engine scratch of its lanes, GBs) is WIPED by the driver on
+    # some boxes -- there a 4 GiB hipMalloc takes 120-360 ms instead of 0.4 (tools/r05_boxes.sh) -- and the wipe runs on the copy
+    # engines this leg's H2D copies need: measured right behind a 20 GB release the pump reads 0.56 of the link and 0.40 ms p95 instead
+    # of 0.87 and 0.19 (profiles/r05_ingest_routes.md section 3).  Untimed, like every leg's warm-up.
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    time.sleep(float(os.environ.get("VAD_BENCH_SETTLE_S", "1.0")))
     eng = Engine(device=local)
     from silero_vad_amd import _lib
     NUMA_NODE["node"] = _lib.lib().vad_bind_host_to_device(local)   # the ring and the source threads on the GPU's NUMA node
