@@ -858,7 +858,7 @@ def run_corpus(args, rank, world, local, dist, passes):
 
     legs = {}
     main_mode = os.environ.get("VAD_BENCH_CORPUS_UPLOAD", "window")
-    short = min(len(lens), 3 * R)
+    short = min(len(lens), 6 * R)       # the comparison legs: 6 passes (0.5 s each: the pipeline's fill and drain, ~20 ms, are 4 % of that)
     if os.environ.get("VAD_BENCH_CORPUS_PRELEG"):               # diagnostic: one short leg BEFORE the main one (order dependence)
         pre = os.environ["VAD_BENCH_CORPUS_PRELEG"]
         legs[f"pre_{pre}"], _ = run_leg(base_i, "buckets", pre, short, False)
@@ -866,7 +866,7 @@ def run_corpus(args, rank, world, local, dist, passes):
     parity = None
     if not args.no_parity:
         parity = corpus_parity_sample(model, gids, lens, offs, base_i, res["counts"], res["segs"], sr)
-    if not args.corpus_main_only:                               # the other ingest routes on 3 passes' worth, for comparison
+    if not args.corpus_main_only:                               # the other ingest routes on 6 passes' worth, for comparison
         for other in ("window", "gather", "dma"):
             if other != main_mode:
                 legs[f"pinned_{other}"], _ = run_leg(base_i, "buckets", other, short, False)
