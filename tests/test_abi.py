@@ -66,6 +66,36 @@ def test_weights_container_errors(built):
     L.vad_destroy(h)
 
 
+def test_pump_and_split_step_refuse_without_a_device(built):
+    """The round-5 entry points on a machine without a GPU: null / host-only handles are refused with a status, never a crash, and the
+    pump's value-returning accessors return NULL / VAD_PUMP_ERROR."""
+    from silero_vad_amd import _lib
+    L = _lib.lib()
+    good = _lib.WEIGHTS_PATH.read_bytes()
+    h = ctypes.c_void_p()
+    assert L.vad_create_host_only(good, len(good), ctypes.byref(h)) == 0
+    prm = _lib.PumpParams()
+    L.vad_pump_params_default(ctypes.byref(prm), 16000, 64)
+    assert (prm.sampling_rate, prm.streams, prm.threshold, prm.min_silence_duration_ms, prm.speech_pad_ms) == (16000, 64, 0.5, 100, 30)
+    p = ctypes.c_void_p()
+    assert L.vad_pump_create(None, ctypes.byref(prm), ctypes.byref(p)) == 1 and not p.value            # VAD_ERR_ARG
+    assert L.vad_pump_create(h, ctypes.byref(prm), ctypes.byref(p)) == 4 and not p.value               # VAD_ERR_NO_DEVICE (host-only engine)
+    prm.sampling_rate = 44100
+    assert L.vad_pump_create(h, ctypes.byref(prm), ctypes.byref(p)) == 2                               # VAD_ERR_SAMPLE_RATE
+    prm.sampling_rate, prm.streams = 16000, 0
+    assert L.vad_pump_create(h, ctypes.byref(prm), ctypes.byref(p)) == 1
+    assert L.vad_pump_slot(None, 0) is None and L.vad_pump_probs(None, 0) is None
+    assert L.vad_pump_submit(None, 0) == 1 and L.vad_pump_open(None, 0) == 1 and L.vad_pump_close(None, 0) == 1
+    assert L.vad_pump_poll(None, 1, None, 0, None) == -3                                                # VAD_PUMP_ERROR
+    assert L.vad_pump_play(None, None, 0, 0, 0, 0, 1, 0, None, 0, None) == -3
+    assert L.vad_pump_last_error(None) == b"null pump"
+    L.vad_pump_destroy(None)
+    assert L.vad_step_split(h, 16000, 4, None, 2, 512, None, None, None, None, None) == 4               # host-only engine
+    assert L.vad_step_split(None, 16000, 4, None, 2, 512, None, None, None, None, None) == 1
+    assert L.vad_streams_overlap(None, None, None) == -1 and L.vad_streams_overlap(h, None, None) == -4
+    L.vad_destroy(h)
+
+
 def test_no_gpu_means_loud_failure(built):
     """The product path has no CPU fallback."""
     import torch

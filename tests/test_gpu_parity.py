@@ -2341,3 +2341,50 @@ def test_ragged_reserve_makes_the_run_allocation_free(golden):
     assert [lm.engine.scratch_generation() for lm, _ in _compute_lanes(m1, 2)] == gens
     want = ragged_probs(audios, load_silero_vad(device=0), 16000, max_bytes=1 << 20)
     assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_step_split_equals_step(model, golden, tag):
+    """vad_step_split (context read from one buffer, written to another; int16 or fp32 device PCM) against vad_step / the one-step
+    vad_forward_audio_i16: identical probabilities, state and context over a chain of steps, ping-ponging two context buffers; and its
+    argument checks."""
+    from silero_vad_amd import _lib
+    L = _lib.lib()
+    eng = model.engine
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    B, T = 37, 9
+    dev = model.device
+    for dtype in (torch.float32, torch.int16):
+        rows = rolled_rows(g["wav"], B, T * n, 3001)
+        x = torch.from_numpy(rows if dtype == torch.float32 else (rows * 32768.0).clip(-32768, 32767).astype(np.int16)).to(dev)
+        ctx_a = torch.zeros((B, n // 8), device=dev)
+        st_a = torch.zeros((2, B, 128), device=dev)
+        pa = []
+        for t in range(T):
+            p = torch.empty((B, 1), device=dev)
+            if dtype == torch.float32:
+                eng.step(x[:, t * n:(t + 1) * n].contiguous(), sr, ctx_a, st_a, p)
+            else:
+                eng.forward_audio(x[:, t * n:(t + 1) * n].contiguous(), sr, ctx_a, st_a, p)
+            pa.append(p)
+        cx = [torch.zeros((B, n // 8), device=dev), torch.full((B, n // 8), 7.0, device=dev)]
+        st_b = torch.zeros((2, B, 128), device=dev)
+        pb = []
+        for t in range(T):
+            p = torch.empty((B,), device=dev)
+            chunk = x[:, t * n:(t + 1) * n].contiguous()
+            rc = L.vad_step_split(eng._h, sr, B, chunk.data_ptr(), chunk.element_size(), n, cx[t & 1].data_ptr(), cx[(t + 1) & 1].data_ptr(),
+                                  st_b.data_ptr(), p.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            assert rc == 0, L.vad_last_error(eng._h)
+            pb.append(p[:, None])
+            torch.cuda.synchronize()
+        assert torch.equal(torch.cat(pa, 1), torch.cat(pb, 1)) and torch.equal(st_a, st_b) and torch.equal(ctx_a, cx[T & 1]), dtype
+    c0 = torch.zeros((B, n // 8), device=dev)
+    p = torch.empty((B,), device=dev)
+    args = lambda ci, co, es=4, ld=n: (eng._h, sr, B, x.data_ptr(), es, ld, ci, co, st_b.data_ptr(), p.data_ptr(), None)
+    assert L.vad_step_split(*args(c0.data_ptr(), c0.data_ptr())) == 1 and b"second" in L.vad_last_error(eng._h)      # in == out
+    assert L.vad_step_split(*args(c0.data_ptr(), cx[0].data_ptr(), es=3)) == 1                                       # element size
+    assert L.vad_step_split(*args(c0.data_ptr(), cx[0].data_ptr(), ld=n - 1)) == 1                                   # row stride < N
+    assert L.vad_step_split(*args(None, cx[0].data_ptr())) == 1
+    assert L.vad_step_split(eng._h, 44100, B, x.data_ptr(), 4, n, c0.data_ptr(), cx[0].data_ptr(), st_b.data_ptr(), p.data_ptr(), None) == 2
