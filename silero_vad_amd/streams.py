@@ -394,6 +394,8 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     plan = plan or RaggedPlan(lengths, max_waste, max_bytes, esz)
     src = _Sources(audios, dtype, check_pinned=on_gpu and mode != "stage" and hasattr(getattr(model, "engine", None), "upload_rows"))
     if not on_gpu:                                        # CPU stand-in models (tests)
+        if prepare_only:
+            return
         for idxs in plan.buckets:
             width = max(plan.lengths[idxs[0]], n)
             host = torch.empty((len(idxs), width), dtype=dtype)

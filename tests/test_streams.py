@@ -441,3 +441,16 @@ def test_iterator_feed_argument_errors_and_event_capacity(built):
         it.feed(np.zeros(5, np.float32))
     with pytest.raises(ValueError, match="expected 4 active flags"):
         it.feed(np.zeros(4, np.float32), active=[True] * 3)
+
+
+def test_ragged_reserve_is_harmless_without_a_gpu(built):
+    """`ragged_reserve` (allocate up front what a run needs) plans and returns when the model is a CPU stand-in; the run after it is
+    the run without it."""
+    from silero_vad_amd import ragged_probs, ragged_reserve
+    wav = _wav().astype(np.float32) / 32768.0
+    audios = [torch.from_numpy(wav[i * 7000: i * 7000 + n].copy()) for i, n in enumerate([9000, 4000, 12000, 700])]
+    m = OracleModel()
+    assert ragged_reserve(audios, m, 16000) is None
+    got = ragged_probs(audios, m, 16000)
+    want = ragged_probs(audios, OracleModel(), 16000)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
