@@ -809,7 +809,8 @@ def run_corpus(args, rank, world, local, dist, passes):
             rec = PackedRecordings(src, (offs if src is base_i else offs_rand)[:m], lens[:m])
             if sched == "buckets":      # length-sorted buckets, one lock-step call each, device scan per bucket
                 return ragged_speech_segments(rec, model, sr, max_waste=0.1, max_bytes=int(os.environ.get("VAD_BENCH_BUCKET_BYTES", 1 << 30)), as_arrays=True)
-            segs = refill_speech_segments(rec, model, sr, slots=2048, slab_chunks=64)   # persistent slots, refilled at slab boundaries
+            rs, rc_ = (int(v) for v in os.environ.get("VAD_BENCH_REFILL", "2048,128").split(","))
+            segs = refill_speech_segments(rec, model, sr, slots=rs, slab_chunks=rc_)     # persistent slots, refilled at slab boundaries
             return np.asarray([len(x) for x in segs]), None
 
         one(min(nrec, 2 * R))                                   # warm-up: pinned buffers, scratch, lanes
