@@ -1137,12 +1137,12 @@ def main():
         if extras and args.config == "c2":              # the other BASELINE configs, for the record
             oc = {}
             legs = [("stream", lambda: run_stream(args, rank, world, local, dist, 1000)),
-                    ("stream_host", lambda: run_stream_host(args, rank, world, local, dist, 1000)),
+                    ("stream_host", lambda: run_stream_host(args, rank, world, local, dist, 2000)),
                     ("corpus", lambda: run_corpus(args, rank, world, local, dist, args.corpus_passes))]
             if world == 1:
                 legs = [("8k", lambda: run_batch(args, 8000, rank, world, local, dist, 100))] + legs + \
                        [("stream_8k", lambda: run_stream(args, rank, world, local, dist, 1000, 8000)),
-                        ("stream_host_8k", lambda: run_stream_host(args, rank, world, local, dist, 1000, 8000)),
+                        ("stream_host_8k", lambda: run_stream_host(args, rank, world, local, dist, 2000, 8000)),
                         ("plumbing", lambda: {"config": {"workload": "configs[0]"}, **run_plumbing(args, local)}),
                         ("plumbing_8k", lambda: {"config": {"workload": "configs[0], 8 kHz"}, **run_plumbing(args, local, 8000)})]
             for name, fn in legs:

@@ -84,7 +84,7 @@ def main():
                 t0 += a.ticks
                 rate = a.streams * a.ticks / (st["wall_ms"] / 1e3)
                 print(f"parts {parts} fill {fill:3d} depth {depth}: {st['wall_ms'] / a.ticks * 1e3:7.1f} us/tick  {rate / 1e6:6.1f} M chunks/s  of link {rate / ceil:.3f}  "
-                      f"tick p50 {st['tick_ms_p50'] * 1e3:6.1f} p95 {st['tick_ms_p95'] * 1e3:6.1f} us   host/tick: fill {st['fill_ms_mean'] * 1e3:6.1f} submit "
+                      f"tick p50 {st['tick_ms_p50'] * 1e3:6.1f} p95 {st['tick_ms_p95'] * 1e3:6.1f} max {st['tick_ms_max'] * 1e3:7.1f} us   host/tick: fill {st['fill_ms_mean'] * 1e3:6.1f} submit "
                       f"{st['submit_ms_mean'] * 1e3:5.1f} blocked {st['wait_ms_mean'] * 1e3:6.1f}", flush=True)
         pump.close()
 
