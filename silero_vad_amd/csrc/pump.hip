@@ -339,6 +339,9 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
     }
     depth = std::max(1, std::min(depth, p->R - 1));
     const long ahead = depth == 1 ? 1 : depth + 1;                             // <= R: the slot's previous tick has been retired by then
+    // waits spin when this process has CPUs to spare and yield when it does not (one of eight ranks under a 16-CPU quota has two: nine
+    // spinning threads per rank would get the whole node throttled, host_threads.hpp)
+    const bool polite = vad::default_host_threads(256) < 4;
     const bool silent = fill_threads < 0;        // diagnostic: the sources write nothing (the slots keep their content): device side only
     int nsrc = fill_threads > 0 ? fill_threads : std::max(1, std::min(8, vad::default_host_threads(32) - 2));
     nsrc = std::max(1, std::min(nsrc, (p->streams + 63) / 64));
@@ -356,7 +359,8 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
             //  single 6 ms stalls of a tick, 1-4 % of a 0.2-0.5 s run; a source thread of an audio server would block on its socket instead)
             while (t - retired.load(std::memory_order_acquire) >= ahead) {
                 if (stop.load(std::memory_order_relaxed)) return;
-                _mm_pause();
+                if (polite) std::this_thread::yield();
+                else _mm_pause();
             }
             if (!silent && b1 > b0) {
                 const double f0 = now_ms();
@@ -397,7 +401,10 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
     const double t0 = now_ms();
     for (long t = first_tick; t < last && ok; ++t) {
         const int r = (int)(t % p->R);
-        while (written[r].load(std::memory_order_acquire) < nsrc) _mm_pause();
+        while (written[r].load(std::memory_order_acquire) < nsrc) {
+            if (polite) std::this_thread::yield();
+            else _mm_pause();
+        }
         written[r].store(0, std::memory_order_relaxed);          // (the slot's next writers wait for this tick's retirement)
         const double s0 = now_ms();
         t_written[r] = s0;
