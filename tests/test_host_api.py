@@ -91,3 +91,26 @@ def test_hubconf_contract(built, tmp_path):
     y = utils[2](str(tmp_path / "a.wav"), 8000)
     assert y.shape == x.shape and (x - y).abs().max() < 1.0 / 16384
     assert torch.equal(utils[4]([{"start": 10, "end": 20}, {"start": 100, "end": 130}], x), torch.cat([x[10:20], x[100:130]]))
+
+
+def test_bench_line_digest_is_last_and_small():
+    """the driver keeps the TAIL of the bench line -- its last key, `legs`, must carry every leg (value, fraction
+    of its bound, its own parity figure, the largest checked probability) in at most 1.5 KB.  Checked on the committed line of the round
+    and by recomputing the digest from it."""
+    import json
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    line = (root / "profiles" / "r05_bench_line.json").read_text().strip()
+    d = json.loads(line)
+    assert list(d)[-1] == "legs" and line.rstrip().endswith("}}")
+    legs = d["legs"]
+    assert set(legs) == {"c2", "8k", "stream", "stream_host", "corpus", "stream_8k", "stream_host_8k", "plumbing", "plumbing_8k"}
+    assert len(json.dumps(legs)) <= 1536
+    for k in ("c2", "8k", "stream", "stream_8k", "stream_host", "stream_host_8k"):
+        assert legs[k]["max_prob"] > 0.9 and legs[k]["dp"] < 1e-4, k          # the self-check spans the sigmoid
+    assert legs["stream_host"]["of_link"] >= 0.85 and legs["stream_host_8k"]["of_link"] >= 0.85
+    assert legs["stream_host"]["tick_ms_p95"] <= 0.3 and legs["stream_host_8k"]["tick_ms_p95"] <= 0.3
+    import sys
+    sys.path.insert(0, str(root))
+    import bench
+    assert bench.compact_legs({k: v for k, v in d.items() if k != "legs"}) == legs
