@@ -556,7 +556,10 @@ def test_plain_c_client_streams_chunks_to_events(model, golden, tag, route, tmp_
     st = torch.zeros((2, 3, 128), device=model.device)
     ctx = torch.zeros((3, n // 8), device=model.device)
     want = model.engine.forward_audio(torch.from_numpy(rows).to(model.device), sr, ctx, st).cpu().numpy()
-    assert np.array_equal(probs[:T].T, want)
+    if os.environ.get("SILERO_VAD_AMD_TEST_ARITH", "fp32") == "fp32":
+        assert np.array_equal(probs[:T].T, want)
+    else:       # (the client is its own process and runs the default arithmetic; the suite's model does not)
+        assert np.abs(probs[:T].T - want).max() < TIGHT
 
 
 @pytest.mark.parametrize("tag", ["16k", "8k"])
