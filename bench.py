@@ -40,8 +40,10 @@ The same JSON line also carries, for the record (none of them is the headline `v
                    stream during the timed steps) against the dense fp32 MFMA peak; always <= 1
   legs             LAST key: every leg's value, its fraction of the bound that applies, its own parity figure and max probability
   cpu_baseline     the reference's own ATen CPU operators (oracle/aten_port.py, kind "aten-port") timed on this
-                   box's host cores under BASELINE.md section 3 protocols R1-R5 (rank 0, N = 1 only; R5 = get_speech_timestamps
-                   on the fixture through the per-chunk protocol, the CPU figure beside `plumbing`)
+                   box's host cores under BASELINE.md section 3 protocols R1-R5 (rank 0, before the process group forms; R5 =
+                   get_speech_timestamps on the fixture through the per-chunk protocol, the CPU figure beside `plumbing`)
+What rank 0 prints on stdout is ONE line of at most 8 192 bytes (`compact_line`: the contract's keys, `parity`, `roofline`, `cpu_baseline`,
+`legs`); the full record with every leg's prose and detail goes to gpurun_out/bench_detail.json and to stderr (`emit`).
 `--config <name>` runs one of the other configs as the main leg instead.
 """
 import argparse
@@ -1043,10 +1045,9 @@ def small(d):
 
 
 def compact_legs(out):
-    """Every leg of the line in one small object that is printed LAST (a reader that keeps only the tail of the line still sees all
-    of them): value in chunks/s, its fraction of what bounds it (fp32 MFMA peak for the kernels, this box's int16 PCIe ceiling for
-    the host-fed legs), the leg's own parity check (max |dp| against the oracle on the leg's own audio, and the largest probability
-    among the checked chunks: a check on probabilities that never leave 0 proves little)."""
+    """Every leg of the run in one small object: value in chunks/s, its fraction of what bounds it (fp32 MFMA peak for the kernels, this
+    box's int16 PCIe ceiling for the host-fed legs), the leg's own parity check (max |dp| against the oracle on the leg's own audio, and the
+    largest probability among the checked chunks: a check on probabilities that never leave 0 proves little)."""
     def one(d):
         if not isinstance(d, dict):
             return None
@@ -1059,25 +1060,155 @@ def compact_legs(out):
             e["of_link"] = d["pcie"].get("fraction_of_pcie_ceiling")
         if isinstance(d.get("tick_latency_ms"), dict):
             e["tick_ms_p95"] = d["tick_latency_ms"].get("p95")
+            if "max" in d["tick_latency_ms"]:
+                e["tick_ms_max"] = d["tick_latency_ms"]["max"]
         par = d.get("parity")
         if isinstance(par, dict):
             e["dp"] = float(f"{par.get('parity_max_abs_dp', 0):.2e}")
             e["max_prob"] = par.get("max_prob")
         elif "parity_sample_max_abs_dp" in d:
             e["dp"] = float(f"{d['parity_sample_max_abs_dp']:.2e}")
+        for k in ("gaps", "first_result_at"):            # live streams with absent rows / results while the shard runs (when the leg has them)
+            if k in d:
+                e[k] = d[k]
         return e
     legs = {"c2": one(out)}
     for name, d in (out.get("other_configs") or {}).items():
         if name.startswith("plumbing"):
             pc = (d or {}).get("per_call_latency_ms") or {}
-            legs[name] = {"call_ms": pc.get("eager_model_call_item"), "identical_segments": next((v.get("identical_segments") for k, v in (d or {}).items()
-                                                                                                    if k.startswith("get_speech_timestamps")), None)}
+            gst = next((v for k, v in (d or {}).items() if k.startswith("get_speech_timestamps")), {}) or {}
+            legs[name] = {"call_ms": pc.get("eager_model_call_item"), "per_chunk_protocol_ms": gst.get("per_chunk_protocol_ms"),
+                          "identical_segments": gst.get("identical_segments")}
+            if isinstance(d, dict) and "error" in d:
+                legs[name] = {"error": d["error"][:80]}
             continue
         legs[name] = one(d)
-        if name == "corpus" and isinstance(d, dict) and isinstance(d.get("legs"), dict):
+        if name.startswith("corpus") and isinstance(d, dict) and isinstance(d.get("legs"), dict):
             legs[name]["of_link"] = d["legs"].get("main", {}).get("fraction_of_pcie_ceiling")
-            legs[name]["routes_of_link"] = {k: v.get("fraction_of_pcie_ceiling") for k, v in d["legs"].items() if k != "main"}
+            routes = {k: v.get("fraction_of_pcie_ceiling") for k, v in d["legs"].items() if k != "main"}
+            if routes:
+                legs[name]["routes_of_link"] = routes
     return legs
+
+
+LINE_CAP = 8192          # bytes: what the driver keeps of stdout; the line must fit in it whole
+DETAIL_FILE = "gpurun_out/bench_detail.json"
+
+
+def _num(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(out):
+    """THE line: everything the measurement contract names, in at most LINE_CAP bytes whatever the run held (9 legs, 8 ranks).  Per-leg
+    workload prose, traffic detail, issue-pipe reading, untimed trials and per-rank records are NOT here: `emit` writes the full record to
+    DETAIL_FILE and to stderr.  Strings stay under 150 characters (the driver's parser clips there)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out[k] for k in keep if k in out}
+    cfg = dict(out.get("config") or {})
+    if isinstance(cfg.get("workload"), str):
+        cfg["workload"] = cfg["workload"][:148]
+    line["config"] = {k: (v[:148] if isinstance(v, str) else v) for k, v in cfg.items()}
+    for k in ("dry", "realtime_factor", "timed_region_s", "outputs_finite", "wall_s", "audio_hours_all_gpus", "ten_k_hours_at_this_rate_s",
+              "recordings_total", "recordings_gathered", "ids_complete", "segments_total"):
+        if k in out:
+            line[k] = out[k]
+    if isinstance(out.get("kernel_ms"), dict):
+        line["kernel_ms"] = {k: v for k, v in out["kernel_ms"].items() if k != "note"}
+    if isinstance(out.get("tick_latency_ms"), dict):
+        line["tick_latency_ms"] = {k: v for k, v in out["tick_latency_ms"].items() if k != "what"}
+    if isinstance(out.get("pcie"), dict):
+        line["pcie"] = out["pcie"]
+    par = out.get("parity")
+    if isinstance(par, dict):
+        line["parity"] = {"max_abs_dp": float(f"{par.get('parity_max_abs_dp', 0):.3e}"), "max_prob": par.get("max_prob"),
+                          "final_state": (float(f"{par['final_state_max_rel_err']:.3e}") if "final_state_max_rel_err" in par else None),
+                          "streams_checked": par.get("streams_checked"), "chunks_checked": par.get("chunks_checked"),
+                          "tolerance": par.get("tolerance"), "checker": "oracle/vad_oracle.c on the timed PCM", "ok": par.get("ok")}
+    ps = out.get("parity_sample")
+    if isinstance(ps, dict):
+        line["parity"] = {"max_abs_dp": float(f"{ps.get('parity_sample_max_abs_dp', 0):.3e}"), "recordings_checked": ps.get("recordings_checked"),
+                          "one_in": ps.get("one_in"), "segments_identical": ps.get("segments_identical_to_oracle_scan"), "tolerance": ps.get("tolerance")}
+    rl = out.get("roofline")
+    if isinstance(rl, dict):
+        r = {k: rl.get(k) for k in ("bound", "kernel", "dtype", "achieved", "peak", "unit", "frac", "avg_launch_ms", "flop_per_launch", "traffic",
+                                    "kernel_io_bytes", "traffic_over_kernel_io") if k in rl}
+        if rl.get("traffic") is None and isinstance(rl.get("traffic_profiled"), dict):
+            r["traffic_profiled"] = rl["traffic_profiled"].get("bytes")      # the committed profile's figure, not this run's
+        if isinstance(rl.get("issue_pipe"), dict):
+            r["issue_pipe_frac"] = rl["issue_pipe"].get("frac")
+        if isinstance(rl.get("hbm"), dict):
+            r["hbm_frac_kernel_io"] = rl["hbm"].get("frac")
+        p = rl.get("path")
+        if isinstance(p, dict):
+            r["path"] = {k: p.get(k) for k in ("algorithmic_bytes", "algorithmic_bytes_per_chunk", "traffic", "traffic_over_algorithmic",
+                                               "mfma_flop_per_chunk") if k in p}
+            if p.get("traffic") is None:
+                r["path"]["traffic_profiled"] = p.get("traffic_profiled")
+            pf = out.get("path_fraction") or {}
+            r["path"]["dense_flop_vs_fp32_peak"] = pf.get("dense_flop_vs_fp32_peak")
+            r["path"]["algorithmic_bytes_vs_hbm_peak"] = pf.get("algorithmic_bytes_vs_hbm_peak")
+            km = out.get("kernel_ms") or {}
+            if km.get("front") and "n_gpus" in out and "value" in out and out.get("value"):
+                # executed matrix flops of BOTH kernels over the whole step time, against the fp32 MFMA peak
+                r["path"]["mfma_frac"] = round(out["value"] / max(out["n_gpus"], 1) * p.get("mfma_flop_per_chunk", 0) / (PEAK_F32_TFLOPS * 1e12), 4)
+        rk = rl.get("rec_kernel")
+        if isinstance(rk, dict):
+            r["rec_kernel"] = {k: rk.get(k) for k in ("avg_launch_ms", "mfma_frac", "hbm_frac")}
+        line["roofline"] = r
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = {k: cb.get(k) for k in ("value", "unit", "cores", "cpu_model", "kind", "best_protocol", "torch", "cached_from") if k in cb}
+        if isinstance(cb.get("runs"), dict):
+            c["runs"] = {k.split("_")[0]: _num(v.get("chunks_per_s") if isinstance(v, dict) else v, 1) for k, v in cb["runs"].items()}
+        if "error" in cb:
+            c["error"] = str(cb["error"])[:140]
+        c["sample"] = "0.03 N(0,1) PCM, audio_forward B x T per protocol R1-R4 (BASELINE.md 3), warm-up 3, median of 5; R5 = fixture per chunk"
+        line["cpu_baseline"] = c
+    oa = out.get("other_arithmetic")
+    if isinstance(oa, dict):
+        line["other_arithmetic"] = {k: {"value": v.get("value"), "max_abs_prob_diff_vs_main": _num(v.get("max_abs_prob_diff_vs_main"), 9)}
+                                    for k, v in oa.items() if isinstance(v, dict)}
+    if "node_totals" in out:
+        line["node_totals"] = out["node_totals"]
+    if "plumbing" in out and isinstance(out["plumbing"], dict):
+        pl = out["plumbing"]
+        line["plumbing"] = {"per_call_latency_ms": {k: v for k, v in (pl.get("per_call_latency_ms") or {}).items() if k != "note"}}
+        for k, v in pl.items():
+            if k.startswith("get_speech_timestamps") and isinstance(v, dict):
+                line["plumbing"][k] = {kk: vv for kk, vv in v.items() if kk != "cpu_beside_it"}
+    line["detail"] = DETAIL_FILE
+    if "legs" in out and not out.get("dry"):
+        legs = out["legs"]
+        line["legs"] = legs if "c2" in legs else {k: {"value": v.get("value"), "of_link": v.get("fraction_of_pcie_ceiling"),
+                                                      "segments_found_rank0": v.get("segments_found_rank0"),
+                                                      "segments_gathered_all_ranks": v.get("segments_gathered_all_ranks")} for k, v in legs.items()}
+    # safety valve: whatever a future leg adds, the line fits -- shed the least important parts first
+    for shed in (("other_arithmetic",), ("plumbing",), ("cpu_baseline", "sample"), ("roofline", "path"), ("legs",), ("node_totals",), ("pcie",)):
+        if len(json.dumps(line)) <= LINE_CAP - 64:
+            break
+        tgt = line
+        for k in shed[:-1]:
+            tgt = tgt.get(k, {})
+        tgt.pop(shed[-1], None)
+        line["shed"] = line.get("shed", []) + ["/".join(shed)]
+    return line
+
+
+def emit(out, stream=None):
+    """Rank 0's output: the full record to DETAIL_FILE (next to this file; `gpurun_out/` is what comes back from a GPU box) and to
+    stderr, then ONE line of at most LINE_CAP bytes on stdout, last."""
+    try:
+        path = ROOT / DETAIL_FILE
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(json.dumps(out, indent=1) + "\n")
+    except OSError as e:
+        print(f"bench: could not write {DETAIL_FILE}: {e}", file=sys.stderr)
+    print("bench detail: " + json.dumps(out), file=sys.stderr, flush=True)
+    text = json.dumps(compact_line(out))
+    assert len(text) <= LINE_CAP, len(text)
+    print(text, file=stream or sys.stdout, flush=True)
+    return text
 
 
 def main():
@@ -1107,7 +1238,8 @@ def main():
         relaunch_distributed(args)                      # does not return
 
     # the CPU baseline runs first, in its own CPU-only process, before this process touches the GPU
-    want_cpu = int(os.environ.get("WORLD_SIZE", 1)) == 1 and not args.no_cpu_baseline and not args.dry
+    # (at N > 1 too, on rank 0: the other ranks wait for it in the rendezvous -- the multi-rank line carries its own baseline)
+    want_cpu = int(os.environ.get("RANK", 0)) == 0 and not args.no_cpu_baseline and not args.dry
     cpu = cpu_baseline(16000 if args.config != "8k" else 8000) if want_cpu else None
 
     import torch
@@ -1202,7 +1334,7 @@ def main():
             out["data"] = "synthetic; FUNCTIONAL run of the multi-rank legs with all ranks on ONE GPU (gloo) -- not a measurement"
         if not args.dry and args.config == "c2" and "legs" not in out:
             out["legs"] = compact_legs(out)             # LAST key of the line
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

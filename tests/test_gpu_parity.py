@@ -1555,11 +1555,15 @@ def test_bench_multi_rank_legs_run_on_shared_gpu(built):
                         "--recordings", "1024", "--corpus-main-only", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1 and len(lines[0]) <= 8192
+    d = json.loads(lines[0])
     main = d["legs"]["main"]
     assert d["n_gpus"] == 2 and d["config"]["host_threads_per_rank"] >= 1
     assert main["segments_gathered_all_ranks"] is not None and main["segments_gathered_all_ranks"] >= main["segments_found_rank0"] > 0
-    assert d["parity_sample"]["segments_identical_to_oracle_scan"] and d["parity_sample_max_abs_dp"] < TOL
+    assert d["parity"]["segments_identical"] and d["parity"]["max_abs_dp"] < TOL
+    full = json.loads((root / d["detail"]).read_text())           # the whole record, beside the line
+    assert full["parity_sample"]["segments_identical_to_oracle_scan"] and len(full["per_rank"]) == 2 and "node_totals" in d
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--config", "stream", "--steps", "50", "--live", "1024",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
