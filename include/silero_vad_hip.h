@@ -137,6 +137,27 @@ int  vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t el
 int  vad_step_split(vad_engine *e, int sr, int B, const void *pcm, size_t elem_size, long ld, const float *ctx_in, float *ctx_out,
                     float *state, float *prob, void *stream);
 
+/* The step for LIVE streams that do not all have a chunk this tick.  In the reference a stream's (h, c) and context change only when
+ * that stream's own caller calls the model -- one call per chunk that arrived (src/silero_vad/utils_vad.py:507-549 VADIterator.__call__;
+ * the model object replaces _state / _context inside that call and nowhere else, JIT!/vad/model/vad_annotator.py:72,86-87; the native
+ * loop around session.run: examples/cpp/silero-vad-onnx.cpp:335-390) -- so a stream whose packet is late simply is not stepped.  In a
+ * lock-step batch that is a per-row flag:
+ *   present  dev [B] bytes (device memory, or page-locked host memory's device alias), or NULL = every row has a chunk.
+ *            present[b] == 0: row b comes out of the call exactly as it went in -- (h, c) not written, its context carried over
+ *            bit for bit (ctx_out[b] = ctx_in[b]), whatever its PCM row holds is ignored -- and prob[b] = VAD_PROB_ABSENT.
+ *            The other rows' results do not depend on the flags (bit-identical to the call without them).
+ *   ctx_out  a second buffer (as vad_step_split), or NULL / == ctx_in: in place (as vad_step)
+ *   pcm      dev [B][N], elem_size 2 = int16 | 4 = fp32, row stride `ld` elements
+ * With present == NULL this IS vad_step_split / vad_step: same kernels, same cost.  With flags it is one more small launch (the carry
+ * of the absent rows' contexts, csrc/kernel_present.hip).                                                                       */
+#define VAD_PROB_ABSENT (-1.0f)
+int  vad_step_present(vad_engine *e, int sr, int B, const void *pcm, size_t elem_size, long ld, const float *ctx_in, float *ctx_out,
+                      float *state, float *prob, const uint8_t *present, void *stream);
+/* vad_step_host with the flags: host_present host [B] page-locked (NULL = all present: exactly vad_step_host), dev_present dev [B]
+ * staging the caller owns; one more small H2D copy on `stream`.                                                                  */
+int  vad_step_host_present(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, void *dev_pcm, float *ctx, float *state,
+                           float *dev_prob, float *host_prob, const uint8_t *host_present, uint8_t *dev_present, void *stream);
+
 /* T = ceil(L / N) lock-step steps for B streams: VADRNNJITMerge.audio_forward
  * (JIT!/vad/model/vad_annotator.py:128-156; ONNX twin utils_vad.py:94-110) with the carried
  * state made explicit (pass zeroed ctx/state for the reference's reset-then-run behaviour).
@@ -260,6 +281,7 @@ typedef struct vad_pump_stats {
     double tick_ms_p50, tick_ms_p95, tick_ms_max;     /* slot written -> its events on the host, per tick                    */
     double fill_ms_mean, submit_ms_mean, wait_ms_mean;/* host time per tick: writing the slot, issuing the tick, blocked     */
     int    fill_threads, depth;
+    long   chunks;                                    /* chunks that were stepped (= ticks x streams unless streams were absent)  */
 } vad_pump_stats;
 enum { VAD_PUMP_IDLE = -1,   /* vad_pump_poll: nothing submitted                                                             */
        VAD_PUMP_BUSY = -2,   /* vad_pump_poll(block = 0): the oldest tick has not finished                                   */
@@ -277,6 +299,14 @@ int16_t *vad_pump_slot(vad_pump *p, int r);
 /* Start one tick over ring slot r: asynchronous (copies and kernels are queued; returns at once).  VAD_ERR_ARG while the slot's
  * previous tick is in flight.  Ticks execute in submission order.                                                          */
 int  vad_pump_submit(vad_pump *p, int r);
+/* The tick for live streams that do not all have a chunk (see vad_step_present): present = host [streams] bytes, 0 = stream b has no
+ * chunk this tick -- its (h, c), context and iterator counters stay exactly as they are, its slot of vad_pump_probs holds
+ * VAD_PROB_ABSENT, whatever its part of the ring slot holds is ignored; NULL = every stream has one (== vad_pump_submit, same copies,
+ * same kernels).  Every ring slot has its own page-locked flag row, vad_pump_present(p, r), in front of its audio (flags and audio
+ * cross the link in ONE copy): write the flags there and pass that pointer, or pass any host array (copied there).  A failure after
+ * the tick's first operation was queued poisons the pump (every later call fails): the carried state is half-advanced.          */
+uint8_t *vad_pump_present(vad_pump *p, int r);
+int  vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present);
 /* Retire the OLDEST submitted tick: wait for it (block != 0) or return VAD_PUMP_BUSY, run the iterator logic of every open
  * stream over its probabilities and write the tick's events (stream order; at most `cap`, the return value is how many there
  * were, <= streams).  *slot = the ring slot that is free again.  The probabilities stay readable in vad_pump_probs(p, slot)
@@ -285,7 +315,9 @@ long vad_pump_poll(vad_pump *p, int block, vad_iter_event *out, long cap, int *s
 const float *vad_pump_probs(const vad_pump *p, int r);   /* [streams] */
 /* A new stream takes slot `stream`: zero (h, c), context and iterator state, ordered behind the ticks already submitted
  * (reset_states, JIT!/vad/model/vad_annotator.py:157-162 + utils_vad.py:500-505).  close: the slot is still computed (lock-step
- * batch) but emits no events.                                                                                              */
+ * batch) but emits no events.  Both take effect BEHIND the ticks that are in flight when they are called, on the device (stream
+ * order) and on the host (the iterator state is reset / muted when those ticks have been retired: their probabilities and events
+ * belong to the slot's previous occupant).                                                                                 */
 int  vad_pump_open(vad_pump *p, int stream);
 int  vad_pump_close(vad_pump *p, int stream);
 /* Test / migration hook: copy stream's carried h[128], c[128], ctx[C] to the host (any may be NULL).  Synchronises.        */
@@ -301,6 +333,13 @@ int  vad_pump_state(vad_pump *p, int stream, float *h, float *c, float *ctx);
  * cap; the return value is their number) and `st` (may be NULL) is filled in (fill_ms_mean: per source thread and tick).          */
 long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long first_tick, long n_ticks, int depth, int fill_threads,
                    vad_iter_event *out, long cap, vad_pump_stats *st);
+/* The same loop with streams that miss ticks: pattern = [pattern_ticks][streams] bytes, stream b has a chunk at tick t iff
+ * pattern[(t % pattern_ticks) * streams + b] != 0.  A stream's audio advances only when it delivers (its k-th delivered chunk is
+ * rows[b * ld + (k * N) % period ...], k counted since the stream was opened): a late packet delays the stream, it does not skip
+ * audio.  The sources write the flags into the slot's flag row and every tick is a vad_pump_submit_present.  pattern == NULL:
+ * vad_pump_play.                                                                                                            */
+long vad_pump_play_gaps(vad_pump *p, const int16_t *rows, long ld, long period, const uint8_t *pattern, long pattern_ticks, long first_tick,
+                        long n_ticks, int depth, int fill_threads, vad_iter_event *out, long cap, vad_pump_stats *st);
 
 /* ---- host-side ingest ---------------------------------------------------------------------------------
  * Pack n recordings of different lengths (lens[i] samples of elem_size 2 = int16 or 4 = float32 at

@@ -45,7 +45,7 @@ class PumpParams(Structure):
 class PumpStats(Structure):
     _fields_ = [("ticks", c_long), ("events", c_long), ("wall_ms", c_double), ("tick_ms_p50", c_double), ("tick_ms_p95", c_double),
                 ("tick_ms_max", c_double), ("fill_ms_mean", c_double), ("submit_ms_mean", c_double), ("wait_ms_mean", c_double),
-                ("fill_threads", c_int), ("depth", c_int)]
+                ("fill_threads", c_int), ("depth", c_int), ("chunks", c_long)]
 
 
 # every symbol include/silero_vad_hip.h declares: name -> (restype, argtypes)
@@ -62,6 +62,9 @@ SYMBOLS = {
     "vad_step": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vad_step_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vad_step_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vad_step_present": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vad_step_host_present": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
     "vad_pump_params_default": (None, [POINTER(PumpParams), c_int, c_int]),
     "vad_pump_create": (c_int, [c_void_p, POINTER(PumpParams), POINTER(c_void_p)]),
     "vad_pump_destroy": (None, [c_void_p]),
@@ -69,6 +72,10 @@ SYMBOLS = {
     "vad_pump_geometry": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "vad_pump_slot": (c_void_p, [c_void_p, c_int]),
     "vad_pump_submit": (c_int, [c_void_p, c_int]),
+    "vad_pump_present": (c_void_p, [c_void_p, c_int]),
+    "vad_pump_submit_present": (c_int, [c_void_p, c_int, c_void_p]),
+    "vad_pump_play_gaps": (c_long, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_long, c_int, c_int, c_void_p, c_long,
+                                    POINTER(PumpStats)]),
     "vad_pump_poll": (c_long, [c_void_p, c_int, c_void_p, c_long, POINTER(c_int)]),
     "vad_pump_probs": (c_void_p, [c_void_p, c_int]),
     "vad_pump_open": (c_int, [c_void_p, c_int]),

@@ -66,6 +66,8 @@ struct CellArgs {
     float *state;            // [2][B][128] in/out
     float *probs;            // [B][ldp], this step's column is t0
     long ldp;
+    const uint8_t *present;  // [B] or null (= all): rows with present[b] == 0 have NO chunk this tick -- their (h, c) and their
+                             // probability slot are not written (the carry pass of kernel_present.hip finishes the row)
 };
 template <typename PcmT>
 hipError_t launch_step_lat(int sr, const FrontArgs &a, const CellArgs &c, hipStream_t s);
@@ -84,8 +86,14 @@ struct RecArgs {
     float *probs;            // [B][ldp]
     long ldp, t0, nt;
     int B;
+    const uint8_t *present;  // [B] or null (= all); one-step calls only: an absent row's (h, c) and probability are not written
 };
 hipError_t launch_rec(int sr, const RecArgs &a, hipStream_t s);
+// Live streams that have no chunk this tick (vad_step_present): behind the step kernels, for every row with present[b] == 0 the
+// context is carried over unchanged, ctx_out[b] = ctx_in[b] (the frontend wrote the tail of whatever the row's PCM slot held), and
+// the probability slot gets the sentinel VAD_PROB_ABSENT.  The step kernels themselves left the row's (h, c) unwritten.
+hipError_t launch_carry_absent(const uint8_t *present, const float *ctx_in, float *ctx_out, int C, float *probs, long ldp, int B,
+                               hipStream_t s);
 // The same recurrence, bit for bit, for at most kRecSmallMaxB streams (1, 2 or 4 per workgroup): W_hh * h as matrix-vector products on the VALU (kernel_rec_small.hip);
 // `whh` points at the row image (layout.hpp "whh_rows").
 constexpr int kRecSmallMaxB = 1024;

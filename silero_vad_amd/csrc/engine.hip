@@ -198,12 +198,13 @@ int grow(vad_engine *e, void **buf, size_t *have, size_t need, hipStream_t strea
 // folded into the load; fp32 frontend).
 template <typename PcmT>
 int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm, long ld, float *ctx,
-                 float *state, float *probs, long ldp, hipStream_t stream, float *ctx_next = nullptr) {
+                 float *state, float *probs, long ldp, hipStream_t stream, float *ctx_next = nullptr, const uint8_t *present = nullptr) {
     const int ni = net_index(sr);
     const int N = sr == 16000 ? 512 : 256, C = N / 8;
     const long Ld = (L + dec - 1) / dec;                 // samples per row at the net's rate
     const long T = (Ld + N - 1) / N;
     if (ldp < T) return fail(e, VAD_ERR_ARG, "ldp < T");
+    if (present && T != 1) return fail(e, VAD_ERR_ARG, "present[] is for one-step calls");
     if (((size_t)ctx & 15) || ((size_t)state & 15))
         return fail(e, VAD_ERR_ARG, "ctx and state must be 16-byte aligned");
     int rc = ensure_scratch(e, sr, B, T, stream);
@@ -261,6 +262,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         ra.state = state;
         ra.probs = probs;
         ra.ldp = ldp; ra.t0 = t0; ra.nt = nt; ra.B = B;
+        ra.present = present;
         hipEvent_t *ev = nullptr;
         if (prof) {
             while (e->ev_pool.size() < e->ev_used + 3) {
@@ -280,6 +282,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             ca.state = state;
             ca.probs = probs;
             ca.ldp = ldp;
+            ca.present = present;
             HIP_TRY(e, vad::launch_step_lat<PcmT>(sr, fa, ca, stream));
             if (prof) {
                 HIP_TRY(e, hipEventRecord(ev[1], stream));
@@ -308,6 +311,9 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         } else HIP_TRY(e, vad::launch_rec(sr, ra, stream));
         if (prof) HIP_TRY(e, hipEventRecord(ev[2], stream));
     }
+    // rows without a chunk this tick: the step kernels left their (h, c) and probability alone; carry their context over and mark
+    // their probability slot (kernel_present.hip)
+    if (present) HIP_TRY(e, vad::launch_carry_absent(present, ctx, ctx_next ? ctx_next : e->d_ctx_new, C, probs, ldp, B, stream));
     if (!ctx_next) HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return VAD_OK;
 }
@@ -595,33 +601,48 @@ int vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ctx
     return forward_impl<float>(e, sr, B, N, pcm, ld, ctx, state, prob, 1, stream);
 }
 
-int vad_step_split(vad_engine *e, int sr, int B, const void *pcm, size_t elem_size, long ld, const float *ctx_in, float *ctx_out,
-                   float *state, float *prob, void *stream) {
+int vad_step_present(vad_engine *e, int sr, int B, const void *pcm, size_t elem_size, long ld, const float *ctx_in, float *ctx_out,
+                     float *state, float *prob, const uint8_t *present, void *stream) {
     if (!e) return VAD_ERR_ARG;
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
     const int ni = net_index(sr);
     if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000]");
     const int N = sr == 16000 ? 512 : 256;
-    if (B < 0 || (elem_size != 2 && elem_size != 4) || ld < N || (B > 0 && (!pcm || !ctx_in || !ctx_out || !state || !prob)))
+    if (B < 0 || (elem_size != 2 && elem_size != 4) || ld < N || (B > 0 && (!pcm || !ctx_in || !state || !prob)))
         return fail(e, VAD_ERR_ARG, "bad argument");
-    if (ctx_in == ctx_out || ((size_t)ctx_out & 15)) return fail(e, VAD_ERR_ARG, "vad_step_split: ctx_out must be a second, 16-byte aligned buffer");
-    if (e->impl_reference) return fail(e, VAD_ERR_OPTION, "vad_step_split: impl=reference has no split-context form");
+    if (ctx_out == ctx_in) ctx_out = nullptr;                 // in place: through the engine's second buffer, like vad_step
+    if ((size_t)ctx_out & 15) return fail(e, VAD_ERR_ARG, "ctx_out must be 16-byte aligned");
+    if (e->impl_reference) return fail(e, VAD_ERR_OPTION, "impl=reference has no split-context / present[] form");
     if (B == 0) return VAD_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     float *ci = const_cast<float *>(ctx_in);
     return elem_size == 2
-        ? forward_core<int16_t>(e, sr, 1, B, N, static_cast<const int16_t *>(pcm), ld, ci, state, prob, 1, (hipStream_t)stream, ctx_out)
-        : forward_core<float>(e, sr, 1, B, N, static_cast<const float *>(pcm), ld, ci, state, prob, 1, (hipStream_t)stream, ctx_out);
+        ? forward_core<int16_t>(e, sr, 1, B, N, static_cast<const int16_t *>(pcm), ld, ci, state, prob, 1, (hipStream_t)stream, ctx_out, present)
+        : forward_core<float>(e, sr, 1, B, N, static_cast<const float *>(pcm), ld, ci, state, prob, 1, (hipStream_t)stream, ctx_out, present);
+}
+
+int vad_step_split(vad_engine *e, int sr, int B, const void *pcm, size_t elem_size, long ld, const float *ctx_in, float *ctx_out,
+                   float *state, float *prob, void *stream) {
+    if (e && !e->host_only && B > 0 && (!ctx_out || ctx_in == ctx_out))
+        return fail(e, VAD_ERR_ARG, "vad_step_split: ctx_out must be a second, 16-byte aligned buffer");
+    return vad_step_present(e, sr, B, pcm, elem_size, ld, ctx_in, ctx_out, state, prob, nullptr, stream);
 }
 
 int vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, void *dev_pcm, float *ctx, float *state,
                   float *dev_prob, float *host_prob, void *stream_v) {
+    return vad_step_host_present(e, sr, B, host_pcm, elem_size, dev_pcm, ctx, state, dev_prob, host_prob, nullptr, nullptr, stream_v);
+}
+
+int vad_step_host_present(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, void *dev_pcm, float *ctx, float *state,
+                          float *dev_prob, float *host_prob, const uint8_t *host_present, uint8_t *dev_present, void *stream_v) {
     if (!e) return VAD_ERR_ARG;
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
     const int ni = net_index(sr);
     if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000]");
-    if (B < 0 || (elem_size != 2 && elem_size != 4) || (B > 0 && (!host_pcm || !dev_pcm || !ctx || !state || !host_prob)))
+    if (B < 0 || (elem_size != 2 && elem_size != 4) || (B > 0 && (!host_pcm || !dev_pcm || !ctx || !state || !host_prob)) ||
+        (host_present && !dev_present))
         return fail(e, VAD_ERR_ARG, "bad argument");
+    if (host_present && e->impl_reference) return fail(e, VAD_ERR_OPTION, "impl=reference has no present[] form");
     if (B == 0) return VAD_OK;
     hipStream_t stream = (hipStream_t)stream_v;
     const long N = sr == 16000 ? 512 : 256;
@@ -638,9 +659,15 @@ int vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t ele
         out = static_cast<float *>(dv);
     }
     HIP_TRY(e, hipMemcpyAsync(dev_pcm, host_pcm, (size_t)B * N * elem_size, hipMemcpyHostToDevice, stream));
-    const int rc = elem_size == 2
-        ? forward_impl<int16_t>(e, sr, B, N, static_cast<const int16_t *>(dev_pcm), N, ctx, state, out, 1, stream_v)
-        : forward_impl<float>(e, sr, B, N, static_cast<const float *>(dev_pcm), N, ctx, state, out, 1, stream_v);
+    int rc;
+    if (host_present) {
+        HIP_TRY(e, hipMemcpyAsync(dev_present, host_present, (size_t)B, hipMemcpyHostToDevice, stream));
+        rc = vad_step_present(e, sr, B, dev_pcm, elem_size, N, ctx, nullptr, state, out, dev_present, stream_v);
+    } else {
+        rc = elem_size == 2
+            ? forward_impl<int16_t>(e, sr, B, N, static_cast<const int16_t *>(dev_pcm), N, ctx, state, out, 1, stream_v)
+            : forward_impl<float>(e, sr, B, N, static_cast<const float *>(dev_pcm), N, ctx, state, out, 1, stream_v);
+    }
     if (rc) return rc;
     if (dev_prob) HIP_TRY(e, hipMemcpyAsync(host_prob, dev_prob, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, stream));
     return VAD_OK;

@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
         // sums (one per 16-unit row block) are added in the same order.  (reference: aten::lstm_cell, JIT!/torch/nn/modules/rnn.py:69)
         __shared__ __attribute__((aligned(16))) float gbuf[4][8][256];          // gates: [gate][row block][lane][4]
         __shared__ float pb[8 * 16];                                              // head partial sums: [row block][stream]
-        const bool valid = bb < a.B;
+        const bool valid = bb < a.B && (cell.present == nullptr || cell.present[ln.b] != 0);   // (an absent row keeps its state)
         run_segment<S_HH, 64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
                                  [&](auto kg) VAD_INLINE { return Hp[IC(kg)]; }, gload);
 #pragma unroll

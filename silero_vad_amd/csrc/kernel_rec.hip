@@ -41,8 +41,8 @@ __global__ void __launch_bounds__(512, 2) rec_kernel(const RecArgs a) {
     const int g = lane >> 4, j = lane & 15;
     const long st = blockIdx.x;
     const long b = st * 16 + j;
-    const bool valid = b < a.B;
-    const long bc = valid ? b : a.B - 1;
+    const long bc = b < a.B ? b : a.B - 1;
+    const bool valid = b < a.B && (a.present == nullptr || a.present[bc] != 0);          // (an absent row keeps its state: vad_step_present)
 
     // W_hh slice -> registers: A[q][kg] holds k-steps 4kg..4kg+3 of gate q
     f32x4 A[4][8];
@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(512, 2) rec_skew_kernel(const RecArgs a) {
     const int g = lane >> 4, j = lane & 15;
     const long st = blockIdx.x;
     const long b = st * 16 + j;
-    const bool valid = b < a.B;
-    const long bc = valid ? b : a.B - 1;
+    const long bc = b < a.B ? b : a.B - 1;
+    const bool valid = b < a.B && (a.present == nullptr || a.present[bc] != 0);          // (an absent row keeps its state: vad_step_present)
 
     f32x4 A[4][8];
     {

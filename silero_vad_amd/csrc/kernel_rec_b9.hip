@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(512, 1) rec_b9_kernel(const RecArgs a) {
     const int g = lane >> 4, j = lane & 15;
     const long st = blockIdx.x;
     const long b = st * 16 + j;
-    const bool valid = b < a.B;
-    const long bc = valid ? b : a.B - 1;
+    const long bc = b < a.B ? b : a.B - 1;
+    const bool valid = b < a.B && (a.present == nullptr || a.present[bc] != 0);          // (an absent row keeps its state: vad_step_present)
 
     // W_hh slice: pieces 0, 1 -> registers, piece 2 -> LDS.  Image [wave][piece][gate][u][lane][8 bf16] (16 B per lane)
     const u32x4 *img = reinterpret_cast<const u32x4 *>(a.whh) + (size_t)w * 3 * 16 * 64 + lane;

@@ -51,8 +51,8 @@ __global__ void __launch_bounds__(512, 1) rec_small_kernel(const RecArgs a) {
     // pointwise role: thread (pj, pw, pg) holds units 16 pw + 4 pg + rr of stream pj
     const bool pt = tid < 32 * NB;
     const int pj = tid >> 5, pw = (tid & 31) >> 2, pg = tid & 3;
-    const bool pvalid = pt && pj < nb;
     const long pb = b0 + (pj < nb ? pj : nb - 1);          // this thread's stream (clamped: lanes of missing streams compute, never store)
+    const bool pvalid = pt && pj < nb && (a.present == nullptr || a.present[pb] != 0);   // (an absent row keeps its state: vad_step_present)
     f32x4 h = {0.f, 0.f, 0.f, 0.f}, c = h, wo = h;
     float bo = 0.f;
     size_t soff = 0;

@@ -21,12 +21,30 @@
 //     reads), so a tick is exactly `parts` copies and `parts` kernels -- no D2D blit of the context, no D2H operation;
 //   * a ring slot may be rewritten by its sources as soon as the tick that read it has been retired (vad_pump_poll), and is refused
 //     (VAD_ERR_ARG) while that tick is in flight.
+//
+// Streams that have no chunk this tick (vad_pump_submit_present): in the reference a stream is stepped when ITS caller has a chunk
+// (utils_vad.py:507-549: one model call per arrived chunk; silero-vad-onnx.cpp:335-390), so a live stream whose packet is late must
+// come out of the tick untouched.  Every ring slot starts with a header of `streams` flag bytes (page-locked, in front of the audio,
+// so that flags + audio are ONE H2D copy); a masked tick copies the header along, the step kernels skip the absent rows' (h, c) and
+// probability, kernel_present.hip carries their contexts over (vad_step_present), and vad_pump_poll leaves their iterator counters
+// alone.  An unmasked tick copies no header and runs exactly the kernels it always ran.
+//
+// Waits block.  A source thread of a real server sleeps in its socket; the source threads of vad_pump_play, and its server loop, spin
+// for at most 20 us on the counter they wait for and then sleep on it (futex), whatever the CPU budget: one of eight ranks under a
+// 16-CPU quota has two CPUs for a server loop, a source thread and the HIP runtime's own threads, and a spinning (or yielding) thread
+// there costs the tick it is waiting for (profiles/r06_pump_one_of_eight.md).
 #include <hip/hip_runtime.h>
+#if defined(__x86_64__)
 #include <emmintrin.h>
+#endif
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -43,10 +61,11 @@ struct vad_pump {
     std::vector<int> lo, hi;                     // part k = streams [lo[k], hi[k])
     double threshold = 0.5, min_silence = 1600, pad = 480;
 
-    int16_t *h_pcm = nullptr;                    // [R][streams][N]   page-locked ingest ring
+    size_t hdr = 0, slot_bytes = 0;              // a ring slot / a device batch buffer: [hdr bytes: present[streams], padded][streams][N] int16
+    uint8_t *h_ring = nullptr;                   // [R] slots, page-locked ingest ring
     float *h_prob = nullptr;                     // [R][streams]      page-locked, mapped: the kernels store here
     float *d_prob = nullptr;                     // device alias of h_prob
-    int16_t *d_pcm = nullptr;                    // [2][streams][N]   device batch, double-buffered
+    uint8_t *d_batch = nullptr;                  // [2] device batch buffers (same layout as a ring slot), double-buffered
     float *d_ctx[2] = {nullptr, nullptr};        // [streams][C]      ping-pong
     std::vector<float *> d_state;                // per part: [2][hi - lo][128]
     hipStream_t copy[2] = {nullptr, nullptr}, compute = nullptr;    // copy[t & 1]: the copies of tick t
@@ -56,12 +75,23 @@ struct vad_pump {
     bool batch_used[2] = {false, false};
 
     long ticks = 0;                              // ticks submitted so far (tick t: batch buffer t & 1, context t & 1 -> (t + 1) & 1)
-    std::deque<int> inflight;                    // ring slots of the submitted, not yet retired ticks, oldest first
+    long retired = 0;                            // ticks retired so far (vad_pump_poll)
+    struct Flight { int r; bool masked; };
+    std::deque<Flight> inflight;                 // the submitted, not yet retired ticks, oldest first
     std::vector<uint8_t> slot_busy;              // [R]
     // VADIterator state of every stream (utils_vad.py:500-503)
-    std::vector<uint8_t> active, triggered;
+    std::vector<uint8_t> active, triggered, feed_mask;
     std::vector<int64_t> temp_end, current;
+    // open / close take effect on the HOST side (iterator reset, active flag) at the tick they were issued before: ticks submitted
+    // earlier are still in flight and belong to the slot's previous occupant
+    struct Op { long at_tick; int stream; bool open; };
+    std::deque<Op> pending;
+    std::vector<long> src_pos;                   // vad_pump_play with a presence pattern: chunks stream b has delivered so far
+    bool poisoned = false;                       // a tick failed half-way: the carried state is no longer what any caller expects
     std::string err;
+
+    uint8_t *slot_present(int r) const { return h_ring + (size_t)r * slot_bytes; }
+    int16_t *slot_pcm(int r) const { return reinterpret_cast<int16_t *>(h_ring + (size_t)r * slot_bytes + hdr); }
 };
 
 namespace {
@@ -78,6 +108,86 @@ int pfail(vad_pump *p, int code, const std::string &msg) {
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+inline void cpu_relax() {
+#if defined(__x86_64__)
+    _mm_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+
+// dst <- src, `bytes` a multiple of 16, both 16-byte aligned on the destination side: streaming stores where the ISA has them (the
+// data is bound for the DMA engine, not for this core's cache)
+inline void stream_copy(void *dst, const void *src, size_t bytes) {
+#if defined(__x86_64__)
+    const __m128i *s = static_cast<const __m128i *>(src);
+    __m128i *d = static_cast<__m128i *>(dst);
+    for (size_t i = 0; i < bytes / 16; ++i) _mm_stream_si128(d + i, _mm_loadu_si128(s + i));
+#else
+    std::memcpy(dst, src, bytes);
+#endif
+}
+inline void stream_fence() {
+#if defined(__x86_64__)
+    _mm_sfence();
+#else
+    std::atomic_thread_fence(std::memory_order_release);
+#endif
+}
+
+// An event count: waiters spin for a bounded time on their own condition, then sleep in the kernel until somebody signals.  signal()
+// is one atomic increment, plus a futex wake only if somebody sleeps.
+struct Gate {
+    std::atomic<uint32_t> seq{0};
+    std::atomic<int> sleepers{0};
+    static constexpr double kSpinMs = 0.020;
+
+    template <class Cond>
+    void wait(Cond cond) {
+        const double t0 = now_ms();
+        for (int i = 0;; ++i) {
+            if (cond()) return;
+            cpu_relax();
+            if ((i & 63) == 63 && now_ms() - t0 > kSpinMs) break;
+        }
+        for (;;) {
+            sleepers.fetch_add(1, std::memory_order_seq_cst);
+            const uint32_t s = seq.load(std::memory_order_seq_cst);
+            if (cond()) {
+                sleepers.fetch_sub(1, std::memory_order_seq_cst);
+                return;
+            }
+            // (a signal between the load of `seq` and here changes the word: the call returns at once)
+            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&seq), FUTEX_WAIT_PRIVATE, s, nullptr, nullptr, 0);
+            sleepers.fetch_sub(1, std::memory_order_seq_cst);
+        }
+    }
+    void signal() {
+        seq.fetch_add(1, std::memory_order_seq_cst);
+        if (sleepers.load(std::memory_order_seq_cst) > 0)
+            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&seq), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+    }
+};
+
+// host side of open / close: applied when the tick they were issued before is the next to retire (or at once if nothing is in flight)
+void apply_ops(vad_pump *p) {
+    while (!p->pending.empty() && p->pending.front().at_tick <= p->retired) {
+        const vad_pump::Op op = p->pending.front();
+        p->pending.pop_front();
+        if (op.open) {
+            p->active[op.stream] = 1;
+            p->triggered[op.stream] = 0;
+            p->temp_end[op.stream] = 0;
+            p->current[op.stream] = 0;
+            p->src_pos[op.stream] = 0;
+        } else {
+            p->active[op.stream] = 0;
+        }
+    }
 }
 
 }  // namespace
@@ -110,8 +220,8 @@ void vad_pump_destroy(vad_pump *p) {
     }
     for (hipEvent_t ev : p->tick_done) (void)hipEventDestroy(ev);
     for (float *s : p->d_state) (void)hipFree(s);
-    if (p->d_pcm) (void)hipFree(p->d_pcm);
-    if (p->h_pcm) (void)hipHostFree(p->h_pcm);
+    if (p->d_batch) (void)hipFree(p->d_batch);
+    if (p->h_ring) (void)hipHostFree(p->h_ring);
     if (p->h_prob) (void)hipHostFree(p->h_prob);
     for (hipStream_t cs : p->copy)
         if (cs) (void)hipStreamDestroy(cs);
@@ -142,6 +252,9 @@ int vad_pump_create(vad_engine *e, const vad_pump_params *prm, vad_pump **out) {
     p->pad = (double)p->sr * prm->speech_pad_ms / 1000.0;
     p->device = vad_device(e);
     if (p->device < 0 || vad_clone(e, &p->eng) != VAD_OK) return bail(VAD_ERR_NO_DEVICE);
+    // the clone takes the caller's options with it; the pump steps through the product kernels whatever the caller's engine was set to
+    // for its own A/B runs (impl=reference has no split-context step: every submit would fail)
+    if (vad_set_option(p->eng, "impl", "mfma") != VAD_OK) return bail(VAD_ERR_OPTION);
     // parts of whole 16-stream tiles (a tile is the kernels' unit; rows of a part start 16-byte aligned)
     const int tiles = (p->streams + 15) / 16;
     const int parts = std::max(1, std::min(prm->parts > 0 ? prm->parts : 1, tiles));
@@ -155,15 +268,18 @@ int vad_pump_create(vad_engine *e, const vad_pump_params *prm, vad_pump **out) {
     p->parts = (int)p->lo.size();
     if (hipSetDevice(p->device) != hipSuccess) return bail(VAD_ERR_HIP);
     const size_t S = (size_t)p->streams;
-    if (hipHostMalloc((void **)&p->h_pcm, (size_t)p->R * S * N * sizeof(int16_t), hipHostMallocDefault) != hipSuccess ||
+    p->hdr = (S + 4095) / 4096 * 4096;
+    p->slot_bytes = p->hdr + S * N * sizeof(int16_t);
+    if (hipHostMalloc((void **)&p->h_ring, (size_t)p->R * p->slot_bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&p->h_prob, (size_t)p->R * S * sizeof(float), hipHostMallocMapped) != hipSuccess)
         return bail(VAD_ERR_ALLOC);
-    std::memset(p->h_pcm, 0, (size_t)p->R * S * N * sizeof(int16_t));
+    std::memset(p->h_ring, 0, (size_t)p->R * p->slot_bytes);
+    for (int r = 0; r < p->R; ++r) std::memset(p->slot_present(r), 1, S);
     std::memset(p->h_prob, 0, (size_t)p->R * S * sizeof(float));
     void *dv = nullptr;
     if (hipHostGetDevicePointer(&dv, p->h_prob, 0) != hipSuccess || !dv) return bail(VAD_ERR_HIP);
     p->d_prob = static_cast<float *>(dv);
-    if (hipMalloc((void **)&p->d_pcm, 2 * S * N * sizeof(int16_t)) != hipSuccess) return bail(VAD_ERR_ALLOC);
+    if (hipMalloc((void **)&p->d_batch, 2 * p->slot_bytes) != hipSuccess) return bail(VAD_ERR_ALLOC);
     for (int b = 0; b < 2; ++b) {
         if (hipMalloc((void **)&p->d_ctx[b], S * C * sizeof(float)) != hipSuccess) return bail(VAD_ERR_ALLOC);
         if (hipMemset(p->d_ctx[b], 0, S * C * sizeof(float)) != hipSuccess) return bail(VAD_ERR_HIP);
@@ -189,15 +305,20 @@ int vad_pump_create(vad_engine *e, const vad_pump_params *prm, vad_pump **out) {
         if (!mk(&p->batch_free[b])) return bail(VAD_ERR_HIP);
     }
     p->tick_done.resize(p->R);
+    // a process with CPUs to spare lets hipEventSynchronize spin on the tick's event (lowest latency); one with fewer than four (one of
+    // eight ranks under a 16-CPU quota) sleeps on the interrupt instead: the CPU the spin would burn is the source thread's
+    const bool blocking = vad::default_host_threads(256) < 4;
     for (auto &ev : p->tick_done)
-        if (!mk(&ev)) return bail(VAD_ERR_HIP);
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)) != hipSuccess) return bail(VAD_ERR_HIP);
     if (vad_reserve(p->eng, p->sr, maxB, 1) != VAD_OK) return bail(VAD_ERR_ALLOC);
     if (hipDeviceSynchronize() != hipSuccess) return bail(VAD_ERR_HIP);
     p->slot_busy.assign(p->R, 0);
     p->active.assign(S, 1);
+    p->feed_mask.assign(S, 1);
     p->triggered.assign(S, 0);
     p->temp_end.assign(S, 0);
     p->current.assign(S, 0);
+    p->src_pos.assign(S, 0);
     *out = p;
     return VAD_OK;
 }
@@ -211,54 +332,78 @@ int vad_pump_geometry(const vad_pump *p, int *streams, int *chunk, int *ring_slo
     return VAD_OK;
 }
 
-int16_t *vad_pump_slot(vad_pump *p, int r) {
-    return (p && r >= 0 && r < p->R) ? p->h_pcm + (size_t)r * p->streams * p->N : nullptr;
-}
+int16_t *vad_pump_slot(vad_pump *p, int r) { return (p && r >= 0 && r < p->R) ? p->slot_pcm(r) : nullptr; }
+
+uint8_t *vad_pump_present(vad_pump *p, int r) { return (p && r >= 0 && r < p->R) ? p->slot_present(r) : nullptr; }
 
 const float *vad_pump_probs(const vad_pump *p, int r) {
     return (p && r >= 0 && r < p->R) ? p->h_prob + (size_t)r * p->streams : nullptr;
 }
 
-int vad_pump_submit(vad_pump *p, int r) {
+int vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present) {
     if (!p) return VAD_ERR_ARG;
+    if (p->poisoned) return pfail(p, VAD_ERR_HIP, "the pump failed half-way through an earlier tick; destroy it (" + p->err + ")");
     if (r < 0 || r >= p->R) return pfail(p, VAD_ERR_ARG, "vad_pump_submit: no such ring slot");
     if (p->slot_busy[r]) return pfail(p, VAD_ERR_ARG, "vad_pump_submit: the slot's previous tick has not been retired (vad_pump_poll)");
     PUMP_TRY(p, hipSetDevice(p->device));
     const int buf = (int)(p->ticks & 1);
     const size_t S = (size_t)p->streams, N = (size_t)p->N, C = (size_t)p->C;
-    int16_t *batch = p->d_pcm + (size_t)buf * S * N;
-    const int16_t *src = p->h_pcm + (size_t)r * S * N;
+    const bool masked = present != nullptr;
+    if (masked && present != p->slot_present(r)) std::memcpy(p->slot_present(r), present, S);
+    uint8_t *dbuf = p->d_batch + (size_t)buf * p->slot_bytes;
+    int16_t *batch = reinterpret_cast<int16_t *>(dbuf + p->hdr);
+    const uint8_t *d_present = masked ? dbuf : nullptr;
+    const int16_t *src = p->slot_pcm(r);
     const float *ctx_in = p->d_ctx[buf];
     float *ctx_out = p->d_ctx[buf ^ 1];
     hipStream_t copy = p->copy[buf];
+    // from the first queued operation on, a failure leaves the tick half-done: (h, c) of some parts advanced, the context ping-pong out
+    // of step.  There is no retry that is right; the pump says so from then on.
+    auto broken = [&](int code, const std::string &msg) {
+        p->poisoned = true;
+        return pfail(p, code, msg);
+    };
+#define TICK_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        const hipError_t rc_ = (expr);                                                                  \
+        if (rc_ != hipSuccess) return broken(VAD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(rc_)); \
+    } while (0)
     // the copies may not overwrite the batch buffer before the kernels of two ticks ago have read it
-    if (p->batch_used[buf]) PUMP_TRY(p, hipStreamWaitEvent(copy, p->batch_free[buf], 0));
+    if (p->batch_used[buf]) TICK_TRY(hipStreamWaitEvent(copy, p->batch_free[buf], 0));
     for (int k = 0; k < p->parts; ++k) {
         const size_t a = (size_t)p->lo[k], n = (size_t)(p->hi[k] - p->lo[k]);
-        PUMP_TRY(p, hipMemcpyAsync(batch + a * N, src + a * N, n * N * sizeof(int16_t), hipMemcpyHostToDevice, copy));
-        PUMP_TRY(p, hipEventRecord(p->h2d_done[buf][k], copy));
+        if (k == 0 && masked)        // the flags of ALL streams ride in front of part 0's audio: one copy (part 0 starts at stream 0)
+            TICK_TRY(hipMemcpyAsync(dbuf, p->slot_present(r), p->hdr + n * N * sizeof(int16_t), hipMemcpyHostToDevice, copy));
+        else
+            TICK_TRY(hipMemcpyAsync(batch + a * N, src + a * N, n * N * sizeof(int16_t), hipMemcpyHostToDevice, copy));
+        TICK_TRY(hipEventRecord(p->h2d_done[buf][k], copy));
     }
     for (int k = 0; k < p->parts; ++k) {
         const size_t a = (size_t)p->lo[k];
         const int n = p->hi[k] - p->lo[k];
-        PUMP_TRY(p, hipStreamWaitEvent(p->compute, p->h2d_done[buf][k], 0));
-        const int rc = vad_step_split(p->eng, p->sr, n, batch + a * N, sizeof(int16_t), (long)N, ctx_in + a * C, ctx_out + a * C, p->d_state[k],
-                                      p->d_prob + (size_t)r * S + a, p->compute);
-        if (rc != VAD_OK) return pfail(p, rc, std::string("vad_step_split: ") + vad_last_error(p->eng));
+        TICK_TRY(hipStreamWaitEvent(p->compute, p->h2d_done[buf][k], 0));
+        if (k > 0 && masked) TICK_TRY(hipStreamWaitEvent(p->compute, p->h2d_done[buf][0], 0));     // (the flags came with part 0)
+        const int rc = vad_step_present(p->eng, p->sr, n, batch + a * N, sizeof(int16_t), (long)N, ctx_in + a * C, ctx_out + a * C, p->d_state[k],
+                                        p->d_prob + (size_t)r * S + a, masked ? d_present + a : nullptr, p->compute);
+        if (rc != VAD_OK) return broken(rc, std::string("vad_step_present: ") + vad_last_error(p->eng));
     }
-    PUMP_TRY(p, hipEventRecord(p->batch_free[buf], p->compute));
-    PUMP_TRY(p, hipEventRecord(p->tick_done[r], p->compute));
+    TICK_TRY(hipEventRecord(p->batch_free[buf], p->compute));
+    TICK_TRY(hipEventRecord(p->tick_done[r], p->compute));
+#undef TICK_TRY
     p->batch_used[buf] = true;
     p->slot_busy[r] = 1;
-    p->inflight.push_back(r);
+    p->inflight.push_back(vad_pump::Flight{r, masked});
     ++p->ticks;
     return VAD_OK;
 }
 
+int vad_pump_submit(vad_pump *p, int r) { return vad_pump_submit_present(p, r, nullptr); }
+
 long vad_pump_poll(vad_pump *p, int block, vad_iter_event *out, long cap, int *slot) {
     if (!p || cap < 0 || (cap > 0 && !out)) return VAD_PUMP_ERROR;
     if (p->inflight.empty()) return VAD_PUMP_IDLE;
-    const int r = p->inflight.front();
+    const vad_pump::Flight f = p->inflight.front();
+    const int r = f.r;
     if (block) {
         if (hipEventSynchronize(p->tick_done[r]) != hipSuccess) {
             pfail(p, VAD_ERR_HIP, "hipEventSynchronize(tick_done)");
@@ -275,8 +420,21 @@ long vad_pump_poll(vad_pump *p, int block, vad_iter_event *out, long cap, int *s
     p->inflight.pop_front();
     p->slot_busy[r] = 0;
     if (slot) *slot = r;
-    return vad_iterator_feed(p->h_prob + (size_t)r * p->streams, p->active.data(), p->streams, p->N, p->threshold, p->min_silence, p->pad,
-                             p->triggered.data(), p->temp_end.data(), p->current.data(), out, cap);
+    apply_ops(p);                                // opens / closes issued before this tick was submitted take effect with it
+    const uint8_t *mask = p->active.data();
+    if (f.masked) {                              // a stream without a chunk this tick: no model call, no iterator call (utils_vad.py:507-549)
+        const uint8_t *pr = p->slot_present(r);
+        for (int s = 0; s < p->streams; ++s) p->feed_mask[s] = p->active[s] & (pr[s] != 0);
+        mask = p->feed_mask.data();
+    }
+    const long m = vad_iterator_feed(p->h_prob + (size_t)r * p->streams, mask, p->streams, p->N, p->threshold, p->min_silence, p->pad,
+                                     p->triggered.data(), p->temp_end.data(), p->current.data(), out, cap);
+    ++p->retired;
+    if (p->inflight.empty()) {                   // nothing in flight: later opens / closes have nothing to wait for
+        p->retired = p->ticks;
+        apply_ops(p);
+    }
+    return m;
 }
 
 int vad_pump_open(vad_pump *p, int stream) {
@@ -290,17 +448,26 @@ int vad_pump_open(vad_pump *p, int stream) {
     PUMP_TRY(p, hipMemsetAsync(p->d_state[k] + row * 128, 0, 128 * sizeof(float), p->compute));
     PUMP_TRY(p, hipMemsetAsync(p->d_state[k] + (n + row) * 128, 0, 128 * sizeof(float), p->compute));
     PUMP_TRY(p, hipMemsetAsync(p->d_ctx[p->ticks & 1] + (size_t)stream * p->C, 0, (size_t)p->C * sizeof(float), p->compute));
-    p->active[stream] = 1;
-    p->triggered[stream] = 0;
-    p->temp_end[stream] = 0;
-    p->current[stream] = 0;
+    // ... and the host side (iterator state, active flag) when those ticks have been retired: their probabilities belong to the slot's
+    // previous occupant and must neither advance the new stream's sample counter nor open a segment for it
+    p->pending.push_back(vad_pump::Op{p->ticks, stream, true});
+    if (p->inflight.empty()) {
+        p->retired = p->ticks;
+        apply_ops(p);
+    }
     return VAD_OK;
 }
 
 int vad_pump_close(vad_pump *p, int stream) {
     if (!p) return VAD_ERR_ARG;
     if (stream < 0 || stream >= p->streams) return pfail(p, VAD_ERR_ARG, "vad_pump_close: no such stream");
-    p->active[stream] = 0;                    // the slot is still computed (lock-step batch); it emits no events
+    // the slot is still computed (lock-step batch) but emits no events -- from the next tick submitted on: the ticks in flight carry
+    // chunks the stream did deliver, their events are still its own
+    p->pending.push_back(vad_pump::Op{p->ticks, stream, false});
+    if (p->inflight.empty()) {
+        p->retired = p->ticks;
+        apply_ops(p);
+    }
     return VAD_OK;
 }
 
@@ -325,11 +492,14 @@ int vad_pump_state(vad_pump *p, int stream, float *h, float *c, float *ctx) {
 // flight retire the oldest (wait, iterator logic, events).  depth 1: strictly one tick at a time -- the next chunks are written
 // after the previous tick's events are out, so "written -> events" is the latency of ONE tick.  depth >= 2: the sources write the
 // tick that comes next while `depth` ticks are in flight (they run depth + 1 ticks ahead of the retired ones).
-long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long first_tick, long n_ticks, int depth, int fill_threads,
-                   vad_iter_event *out, long cap, vad_pump_stats *st) {
+// Both sides BLOCK when they have to wait (Gate: 20 us of spinning, then a futex): the sources on the count of retired ticks, the
+// server on the count of sources that have written the slot.
+long vad_pump_play_gaps(vad_pump *p, const int16_t *rows, long ld, long period, const uint8_t *pattern, long pattern_ticks, long first_tick,
+                        long n_ticks, int depth, int fill_threads, vad_iter_event *out, long cap, vad_pump_stats *st) {
     if (!p) return VAD_PUMP_ERROR;
     const long N = p->N;
-    if (!rows || ld < period || period < N || period % N || first_tick < 0 || n_ticks < 0 || cap < 0 || (cap > 0 && !out)) {
+    if (!rows || ld < period || period < N || period % N || first_tick < 0 || n_ticks < 0 || cap < 0 || (cap > 0 && !out) ||
+        (pattern && pattern_ticks <= 0)) {
         pfail(p, VAD_ERR_ARG, "vad_pump_play: bad argument");
         return VAD_PUMP_ERROR;
     }
@@ -339,9 +509,6 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
     }
     depth = std::max(1, std::min(depth, p->R - 1));
     const long ahead = depth == 1 ? 1 : depth + 1;                             // <= R: the slot's previous tick has been retired by then
-    // waits spin when this process has CPUs to spare and yield when it does not (one of eight ranks under a 16-CPU quota has two: nine
-    // spinning threads per rank would get the whole node throttled, host_threads.hpp)
-    const bool polite = vad::default_host_threads(256) < 4;
     const bool silent = fill_threads < 0;        // diagnostic: the sources write nothing (the slots keep their content): device side only
     int nsrc = fill_threads > 0 ? fill_threads : std::max(1, std::min(8, vad::default_host_threads(32) - 2));
     nsrc = std::max(1, std::min(nsrc, (p->streams + 63) / 64));
@@ -351,31 +518,42 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
     std::vector<std::atomic<int>> written(p->R);
     for (auto &w : written) w.store(0);
     std::atomic<bool> stop{false};
-    std::atomic<long> fill_ns{0};
+    std::atomic<long> fill_ns{0}, chunks{0};
+    Gate room, filled;                           // room: a tick was retired (sources wait); filled: a source finished a slot (server waits)
     auto source = [&](int k) {
         const long b0 = std::min<long>(p->streams, k * per), b1 = std::min<long>(p->streams, b0 + per);
+        long mine = 0;
         for (long t = first_tick; t < last; ++t) {
-            // (spin, do not yield: a sched_yield hands the CPU to whatever else is runnable there for a scheduler period -- measured as
-            //  single 6 ms stalls of a tick, 1-4 % of a 0.2-0.5 s run; a source thread of an audio server would block on its socket instead)
-            while (t - retired.load(std::memory_order_acquire) >= ahead) {
-                if (stop.load(std::memory_order_relaxed)) return;
-                if (polite) std::this_thread::yield();
-                else _mm_pause();
-            }
+            room.wait([&] { return t - retired.load(std::memory_order_acquire) < ahead || stop.load(std::memory_order_relaxed); });
+            if (stop.load(std::memory_order_relaxed)) return;
             if (!silent && b1 > b0) {
                 const double f0 = now_ms();
-                int16_t *slot = p->h_pcm + (size_t)(t % p->R) * p->streams * N;
-                const long off = (t * N) % period;
-                for (long b = b0; b < b1; ++b) {
-                    const __m128i *src = reinterpret_cast<const __m128i *>(rows + b * ld + off);
-                    __m128i *dst = reinterpret_cast<__m128i *>(slot + b * N);
-                    for (long i = 0; i < N / 8; ++i) _mm_stream_si128(dst + i, _mm_loadu_si128(src + i));
+                const int r = (int)(t % p->R);
+                int16_t *slot = p->slot_pcm(r);
+                if (!pattern) {
+                    const long off = (t * N) % period;
+                    for (long b = b0; b < b1; ++b) stream_copy(slot + b * N, rows + b * ld + off, (size_t)N * sizeof(int16_t));
+                    mine += b1 - b0;
+                } else {
+                    // stream b has a chunk this tick iff its flag says so; its audio advances only then (a late packet delays the
+                    // stream's own next chunk, it does not skip audio)
+                    const uint8_t *pat = pattern + (size_t)(t % pattern_ticks) * p->streams;
+                    uint8_t *flags = p->slot_present(r);
+                    for (long b = b0; b < b1; ++b) {
+                        flags[b] = pat[b];
+                        if (!pat[b]) continue;
+                        const long off = (p->src_pos[b]++ * N) % period;
+                        stream_copy(slot + b * N, rows + b * ld + off, (size_t)N * sizeof(int16_t));
+                        ++mine;
+                    }
                 }
-                _mm_sfence();
+                stream_fence();
                 fill_ns.fetch_add((long)((now_ms() - f0) * 1e6), std::memory_order_relaxed);
             }
             written[t % p->R].fetch_add(1, std::memory_order_release);
+            filled.signal();
         }
+        chunks.fetch_add(mine, std::memory_order_relaxed);
     };
     std::vector<std::thread> sources;
     for (int k = 0; k < nsrc; ++k) sources.emplace_back(source, k);
@@ -396,30 +574,29 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
         for (long i = 0; i < m; ++i, ++n_events)
             if (n_events < cap) out[n_events] = scratch[i];
         retired.fetch_add(1, std::memory_order_release);
+        room.signal();
         return true;
     };
     const double t0 = now_ms();
     for (long t = first_tick; t < last && ok; ++t) {
         const int r = (int)(t % p->R);
-        while (written[r].load(std::memory_order_acquire) < nsrc) {
-            if (polite) std::this_thread::yield();
-            else _mm_pause();
-        }
+        filled.wait([&] { return written[r].load(std::memory_order_acquire) >= nsrc; });
         written[r].store(0, std::memory_order_relaxed);          // (the slot's next writers wait for this tick's retirement)
         const double s0 = now_ms();
         t_written[r] = s0;
-        ok = vad_pump_submit(p, r) == VAD_OK;
+        ok = vad_pump_submit_present(p, r, pattern && !silent ? p->slot_present(r) : nullptr) == VAD_OK;
         submit_ms += now_ms() - s0;
         if (ok && (int)p->inflight.size() >= depth) ok = retire();
     }
     while (ok && !p->inflight.empty()) ok = retire();
     const double t1 = now_ms();
     stop.store(true);
+    room.signal();
     for (auto &th : sources) th.join();
     if (!ok) {
         (void)hipStreamSynchronize(p->compute);                                  // leave nothing in flight behind an error
         while (!p->inflight.empty()) {
-            p->slot_busy[p->inflight.front()] = 0;
+            p->slot_busy[p->inflight.front().r] = 0;
             p->inflight.pop_front();
         }
         return VAD_PUMP_ERROR;
@@ -438,8 +615,14 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
         st->wait_ms_mean = n_ticks ? wait_ms / n_ticks : 0.0;
         st->fill_threads = silent ? 0 : nsrc;
         st->depth = depth;
+        st->chunks = silent ? (long)p->streams * n_ticks : chunks.load();
     }
     return n_events;
+}
+
+long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long first_tick, long n_ticks, int depth, int fill_threads,
+                   vad_iter_event *out, long cap, vad_pump_stats *st) {
+    return vad_pump_play_gaps(p, rows, ld, period, nullptr, 0, first_tick, n_ticks, depth, fill_threads, out, cap, st);
 }
 
 }  // extern "C"

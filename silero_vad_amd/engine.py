@@ -140,14 +140,33 @@ class Engine:
                                      ctx.data_ptr(), state.data_ptr(), prob.data_ptr(), self._stream()))
         return prob
 
-    def step_host(self, host_pcm, dev_pcm, sr, ctx, state, dev_prob, host_prob, stream=None):
+    def step_present(self, pcm, sr, ctx, state, prob, present=None, ctx_out=None):
+        """vad_step_present: one step of B live streams (pcm [B, N] float32 or int16, cuda) of which only the rows with
+        present[b] != 0 (uint8 / bool cuda tensor [B]; None = all) have a chunk this tick.  An absent row's ctx / state are left
+        exactly as they are and prob[b] = -1.0 (VAD_PROB_ABSENT).  ctx_out: a second context buffer (else in place)."""
+        B = pcm.shape[0]
+        if present is not None and (not present.is_cuda or present.numel() != B or present.element_size() != 1 or not present.is_contiguous()):
+            raise ValueError("present must be a contiguous 1-byte cuda tensor of B flags")
+        self._check(self._L.vad_step_present(self._h, sr, B, pcm.data_ptr(), pcm.element_size(), pcm.stride(0) if B > 1 else pcm.shape[1],
+                                             ctx.data_ptr(), None if ctx_out is None else ctx_out.data_ptr(), state.data_ptr(), prob.data_ptr(),
+                                             None if present is None else present.data_ptr(), self._stream()))
+        return prob
+
+    def step_host(self, host_pcm, dev_pcm, sr, ctx, state, dev_prob, host_prob, stream=None, host_present=None, dev_present=None):
         """One tick from page-locked host chunks to page-locked host probabilities on `stream` (a raw stream handle; default:
         torch's current stream): H2D, the step, D2H -- vad_step_host, asynchronous.  dev_prob None: the kernel writes the
-        probabilities straight into host_prob."""
+        probabilities straight into host_prob.  host_present / dev_present (page-locked [B] bytes and its device staging): the
+        flags of vad_step_host_present (absent rows keep their state)."""
         B = host_pcm.shape[0]
-        self._check(self._L.vad_step_host(self._h, sr, B, host_pcm.data_ptr(), host_pcm.element_size(), dev_pcm.data_ptr(),
-                                          ctx.data_ptr(), state.data_ptr(), None if dev_prob is None else dev_prob.data_ptr(), host_prob.data_ptr(),
-                                          self._stream() if stream is None else ctypes.c_void_p(stream)))
+        s = self._stream() if stream is None else ctypes.c_void_p(stream)
+        dp = None if dev_prob is None else dev_prob.data_ptr()
+        if host_present is None:
+            self._check(self._L.vad_step_host(self._h, sr, B, host_pcm.data_ptr(), host_pcm.element_size(), dev_pcm.data_ptr(),
+                                              ctx.data_ptr(), state.data_ptr(), dp, host_prob.data_ptr(), s))
+        else:
+            self._check(self._L.vad_step_host_present(self._h, sr, B, host_pcm.data_ptr(), host_pcm.element_size(), dev_pcm.data_ptr(),
+                                                      ctx.data_ptr(), state.data_ptr(), dp, host_prob.data_ptr(), host_present.data_ptr(),
+                                                      dev_present.data_ptr(), s))
 
     def upload_rows(self, rows, lens, n, width, elem_size, dst, how=0):
         """Ragged rows in PINNED host memory -> dst[n, width] on the GPU, zero padded, on the current stream

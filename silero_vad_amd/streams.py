@@ -1033,6 +1033,12 @@ class StreamPool:
     `graph=True` the step is captured once into a hipGraph and replayed; the input is then copied
     into a fixed staging buffer first.
 
+    `tick(chunks, present=flags)`: live streams do not arrive in lock step.  A row whose flag is 0 has NO chunk this tick and is
+    not stepped: its (h, c) and context stay bit for bit what they were and its probability slot holds -1.0 (VAD_PROB_ABSENT) --
+    what the reference's per-stream callers do by simply not calling the model (src/silero_vad/utils_vad.py:507-549, one
+    `__call__` per chunk that arrived).  The other rows' results do not depend on the flags.  Without flags the tick is the
+    same launch it always was (a second hipGraph holds the flagged form; it is captured on first use).
+
     `dtype=torch.int16`: the chunks are 16-bit PCM, scaled by 1/32768 inside the kernel's loads -- what every
     non-Python client of the reference feeds (examples/onnx_sequence/run.py:115-119, examples/cpp/wav.h:113-118) and
     half the PCIe bytes of fp32.
@@ -1068,6 +1074,10 @@ class StreamPool:
                 self.host_prob = torch.zeros((self.host_slots, self.capacity), dtype=torch.float32, pin_memory=True)
                 self.stream = torch.cuda.Stream(self.device)
                 self._done = [torch.cuda.Event() for _ in range(self.host_slots)]
+                self.host_present = torch.ones((self.host_slots, self.capacity), dtype=torch.uint8, pin_memory=True)
+            self.present = torch.ones((self.capacity,), dtype=torch.uint8, device=self.device)     # flags of the tick (device staging)
+        self._graph_present = None
+        self._host_graphs_present = None
         self.open_mask = np.zeros(self.capacity, dtype=bool)
         self._free = list(range(self.capacity - 1, -1, -1))
         self._graph = None
@@ -1078,16 +1088,22 @@ class StreamPool:
         if graph:
             self._capture()
 
-    def _launch(self):
-        if self.dtype == torch.float32:
+    def _launch(self, masked=False):
+        if masked:  # rows with self.present[b] == 0 are not stepped (vad_step_present)
+            self.engine.step_present(self.pcm, self.sr, self.ctx, self.state, self.prob, self.present)
+        elif self.dtype == torch.float32:
             self.engine.step(self.pcm, self.sr, self.ctx, self.state, self.prob)
         else:       # one chunk of int16 PCM per stream: a ONE-step vad_forward_audio_i16 call (the same fused kernel)
             self.engine.forward_audio(self.pcm, self.sr, self.ctx, self.state, self.prob.view(self.capacity, 1))
 
-    def _host_tick(self, r, stream=None):
+    def _host_tick(self, r, stream=None, masked=False):
         """What slot r's graph holds: ingest ring -> HBM, the step, probabilities -> host (one native call: vad_step_host)."""
         # (the kernel stores the probabilities straight into the page-locked host_prob[r]: no device buffer, no D2H operation)
-        self.engine.step_host(self.host_pcm[r], self.pcm, self.sr, self.ctx, self.state, None, self.host_prob[r], stream)
+        if masked:
+            self.engine.step_host(self.host_pcm[r], self.pcm, self.sr, self.ctx, self.state, None, self.host_prob[r], stream,
+                                  host_present=self.host_present[r], dev_present=self.present)
+        else:
+            self.engine.step_host(self.host_pcm[r], self.pcm, self.sr, self.ctx, self.state, None, self.host_prob[r], stream)
 
     def _capture(self):
         """Capture one step into a hipGraph.  The graph bakes in the engine's scratch addresses, so it is tied to
@@ -1107,6 +1123,14 @@ class StreamPool:
             with torch.cuda.graph(g):
                 self._launch()
             self._graph = g
+            if self._graph_present is not None:            # (only pools that have ticked with flags hold the flagged graphs)
+                with torch.cuda.stream(side):
+                    self._launch(masked=True)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch(masked=True)
+                self._graph_present = g
             if self.host_slots:
                 self._host_graphs = []
                 for r in range(self.host_slots):
@@ -1114,6 +1138,13 @@ class StreamPool:
                     with torch.cuda.graph(hg, stream=self.stream):
                         self._host_tick(r)
                     self._host_graphs.append(hg)
+                if self._host_graphs_present is not None:
+                    self._host_graphs_present = []
+                    for r in range(self.host_slots):
+                        hg = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(hg, stream=self.stream):
+                            self._host_tick(r, masked=True)
+                        self._host_graphs_present.append(hg)
             torch.cuda.synchronize(self.device)
             self.ctx.copy_(keep_ctx)                       # the warm-up step advanced them
             self.state.copy_(keep_state)
@@ -1159,39 +1190,57 @@ class StreamPool:
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     # -- the tick --------------------------------------------------------------------------------------
-    def tick(self, chunks: torch.Tensor) -> torch.Tensor:
+    def tick(self, chunks: torch.Tensor, present=None) -> torch.Tensor:
         if chunks.shape != (self.capacity, self.n):
             raise ValueError(f"expected chunks of shape {(self.capacity, self.n)}, got {tuple(chunks.shape)}")
         if (chunks.dtype == torch.int16) != (self.dtype == torch.int16):
             raise TypeError(f"this pool takes {self.dtype} chunks, got {chunks.dtype}")
         with torch.cuda.device(self.device):
             self.pcm.copy_(chunks, non_blocking=True)
-            self.tick_staged()
+            if present is not None:
+                self.present.copy_(self._flags(present), non_blocking=True)
+            self.tick_staged(masked=present is not None)
         return self.prob
 
-    def tick_staged(self):
+    def _flags(self, present) -> torch.Tensor:
+        f = torch.as_tensor(present)
+        if f.shape != (self.capacity,):
+            raise ValueError(f"expected {self.capacity} present flags, got shape {tuple(f.shape)}")
+        return (f != 0).to(torch.uint8)
+
+    def tick_staged(self, masked: bool = False):
         """One step over whatever `self.pcm` holds (for callers that write the staging buffer
-        themselves, e.g. a device-side audio source)."""
+        themselves, e.g. a device-side audio source); masked: only the rows flagged in `self.present`."""
         if self._graph is not None:
-            if self.engine.scratch_generation() != self._graph_gen:
+            if masked and self._graph_present is None:
+                self._graph_present = False                # (asks _capture for the flagged graphs too)
+                self._capture()
+            elif self.engine.scratch_generation() != self._graph_gen:
                 self._capture()                            # the engine's scratch moved: the old graph is stale
-            self._graph.replay()
+            (self._graph_present if masked else self._graph).replay()
         else:
-            self._launch()
+            self._launch(masked)
         return self.prob
 
     # -- host to host ------------------------------------------------------------------------------------
-    def submit(self, r: int = 0):
-        """Start one tick over `host_pcm[r]` on the pool's stream; returns at once (see the class docstring)."""
+    def submit(self, r: int = 0, present=None):
+        """Start one tick over `host_pcm[r]` on the pool's stream; returns at once (see the class docstring).  present: flags of
+        the streams that have a chunk in the slot (None = all; or True = `host_present[r]` as the sources left it)."""
         if not self.host_slots:
             raise RuntimeError("StreamPool was created without host_slots")
+        masked = present is not None
+        if masked and present is not True:
+            self.host_present[r].copy_(self._flags(present))
         if self._use_graph:
-            if self.engine.scratch_generation() != self._graph_gen:
+            if masked and self._host_graphs_present is None:
+                self._host_graphs_present = []
+                self._capture()
+            elif self.engine.scratch_generation() != self._graph_gen:
                 self._capture()
             with torch.cuda.stream(self.stream):             # (replay launches on torch's current stream)
-                self._host_graphs[r].replay()
+                (self._host_graphs_present if masked else self._host_graphs)[r].replay()
         else:       # one native call on the pool's stream: no stream switch on the host side
-            self._host_tick(r, self.stream.cuda_stream)
+            self._host_tick(r, self.stream.cuda_stream, masked)
         self._done[r].record(self.stream)
 
     def wait(self, r: int = 0) -> torch.Tensor:
@@ -1294,10 +1343,12 @@ class StreamPump:
                                              shape=(self.streams, self.n)) for r in range(self.ring_slots)]
         self._probs = [np.ctypeslib.as_array(ctypes.cast(self._L.vad_pump_probs(h, r), ctypes.POINTER(ctypes.c_float)),
                                              shape=(self.streams,)) for r in range(self.ring_slots)]
+        self._present = [np.ctypeslib.as_array(ctypes.cast(self._L.vad_pump_present(h, r), ctypes.POINTER(ctypes.c_uint8)),
+                                               shape=(self.streams,)) for r in range(self.ring_slots)]
 
     def close(self):
         if getattr(self, "_h", None):
-            self._slots = self._probs = None
+            self._slots = self._probs = self._present = None
             self._L.vad_pump_destroy(self._h)
             self._h = None
 
@@ -1313,8 +1364,23 @@ class StreamPump:
     def probs(self, r: int) -> np.ndarray:
         return self._probs[r]
 
-    def submit(self, r: int):
-        self._check(self._L.vad_pump_submit(self._h, int(r)))
+    def present(self, r: int) -> np.ndarray:
+        """Slot r's flag row, [streams] uint8 (page-locked, in front of the slot's audio): 0 = the stream has no chunk this tick."""
+        return self._present[r]
+
+    def submit(self, r: int, present=None):
+        """Start the tick over ring slot r.  present: None = every stream has a chunk; True = the flags the sources wrote into
+        `present(r)`; an array of `streams` flags = copied there.  A stream whose flag is 0 is not stepped: its (h, c), context and
+        iterator counters stay as they are and `probs(r)[b]` reads -1.0 (vad_pump_submit_present)."""
+        if present is None:
+            self._check(self._L.vad_pump_submit(self._h, int(r)))
+            return
+        if present is not True:
+            f = np.asarray(present)
+            if f.shape != (self.streams,):
+                raise ValueError(f"expected {self.streams} present flags, got shape {f.shape}")
+            self._present[r][:] = f != 0
+        self._check(self._L.vad_pump_submit_present(self._h, int(r), self._present[r].ctypes.data))
 
     def poll(self, block: bool = True):
         """-> (events, ring slot) of the oldest submitted tick; (None, None) if nothing is in flight or (block=False) it has not finished."""
@@ -1339,16 +1405,22 @@ class StreamPump:
         self._check(self._L.vad_pump_state(self._h, int(stream), h.ctypes.data, c.ctypes.data, x.ctypes.data))
         return h, c, x
 
-    def play(self, rows: np.ndarray, n_ticks: int, first_tick: int = 0, depth: int = 2, fill_threads: int = 0, max_events: int = 0):
+    def play(self, rows: np.ndarray, n_ticks: int, first_tick: int = 0, depth: int = 2, fill_threads: int = 0, max_events: int = 0,
+             pattern: np.ndarray = None):
         """vad_pump_play: stream b plays rows[b] (int16, length a multiple of the chunk) circularly, chunk by chunk.
+        pattern [pattern_ticks, streams] uint8 (vad_pump_play_gaps): stream b delivers a chunk at tick t iff pattern[t % pattern_ticks, b];
+        its audio advances only when it delivers.
         -> (events [(stream, {...}), ...] (the first max_events of them), stats dict)."""
         if rows.dtype != np.int16 or rows.ndim != 2 or rows.shape[0] != self.streams or not rows.flags.c_contiguous:
             raise ValueError(f"rows must be C-contiguous int16 [{self.streams}, period]")
+        if pattern is not None and (pattern.dtype != np.uint8 or pattern.ndim != 2 or pattern.shape[1] != self.streams or not pattern.flags.c_contiguous):
+            raise ValueError(f"pattern must be C-contiguous uint8 [pattern_ticks, {self.streams}]")
         cap = int(max_events)
         buf = (_lib.IterEvent * max(cap, 1))()
         st = _lib.PumpStats()
-        m = self._L.vad_pump_play(self._h, rows.ctypes.data, rows.shape[1], rows.shape[1], int(first_tick), int(n_ticks), int(depth),
-                                  int(fill_threads), buf if cap else None, cap, ctypes.byref(st))
+        m = self._L.vad_pump_play_gaps(self._h, rows.ctypes.data, rows.shape[1], rows.shape[1], None if pattern is None else pattern.ctypes.data,
+                                       0 if pattern is None else pattern.shape[0], int(first_tick), int(n_ticks), int(depth),
+                                       int(fill_threads), buf if cap else None, cap, ctypes.byref(st))
         if m < 0:
             raise RuntimeError("vad_pump_play: " + self._L.vad_pump_last_error(self._h).decode())
         ev = [(buf[i].slot, {"end" if buf[i].kind else "start": buf[i].sample}) for i in range(min(m, cap))]

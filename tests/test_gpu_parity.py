@@ -2395,3 +2395,251 @@ def test_step_split_equals_step(model, golden, tag):
     assert L.vad_step_split(*args(c0.data_ptr(), cx[0].data_ptr(), ld=n - 1)) == 1                                   # row stride < N
     assert L.vad_step_split(*args(None, cx[0].data_ptr())) == 1
     assert L.vad_step_split(eng._h, 44100, B, x.data_ptr(), 4, n, c0.data_ptr(), cx[0].data_ptr(), st_b.data_ptr(), p.data_ptr(), None) == 2
+
+
+# ---- (30) live streams that miss ticks: present[] flags (vad_step_present, StreamPool.tick(present=), vad_pump_submit_present) --------------
+def gap_pattern(streams, chunks, rng, miss=0.10, max_burst=5):
+    """[ticks, streams] uint8: every stream delivers exactly `chunks` chunks; between deliveries it misses ticks in bursts of 1..max_burst
+    (about `miss` of its ticks), independently of the others; after its last chunk it stays absent.  The reference's picture of a live
+    stream: the caller calls the model when a chunk arrived (src/silero_vad/utils_vad.py:507-549), not on a global clock."""
+    cols, longest = [], 0
+    p_start = miss / (1.0 - miss) / ((1 + max_burst) / 2.0)            # bursts per delivered chunk
+    for _ in range(streams):
+        col = []
+        for _ in range(chunks):
+            if rng.random() < p_start:
+                col += [0] * int(rng.integers(1, max_burst + 1))
+            col.append(1)
+        cols.append(col)
+        longest = max(longest, len(col))
+    pat = np.zeros((longest, streams), np.uint8)
+    for s, col in enumerate(cols):
+        pat[:len(col), s] = col
+    return pat
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, golden, tag):
+    """100 live streams, each missing ~10 % of the ticks in bursts of up to 5, through vad_pump_submit_present: every stream's
+    probabilities, events and final (h, c, context) EQUAL -- bit for bit -- the gap-free run in which it is fed its own chunks back to
+    back (so do its tile neighbours': a row's result does not depend on the flags of the others), an absent stream's slot reads
+    VAD_PROB_ABSENT, and for a handful of streams the events equal a per-stream VADIterator over the B = 1 model object fed only that
+    stream's chunks; the probabilities agree with the CPU oracle on the stream's own audio.  vad_pump_play_gaps (the loop natively,
+    flags written by the source threads) gives the same events.  (reference: utils_vad.py:507-549, JIT!/vad/model/vad_annotator.py:72,86-87,
+    examples/cpp/silero-vad-onnx.cpp:335-390)"""
+    from silero_vad_amd import StreamPump, VADIterator
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    pcm = g["pcm_i16"]
+    cap, K = 100, 110
+    rows = np.ascontiguousarray(np.stack([np.roll(pcm, -(40 * n + s * 7919))[:K * n] for s in range(cap)]))
+    pat = gap_pattern(cap, K, np.random.default_rng(5))
+    Tt = pat.shape[0]
+    spans = np.array([np.flatnonzero(pat[:, s])[-1] + 1 for s in range(cap)])         # ticks from a stream's first to its last chunk
+    missing = 1.0 - K / spans.mean()
+    assert (pat.sum(0) == K).all() and 0.06 < missing < 0.15 and Tt > K + 5
+    rec = golden["segments"][tag]["iterator"]["default"]
+
+    def run(pattern):
+        pump = StreamPump(model.engine, sr, streams=cap, parts=2, ring_slots=3, **rec["init"])
+        events = {s: [] for s in range(cap)}
+        got = np.full((cap, K), np.nan, np.float32)
+        pos = np.zeros(cap, np.int64)
+        ticks = K if pattern is None else pattern.shape[0]
+        sent = []
+        for t in range(ticks + 1):
+            if t < ticks:
+                r = t % 3
+                fl = np.ones(cap, np.uint8) if pattern is None else pattern[t]
+                slot = pump.slot(r)
+                slot[:] = 12345                                    # an absent stream's part of the slot holds whatever it holds
+                for s in np.flatnonzero(fl):
+                    slot[s] = rows[s, pos[s] * n:(pos[s] + 1) * n]
+                sent.append((fl.copy(), pos.copy()))
+                pos += fl
+                pump.submit(r, present=None if pattern is None else fl)
+            if t > 0:
+                ev, r = pump.poll()
+                fl, at = sent[t - 1]
+                p = pump.probs(r)
+                assert (p[fl == 0] == -1.0).all()                   # VAD_PROB_ABSENT
+                got[fl != 0, at[fl != 0]] = p[fl != 0]
+                for s, e in ev:
+                    assert fl[s], "an absent stream emitted an event"
+                    events[s].append(e)
+        state = [pump.state(s) for s in range(cap)]
+        pump.close()
+        return got, events, state
+
+    want, want_ev, want_st = run(None)
+    got, got_ev, got_st = run(pat)
+    assert np.array_equal(got, want) and not np.isnan(got).any()
+    assert got_ev == want_ev and sum(len(v) for v in got_ev.values()) > 100
+    for s in range(cap):
+        for a, b in zip(got_st[s], want_st[s]):
+            assert np.array_equal(a, b), s
+    ref = oracle.audio_forward(rows[:32].astype(np.float32) / 32768.0, sr)
+    assert np.abs(got[:32] - ref).max() < TIGHT and ref.max() > 0.9
+    for s in (0, 41, 99):
+        model.reset_states()
+        one = VADIterator(model, sampling_rate=sr, **rec["init"])
+        mine = [e for t in range(K) if (e := one(torch.from_numpy(rows[s, t * n:(t + 1) * n].astype(np.float32) / 32768.0)))]
+        assert got_ev[s] == mine, s
+    flat = sorted((s, k, v) for s in range(cap) for e in got_ev[s] for k, v in e.items())
+    for depth in (1, 2):
+        pump = StreamPump(model.engine, sr, streams=cap, parts=1, ring_slots=4, **rec["init"])
+        ev, stats = pump.play(rows, Tt, depth=depth, fill_threads=2, max_events=100000, pattern=pat)
+        assert stats["chunks"] == cap * K and stats["ticks"] == Tt
+        assert sorted((s, k, v) for s, e in ev for k, v in e.items()) == flat, depth
+        pump.close()
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_step_present_leaves_absent_rows_untouched(model, golden, tag):
+    """vad_step_present on every step path (fused one-kernel step; latency frontend + small / MFMA recurrence; the throughput
+    frontend of a 13 000-stream step), fp32 and int16 PCM, in place and with a second context buffer: rows whose flag is 0 keep
+    (h, c) and context bit for bit and read VAD_PROB_ABSENT, every other row equals the unflagged step bit for bit; with a NULL
+    pointer the call IS vad_step_split."""
+    eng = model.engine
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    dev = model.device
+    rng = np.random.default_rng(3)
+    cases = [(1, {}), (20, {}), (20, {"fuse_step": "0"}), (1500, {"fuse_step": "0", "rec_form": "mfma"}), (13000, {})]
+    for B, opts in cases:
+        T = 6 if B < 2000 else 3
+        rows = rolled_rows(g["wav"], B, T * n, 1201)
+        for dtype in (torch.float32, torch.int16):
+            x = torch.from_numpy(rows if dtype == torch.float32 else (rows * 32768.0).clip(-32768, 32767).astype(np.int16)).to(dev)
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            try:
+                for split in (False, True):
+                    ctx = torch.zeros((B, n // 8), device=dev)
+                    st = torch.zeros((2, B, 128), device=dev)
+                    ctx2 = [torch.zeros((B, n // 8), device=dev), torch.full((B, n // 8), 9.0, device=dev)]
+                    st2 = torch.zeros((2, B, 128), device=dev)
+                    for t in range(T):
+                        chunk = x[:, t * n:(t + 1) * n].contiguous()
+                        fl = torch.from_numpy((rng.random(B) > 0.3).astype(np.uint8)).to(dev)
+                        if t == 1:
+                            fl[:] = 0 if B > 1 else 1               # a tick in which nobody delivers
+                        # the unflagged step on copies: what the present rows must equal
+                        c_ref, s_ref, p_ref = ctx.clone(), st.clone(), torch.empty((B,), device=dev)
+                        eng.step_present(chunk, sr, c_ref, s_ref, p_ref)
+                        p = torch.full((B,), 5.0, device=dev)
+                        junk = chunk.clone()
+                        junk[fl == 0] = 77 if dtype == torch.int16 else float("nan")      # absent rows' PCM is ignored
+                        if split:
+                            ctx2[t & 1].copy_(ctx)
+                            eng.step_present(junk, sr, ctx2[t & 1], st2.copy_(st), p, fl, ctx_out=ctx2[(t + 1) & 1])
+                            c_new, s_new = ctx2[(t + 1) & 1], st2
+                        else:
+                            c_new, s_new = ctx.clone(), st.clone()
+                            eng.step_present(junk, sr, c_new, s_new, p, fl)
+                        on = fl != 0
+                        assert torch.equal(p[on], p_ref[on]) and (p[~on] == -1.0).all(), (B, opts, dtype, split, t)
+                        assert torch.equal(c_new[on], c_ref[on]) and torch.equal(c_new[~on], ctx[~on])
+                        assert torch.equal(s_new[:, on], s_ref[:, on]) and torch.equal(s_new[:, ~on], st[:, ~on])
+                        ctx, st = c_new.clone(), s_new.clone()
+                    assert st.abs().max() > 0
+            finally:
+                for k in opts:
+                    eng.set_option(k, {"fuse_step": "1", "rec_form": "auto"}[k])
+    L = eng._L
+    p = torch.empty((4,), device=dev)
+    assert L.vad_step_present(eng._h, sr, 4, x.data_ptr(), 3, n, ctx.data_ptr(), None, st.data_ptr(), p.data_ptr(), None, None) == 1     # element size
+
+
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+@pytest.mark.parametrize("mode", ["graph", "eager", "host"])
+def test_stream_pool_tick_with_present_flags(model, golden, tag, mode):
+    """StreamPool.tick(chunks, present=) / submit(r, present=): the hipGraph-captured, the eager and the host-to-host tick with flags
+    against the same pool ticked without flags on each stream's own chunk sequence: bit-identical probabilities and carried state,
+    -1.0 in the slots of absent streams; ticks with and without flags may alternate on one pool."""
+    from silero_vad_amd import Engine, StreamPool
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    cap, K = 40, 30
+    pcm = g["pcm_i16"]
+    rows = np.ascontiguousarray(np.stack([np.roll(pcm, -(40 * n + s * 7919))[:K * n] for s in range(cap)]))
+    tail = gap_pattern(cap, K - 3, np.random.default_rng(11), miss=0.2)
+    pat = np.concatenate([np.ones((3, cap), np.uint8), tail])     # the first three ticks go WITHOUT flags (everybody delivers)
+    Tt = pat.shape[0]
+    assert (pat.sum(0) == K).all()
+
+    def run(flags):
+        eng = Engine(device=0)
+        pool = StreamPool(eng, sr, capacity=cap, graph=mode != "eager", dtype=torch.int16, host_slots=2 if mode == "host" else 0)
+        pool.open_all()
+        got = np.full((cap, K), np.nan, np.float32)
+        pos = np.zeros(cap, np.int64)
+        for t in range(Tt if flags else K):
+            fl = pat[t] if flags else np.ones(cap, np.uint8)
+            chunk = np.full((cap, n), -321, np.int16)
+            for s in np.flatnonzero(fl):
+                chunk[s] = rows[s, pos[s] * n:(pos[s] + 1) * n]
+            use = None if (not flags or t < 3) else fl
+            if mode == "host":
+                r = t % 2
+                pool.host_pcm[r].copy_(torch.from_numpy(chunk))
+                pool.submit(r, present=use)
+                p = pool.wait(r).numpy().copy()
+            else:
+                p = pool.tick(torch.from_numpy(chunk).to(model.device), present=None if use is None else torch.from_numpy(use)).cpu().numpy()
+            if use is not None:
+                assert (p[fl == 0] == -1.0).all()
+            got[fl != 0, pos[fl != 0]] = p[fl != 0]
+            pos += fl
+        torch.cuda.synchronize()
+        return got, pool.state.cpu().numpy(), pool.ctx.cpu().numpy()
+
+    want, st_w, cx_w = run(False)
+    got, st_g, cx_g = run(True)
+    assert np.array_equal(got, want) and np.array_equal(st_g, st_w) and np.array_equal(cx_g, cx_w) and want.max() > 0.9
+
+
+def test_pump_open_and_close_take_effect_behind_the_ticks_in_flight(model, golden):
+    """vad_pump_open / vad_pump_close with TWO ticks in flight (the mode the pump is meant for): the ticks submitted before the call
+    belong to the slot's previous occupant -- their probabilities advance HIS iterator and emit HIS events; the new stream's sample
+    counter starts with the first tick submitted after open(), a closed stream's last delivered chunks still emit.  Event lists equal
+    the run that retires everything before calling open / close."""
+    from silero_vad_amd import StreamPump
+    sr, n = 16000, 512
+    pcm = golden["16k"]["pcm_i16"]
+    cap, T, K = 32, 90, 41
+    rows = np.ascontiguousarray(np.stack([np.roll(pcm, -(s * 7919))[:T * n] for s in range(cap)]))
+
+    def run(keep):
+        """`keep` ticks stay in flight behind every submit (0: each tick is retired before the next call, the case that always worked)."""
+        pump = StreamPump(model.engine, sr, streams=cap, parts=1, ring_slots=4)
+        per, inflight = {s: [] for s in range(cap)}, 0
+
+        def retire():
+            ev, _ = pump.poll()
+            for s, e in ev:
+                per[s].append(e)
+        for t in range(T):
+            if t == K:
+                assert inflight == keep
+                pump.open_stream(5)                                # a new stream takes slot 5 ...
+                pump.close_stream(6)                               # ... and stream 6 hangs up
+            src = rows[:, t * n:(t + 1) * n].copy()
+            if t >= K:
+                src[5] = rows[5, (t - K) * n:(t - K + 1) * n]      # the new stream plays the recording from its start
+            pump.slot(t % 4)[:] = src
+            pump.submit(t % 4)
+            inflight += 1
+            while inflight > keep:
+                retire()
+                inflight -= 1
+        while inflight:
+            retire()
+            inflight -= 1
+        pump.close()
+        return per
+    a, b = run(0), run(2)
+    assert a == b
+    # what the lists must hold: slot 5's second occupant starts its sample clock at zero, stream 6 is silent after tick K
+    first = [e for e in a[5] if "start" in e]
+    assert len(first) >= 2 and first[-1]["start"] < (T - K) * n and all(list(e.values())[0] <= K * n for e in a[6])
