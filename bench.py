@@ -610,7 +610,23 @@ def h2d_rate_GBps(dev, nbytes=256 << 20, reps=5):
     return best
 
 
-def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
+def gap_flags(ticks, streams, seed, miss=0.10, max_burst=5):
+    """[ticks, streams] uint8 presence pattern of live streams that do not arrive in lock step: every stream independently misses about
+    `miss` of its ticks, in bursts of 1..max_burst ticks (a late or lost packet train)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    p_start = miss / (1.0 - miss) / ((1 + max_burst) / 2.0)
+    pat = np.ones((ticks, streams), np.uint8)
+    left = np.zeros(streams, np.int64)                          # ticks of the current burst still to miss
+    for t in range(ticks):
+        start = (left == 0) & (rng.random(streams) < p_start)
+        left[start] = rng.integers(1, max_burst + 1, size=int(start.sum()))
+        pat[t, left > 0] = 0
+        left[left > 0] -= 1
+    return pat
+
+
+def run_stream_host(args, rank, world, local, dist, ticks, sr=16000, gaps=0.0):
     """configs[4] END TO END through the native pump (include/silero_vad_hip.h "live streams: the pump", csrc/pump.hip; the shape of
     the reference's native streaming loop, examples/cpp/silero-vad-onnx.cpp:335-390): NO Python and no torch on the tick path.  Per
     tick a source thread WRITES the int16 chunks of all streams into a page-locked ring slot (host memory traffic included: this is
@@ -643,9 +659,12 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
     pump = StreamPump(eng, sr, streams=cap, parts=parts, ring_slots=R)
     NATIVE_PINNED["bytes"] = max(NATIVE_PINNED.get("bytes", 0), R * cap * (n * 2 + 4))
     tick0 = [0]
+    # gaps > 0: the streams do not arrive in lock step -- each misses `gaps` of its ticks in bursts of up to 5 (vad_pump_play_gaps: the
+    # sources write the flags, absent streams are not stepped, a stream's audio advances only when it delivers)
+    pattern = gap_flags(256, cap, 41 + rank, gaps) if gaps > 0 else None
 
     def play(nt, depth):
-        ev, st = pump.play(rows, nt, first_tick=tick0[0], depth=depth)
+        ev, st = pump.play(rows, nt, first_tick=tick0[0], depth=depth, pattern=pattern)
         tick0[0] += nt
         return st
 
@@ -666,22 +685,38 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
         for b in range(16):
             pump.open_stream(b)
         got = np.zeros((16, nt), np.float32)
-        for t in range(nt):
+        pos = np.zeros(cap, np.int64)                           # chunks each stream has delivered
+        t = 0
+        while pos[:16].min() < nt:
             r = t % R
-            pump.slot(r)[:] = rows[:, (t % period) * n:(t % period + 1) * n]
-            pump.submit(r)
+            fl = np.ones(cap, np.uint8) if pattern is None else pattern[t % len(pattern)].copy()
+            fl[:16] &= pos[:16] < nt                            # (a checked stream stops after its nt chunks)
+            on = np.flatnonzero(fl)
+            pump.slot(r)[on] = rows[on[:, None], ((pos[on] % period) * n)[:, None] + np.arange(n)[None, :]]
+            pump.submit(r, present=None if pattern is None else fl)
             pump.poll()
-            got[:, t] = pump.probs(r)[:16]
+            p16 = pump.probs(r)[:16]
+            d = np.flatnonzero(fl[:16])
+            got[d, pos[d]] = p16[d]
+            if pattern is not None and not (p16[fl[:16] == 0] == -1.0).all():
+                raise RuntimeError("stream_gaps: an absent stream's probability slot does not hold VAD_PROB_ABSENT")
+            pos += fl
+            t += 1
         st16 = np.stack([np.stack(pump.state(b)[:2]) for b in range(16)], 1)       # [2, 16, 128]
+        how = (f"{nt} ticks" if pattern is None else f"{nt} delivered chunks each over {t} ticks with ~{gaps:.0%} of them missed (present flags)")
         parity = certify(rows[:16, :nt * n].astype(np.float32) / 32768.0, got, st16, sr,
-                         f"streams 0..15 of {cap}, {nt} ticks of int16 speech from zero state: ring slot -> pump (copies + kernels by events) -> host")
+                         f"streams 0..15 of {cap}, {how} of int16 speech from zero state: ring slot -> pump (copies + kernels by events) -> host")
     pump.close()
     if rank != 0:
         return None
-    value = cap * world * ticks / elapsed
+    delivered = best["chunks"] / (cap * ticks)                  # fraction of (stream, tick) pairs that carried a chunk
+    value = best["chunks"] * world / elapsed                    # chunks that were stepped per second
     out = base_line(args, world, sr, value, elapsed, ticks)
     out["ms_per_step"] = round(elapsed / ticks * 1e3, 4)
-    out["config"] = {"workload": f"configs[4] END TO END: {cap} live {sr // 1000} kHz streams/GPU ({cap * 8} per 8-GPU node), native pump: a source "
+    if pattern is not None:
+        out["gaps"] = {"missed_fraction": round(1.0 - delivered, 4), "max_burst": 5, "ticks_per_s": round(ticks / elapsed, 1),
+                       "what": "every stream independently misses ticks; absent streams keep (h, c), context and iterator state (vad_pump_submit_present)"}
+    out["config"] = {"workload": f"configs[4] END TO END{' WITH GAPS' if pattern is not None else ''}: {cap} live {sr // 1000} kHz streams/GPU ({cap * 8} per 8-GPU node), native pump: a source "
                                  f"thread writes every tick's int16 chunks into a page-locked ring slot -> H2D ({parts} parts, copy stream) -> fused "
                                  "vad_step kernels (compute stream, ordered by events; probabilities stored straight into host memory) -> VADIterator "
                                  "logic of every stream (vad_iterator_feed) -> events; (h,c)+context persistent in HBM; real-speech fixture audio; no "
@@ -698,8 +733,10 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000):
                         "submit": round(best["submit_ms_mean"], 4), "blocked_in_poll": round(best["wait_ms_mean"], 4)}, "untimed_depth_trials": runs,
                         "native_wall_s": round(best["wall_ms"] / 1e3, 4)}
     ceiling = link * 1e9 / (n * 2) * world
+    # (with gaps the whole slot still crosses the link every tick -- the absent rows' bytes are not skipped -- so the link is held
+    #  against the ticks, not against the delivered chunks)
     out["pcie"] = {"h2d_GBps_plain_copy": round(link, 2), "int16_ceiling_chunks_per_s": round(ceiling, 1),
-                   "fraction_of_pcie_ceiling": round(value / ceiling, 3),
+                   "fraction_of_pcie_ceiling": round(cap * world * ticks / elapsed / ceiling, 3),
                    "bytes_per_tick": cap * n * 2}
     out["parity"] = parity
     if parity and world == 1:
@@ -1033,7 +1070,7 @@ def small(d):
         return None
     keep = ("value", "unit", "steps", "ms_per_step", "dtype", "kernel_ms", "tick_latency_ms", "legs", "wall_s", "n_gpus",
             "audio_hours_all_gpus", "ten_k_hours_at_this_rate_s", "parity_sample", "parity_sample_max_abs_dp",
-            "outputs_finite", "realtime_factor", "timed_region_s", "parity", "parity_max_abs_dp", "pcie", "events_emitted", "sustained")
+            "outputs_finite", "realtime_factor", "timed_region_s", "parity", "parity_max_abs_dp", "pcie", "events_emitted", "sustained", "gaps")
     out = {k: d[k] for k in keep if k in d}
     out["workload"] = d["config"]["workload"]
     for k in ("sharding", "host_threads_per_rank", "numa_node_bound", "recordings_per_gpu", "audio_hours_per_gpu", "parts", "ring_slots"):
@@ -1068,9 +1105,10 @@ def compact_legs(out):
             e["max_prob"] = par.get("max_prob")
         elif "parity_sample_max_abs_dp" in d:
             e["dp"] = float(f"{d['parity_sample_max_abs_dp']:.2e}")
-        for k in ("gaps", "first_result_at"):            # live streams with absent rows / results while the shard runs (when the leg has them)
-            if k in d:
-                e[k] = d[k]
+        if isinstance(d.get("gaps"), dict):              # live streams that miss ticks: the fraction of (stream, tick) pairs without a chunk
+            e["missed"] = d["gaps"].get("missed_fraction")
+        if "first_result_at" in d:                       # corpus routes that hand results over while the shard runs
+            e["first_result_at"] = d["first_result_at"]
         return e
     legs = {"c2": one(out)}
     for name, d in (out.get("other_configs") or {}).items():
@@ -1216,7 +1254,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["c2", "8k", "stream", "stream_host", "stream_8k", "stream_host_8k", "corpus", "plumbing", "plumbing_8k"],
+    ap.add_argument("--config", choices=["c2", "8k", "stream", "stream_host", "stream_gaps", "stream_8k", "stream_host_8k", "corpus", "plumbing", "plumbing_8k"],
                     default="c2")
     ap.add_argument("--streams", type=int, default=STREAMS, help=argparse.SUPPRESS)
     ap.add_argument("--chunks", type=int, default=CHUNKS_PER_STREAM, help=argparse.SUPPRESS)
@@ -1229,7 +1267,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs")
     ap.add_argument("--dry", action="store_true", help="no GPU: exercise launch/shard/gather/barrier/reduce/print only (gloo)")
     args = ap.parse_args()
-    default_steps = {"c2": 200, "8k": 200, "stream": 2000, "stream_8k": 2000, "stream_host": 2000, "stream_host_8k": 2000,
+    default_steps = {"c2": 200, "8k": 200, "stream": 2000, "stream_8k": 2000, "stream_host": 2000, "stream_host_8k": 2000, "stream_gaps": 2000,
                      "corpus": 1, "plumbing": 1, "plumbing_8k": 1}   # corpus: one step = the whole shard
     if args.steps is None:
         args.steps = default_steps[args.config]
@@ -1259,8 +1297,9 @@ def main():
             out = run_batch(args, sr, rank, world, local, dist, args.steps, with_other=extras and args.config == "c2")
         elif args.config in ("stream", "stream_8k"):
             out = run_stream(args, rank, world, local, dist, args.steps, 16000 if args.config == "stream" else 8000)
-        elif args.config in ("stream_host", "stream_host_8k"):
-            out = run_stream_host(args, rank, world, local, dist, args.steps, 16000 if args.config == "stream_host" else 8000)
+        elif args.config in ("stream_host", "stream_host_8k", "stream_gaps"):
+            out = run_stream_host(args, rank, world, local, dist, args.steps, 8000 if args.config == "stream_host_8k" else 16000,
+                                  gaps=0.10 if args.config == "stream_gaps" else 0.0)
         elif args.config == "corpus":
             out = run_corpus(args, rank, world, local, dist, args.corpus_passes)
         else:
@@ -1270,6 +1309,7 @@ def main():
             oc = {}
             legs = [("stream", lambda: run_stream(args, rank, world, local, dist, 1000)),
                     ("stream_host", lambda: run_stream_host(args, rank, world, local, dist, 2000)),
+                    ("stream_gaps", lambda: run_stream_host(args, rank, world, local, dist, 2000, gaps=0.10)),
                     ("corpus", lambda: run_corpus(args, rank, world, local, dist, args.corpus_passes))]
             if world == 1:
                 legs = [("8k", lambda: run_batch(args, 8000, rank, world, local, dist, 100))] + legs + \

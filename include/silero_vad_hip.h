@@ -98,6 +98,13 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *   "fuse_step" = "1" (default) | "0": a ONE-step call that takes the latency form (vad_step of a stream pool, a B = 1 call)
  *                 runs the LSTM cell and the head inside the frontend's kernel -- no second launch, no trip of the gate
  *                 pre-activations through HBM; bit-identical to the two-kernel path ("0": force that, A/B for tests)
+ *   "exact_transitions" = "1" (default) | "0": a chunk that holds an EXACTLY silent STFT frame (every sample zero: a muted source, a DTX
+ *                 gap, the zero padding behind a recording's end) beside a frame that is not silent gets its gate pre-activations from a
+ *                 double-precision evaluation of the frontend (csrc/exact_front.hpp: the reference's definition, its own fp32 DFT basis,
+ *                 every sum in double, one rounding), because every one-accumulator fp32 summation is ill-conditioned exactly there
+ *                 (carried (h, c) up to 1.2e-4 from float64 against <= 2e-5 on continuous audio; with the option 1e-5).  A pure function
+ *                 of the chunk's own samples, identical bits on every route; "0": the fp32 chains everywhere (A/B for tests and studies).
+ *                 fp32 frontend only (not with front_mma = bf16x9)
  *   "fused_decimation" = "1" (default) | "0": for sr = 32000 and 48000 the fp32 frontend reads every 2nd / 3rd sample
  *                 itself; "0" forces the separate decimation pass that the higher multiples of 16000 use (A/B for tests)
  *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)

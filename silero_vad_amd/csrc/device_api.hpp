@@ -46,7 +46,17 @@ struct FrontArgs {
                              // the kernel reads every dec-th one (fp32 frontends; 3: kernel_front_f43.hip only); L, T, t0, nt stay
                              // in 16 kHz terms
     long long *trace;        // bring-up only (VAD_TRACE builds): 16 slots per workgroup, else null
+    // chunks that hold an exactly silent STFT frame beside one that is not (exact_front.hpp) get their gx from a double-precision
+    // evaluation.  exact_net: the canonical fp32 tensors (device copy of RefNet), or null = the feature is off.  The latency frontend
+    // computes such chunks itself; the throughput frontend appends their ids ((st * nt + tl) * 16 + j) to exact_list[1 + *exact_list],
+    // and launch_exact_fix overwrites their columns of gx.  exact_list: [0] count, [1] workgroups done (both zero between launches),
+    // [2 ...] ids.
+    const RefNet *exact_net;
+    int *exact_list;
 };
+// Behind a throughput-frontend launch with a.exact_list set: recompute the listed chunks (exact_front.hpp) into a.gx; resets the list.
+template <typename PcmT>
+hipError_t launch_exact_fix(int sr, const FrontArgs &a, hipStream_t s);
 // (A/B form, test builds only -- VAD_AB, libsilero_vad_hip_ab.so: encoder 0 tap by tap, straight-line code, kernel_front.hip)
 template <typename PcmT>
 hipError_t launch_front(int sr, const FrontArgs &a, hipStream_t s);

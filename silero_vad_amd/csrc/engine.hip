@@ -30,6 +30,7 @@ struct vad_images {
     int device = -1;
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
+    vad::RefNet *d_ref = nullptr;                   // the same two structs in device memory (exact_front.hpp reads them from the kernels)
     float *d_front4[2] = {}, *d_whh[2] = {}, *d_whh_lat[2] = {}, *d_whh_rows[2] = {}, *d_tables[2] = {};
     uint16_t *d_whh_b9[2] = {}, *d_front_b9[2] = {};
 #if VAD_AB
@@ -52,6 +53,7 @@ struct vad_images {
 #endif
         }
         if (d_blob) (void)hipFree(d_blob);
+        if (d_ref) (void)hipFree(d_ref);
     }
 };
 
@@ -70,6 +72,8 @@ struct vad_engine {
     bool rec_b9 = false;                            // recurrence: fp32 MFMA chain (default) | exact bf16 x 9 products (option "rec")
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the frontend's loads (option "fused_decimation")
+    bool exact_transitions = true;                  // chunks with an exactly silent frame beside a non-silent one are evaluated in double
+                                                    // (option "exact_transitions"; csrc/exact_front.hpp)
     long lat_tiles = 768;                           // launches of at most this many 16-chunk tiles take the latency form of the frontend
                                                     // (option "front": auto | throughput | latency -> 768 | 0 | LONG_MAX)
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
@@ -79,6 +83,8 @@ struct vad_engine {
     size_t gx_floats = 0;
     float *d_ctx_new = nullptr;
     size_t ctx_floats = 0;
+    int *d_exact = nullptr;                         // [2 + chunks of a slab]: the throughput frontend's list of chunks for the fix-up pass
+    size_t exact_ints = 0;
     void *d_tail = nullptr;                         // [B][N * dec] zero padded last chunk (L % N != 0)
     size_t tail_bytes = 0;
     void *d_realign = nullptr;                      // aligned copy of a misaligned input (rare)
@@ -142,7 +148,8 @@ int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
     // worst case of the tail copy: fp32 samples at 48 kHz (dec = 3) -- sized here so that no forward call has to grow it
     // (a growth is a device synchronisation and cannot happen while the call is being captured into a hipGraph)
     const size_t need_tail = (size_t)B * (sr == 16000 ? 512 * 3 : 256) * sizeof(float);
-    if (need_gx > e->gx_floats || need_ctx > e->ctx_floats || need_tail > e->tail_bytes) {
+    const size_t need_exact = 2 + (size_t)nst * 16 * slab;
+    if (need_gx > e->gx_floats || need_ctx > e->ctx_floats || need_tail > e->tail_bytes || need_exact > e->exact_ints) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
             return fail(e, VAD_ERR_CAPTURE, "scratch must grow during stream capture; call vad_reserve first");
@@ -163,6 +170,15 @@ int ensure_scratch(vad_engine *e, int sr, int B, long T, hipStream_t stream) {
             if (hipMalloc((void **)&e->d_ctx_new, need_ctx * sizeof(float)) != hipSuccess)
                 return fail(e, VAD_ERR_ALLOC, "cannot allocate context scratch");
             e->ctx_floats = need_ctx;
+        }
+        if (need_exact > e->exact_ints) {
+            if (e->d_exact) (void)hipFree(e->d_exact);
+            e->d_exact = nullptr;
+            e->exact_ints = 0;
+            if (hipMalloc((void **)&e->d_exact, need_exact * sizeof(int)) != hipSuccess)
+                return fail(e, VAD_ERR_ALLOC, "cannot allocate the exact-chunk list");
+            HIP_TRY(e, hipMemset(e->d_exact, 0, 2 * sizeof(int)));      // (the fix-up pass leaves the counters at zero: kernel_exact.hip)
+            e->exact_ints = need_exact;
         }
         if (need_tail > e->tail_bytes) {
             if (e->d_tail) (void)hipFree(e->d_tail);
@@ -255,6 +271,9 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         fa.B = B;
         fa.dec = dec;
         fa.trace = e->trace;
+        // chunks with an exactly silent frame beside one that is not: double-precision gx (the product's fp32 frontend only)
+        const bool exact = e->exact_transitions && e->enc0 == 2 && !e->front_b9;
+        fa.exact_net = exact ? e->img->d_ref + ni : nullptr;
         vad::RecArgs ra{};
         ra.whh = e->rec_b9 ? reinterpret_cast<const float *>(e->img->d_whh_b9[ni]) : e->img->d_whh[ni];
         ra.tables = e->img->d_tables[ni];
@@ -290,6 +309,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             }
             continue;
         }
+        bool front_stamped = false;
         if (e->front_b9) {
             fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
             HIP_TRY(e, vad::launch_front_b9<PcmT>(sr, fa, stream));
@@ -300,8 +320,14 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         else
 #endif
         if (tiles <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<PcmT>(sr, fa, stream));
-        else HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
-        if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));
+        else {
+            fa.exact_list = exact ? e->d_exact : nullptr;
+            HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
+            if (prof) HIP_TRY(e, hipEventRecord(ev[1], stream));         // (the frontend's own time ends here ...
+            front_stamped = prof;
+            HIP_TRY(e, vad::launch_exact_fix<PcmT>(sr, fa, stream));     //  ... the fix-up pass is part of the path, not of that kernel)
+        }
+        if (prof && !front_stamped) HIP_TRY(e, hipEventRecord(ev[1], stream));
         if (e->rec_b9) HIP_TRY(e, vad::launch_rec_b9(sr, ra, stream));
         else if (e->rec_form != 1 && B <= vad::kRecSmallMaxB) {
             // a file at a time, a bucket of a few hundred: W_hh h as matrix-vector products on the VALU, 1-4 streams per CU -- the same bits
@@ -460,6 +486,8 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
         r.w_ih = dev(t.w_ih); r.w_hh = dev(t.w_hh); r.b_ih = dev(t.b_ih); r.b_hh = dev(t.b_hh);
         r.w_out = dev(t.w_out); r.b_out = dev(t.b_out);
     }
+    if (hipMalloc((void **)&im.d_ref, sizeof(im.ref)) != hipSuccess) return bail(VAD_ERR_ALLOC);
+    if (hipMemcpy(im.d_ref, im.ref, sizeof(im.ref), hipMemcpyHostToDevice) != hipSuccess) return bail(VAD_ERR_HIP);
     *out = e;
     return VAD_OK;
 }
@@ -480,6 +508,7 @@ void vad_destroy(vad_engine *e) {
         (void)hipDeviceSynchronize();
         if (e->d_gx) (void)hipFree(e->d_gx);
         if (e->d_ctx_new) (void)hipFree(e->d_ctx_new);
+        if (e->d_exact) (void)hipFree(e->d_exact);
         if (e->d_tail) (void)hipFree(e->d_tail);
         if (e->d_realign) (void)hipFree(e->d_realign);
         if (e->d_decim) (void)hipFree(e->d_decim);
@@ -512,6 +541,7 @@ int vad_clone(const vad_engine *src, vad_engine **out) {
     e->rec_form = src->rec_form;
     e->front_b9 = src->front_b9;
     e->fuse_step = src->fuse_step;
+    e->exact_transitions = src->exact_transitions;
     e->gx_cap = src->gx_cap;
     e->trace = src->trace;
     *out = e;
@@ -570,6 +600,11 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         else if (v == "throughput") e->lat_tiles = 0;
         else if (v == "latency") e->lat_tiles = 0x7fffffffL;
         else return fail(e, VAD_ERR_OPTION, "front must be auto|throughput|latency");
+        return VAD_OK;
+    }
+    if (n == "exact_transitions") {                  // "0": every chunk through the fp32 chains (A/B for tests and studies)
+        if (v != "0" && v != "1") return fail(e, VAD_ERR_OPTION, "exact_transitions: 0 | 1");
+        e->exact_transitions = v == "1";
         return VAD_OK;
     }
     if (n == "fused_decimation") {                   // "0": always decimate into scratch first (A/B for tests)
@@ -849,6 +884,8 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.gx = e->d_gx;
     fa.B = B;
     fa.trace = e->trace;
+    const bool exact = e->exact_transitions && e->enc0 == 2 && !e->front_b9;
+    fa.exact_net = exact ? e->img->d_ref + ni : nullptr;
     if (e->front_b9) {
         fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
         HIP_TRY(e, vad::launch_front_b9<float>(sr, fa, stream));
@@ -859,7 +896,11 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     else
 #endif
     if ((long)((B + 15) / 16) * T <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<float>(sr, fa, stream));
-    else HIP_TRY(e, vad::launch_front_f43<float>(sr, fa, stream));
+    else {
+        fa.exact_list = exact ? e->d_exact : nullptr;
+        HIP_TRY(e, vad::launch_front_f43<float>(sr, fa, stream));
+        HIP_TRY(e, vad::launch_exact_fix<float>(sr, fa, stream));
+    }
     HIP_TRY(e, vad::launch_unpack_gx(e->d_gx, gx, B, T, stream));
     return VAD_OK;
 }

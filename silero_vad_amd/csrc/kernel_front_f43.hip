@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "fft_wave.hpp"
+#include "exact_front.hpp"
 #include "front_common.hpp"
 
 namespace vad {
@@ -241,6 +242,13 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     if (VAD_F43_GEMM_PRIO) __builtin_amdgcn_s_setprio(VAD_F43_GEMM_PRIO);
     // |Y_nyq| of chunk j lives in lane group 0 (X[Q]); every lane of the chunk needs it
     const float xn0 = __shfl(X0[Q], ln.j), xn1 = __shfl(X1[Q], ln.j), xn2 = __shfl(X2[Q], ln.j), xn3 = __shfl(X3[Q], ln.j);
+    // chunks with an exactly silent frame beside one that is not (exact_front.hpp): listed for the fix-up pass (kernel_exact.hip), which
+    // overwrites their columns of gx.  Four compares and scalar code; the branch is taken where digital silence begins or ends.
+    if (a.exact_list != nullptr) {
+        const unsigned ex = exact_chunks(X0[0], X1[0], X2[0], X3[0]);
+        if (ex != 0 && ln.tile_valid && ln.g == 0 && ((ex >> ln.j) & 1) && bb < a.B)
+            a.exact_list[2 + atomicAdd(a.exact_list, 1)] = (int)(wt * 16 + ln.j);
+    }
 
 #if VAD_F43_EF
     // The input transform reads the frames through E = x3 - x1 and F = x2 - x0 (kept in place of x3 and x0): t3/t4 = E +- 2F,

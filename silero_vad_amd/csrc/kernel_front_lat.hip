@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include "activations.hpp"
+#include "exact_front.hpp"
 #include "front_common.hpp"
 
 namespace vad {
@@ -233,6 +234,13 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     lds_barrier();                                               // everybody has read xs: its memory becomes ybuf
     // |Y_nyq| of chunk j lives in lane group 0 (X[Q]); every lane of the chunk needs it
     const float xn0 = __shfl(X0[Q], ln.j), xn1 = __shfl(X1[Q], ln.j), xn2 = __shfl(X2[Q], ln.j), xn3 = __shfl(X3[Q], ln.j);
+    // chunks with an exactly silent frame beside one that is not (exact_front.hpp): their gx is recomputed below, in double (every
+    // wave holds all four frames: the same mask in all of them)
+    unsigned exact_mask = 0;
+    if (a.exact_net != nullptr) {
+        const long left = (long)a.B - ln.st * 16;
+        exact_mask = exact_chunks(X0[0], X1[0], X2[0], X3[0]) & (left >= 16 ? 0xffffu : ((1u << left) - 1u));
+    }
     // the F(4,3) input transform reads the frames through E = x3 - x1 and F = x2 - x0 (kept in place of x3 and x0)
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
@@ -378,6 +386,27 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     init_bias<8>(G, tab + tb.b_g + 128 * w, ln);
     run_segment<S_IH, 64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
                              [&](auto kg) VAD_INLINE { return Fe[IC(kg)]; }, gload);
+    if (exact_mask != 0) {
+        // workgroup-uniform and rare: the tile's EXACT chunks one after the other, all 256 threads on each (exact_front.hpp); the lanes of
+        // chunk j then take gate w's 128 rows from the workspace in place of the chain's.  (The workspace lies over the exchange buffers:
+        // every wave is past its last read of them.)
+        ExactWs<Q> &ws = *reinterpret_cast<ExactWs<Q> *>(xy);
+        static_assert(sizeof(ExactWs<Q>) <= sizeof(xy), "the exact workspace aliases the magnitude exchange buffer");
+        __shared__ RefNet net;
+        __syncthreads();
+        if (threadIdx.x == 0) net = *a.exact_net;
+        __syncthreads();
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < 16; ++j) {
+            if (!((exact_mask >> j) & 1)) continue;
+            exact_gx<Q, PcmT, DEC>(a, net, ln.st * 16 + j, ln.t, ws);
+            if (ln.j == j) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) G[m] = *reinterpret_cast<const f32x4 *>(&ws.gx[128 * w + 16 * m + 4 * ln.g]);
+            }
+            __syncthreads();
+        }
+    }
     if constexpr (!CELL) {
         float *gxt = a.gx + ((size_t)(ln.st * a.nt + ln.tl) * 32 + 8 * w) * 256 + ln.lane * 4;
 #pragma unroll

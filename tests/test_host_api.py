@@ -138,7 +138,7 @@ def _worst_case_bench_record(world=8):
            "kernel_ms": {"front": 4.3754, "rec": 1.1309}, "roofline": roof,
            "other_arithmetic": {k: {"what": prose[:250], "value": 2e8, "unit": "chunks/s", "max_abs_prob_diff_vs_main": 1.0281801223754883e-06}
                                 for k in ("rec_bf16x9", "all_bf16x9")},
-           "other_configs": {"8k": leg("8k"), "stream": leg("stream"), "stream_host": leg("stream_host"), "stream_gaps": leg("stream_gaps", gaps=0.1),
+           "other_configs": {"8k": leg("8k"), "stream": leg("stream"), "stream_host": leg("stream_host"), "stream_gaps": leg("stream_gaps", gaps={"missed_fraction": 0.1, "max_burst": 5, "what": prose[:150]}),
                              "corpus": leg("corpus", parity=None, parity_sample={"recordings_checked": 15, "one_in": 10000, "parity_sample_max_abs_dp": 2.2e-6},
                                            parity_sample_max_abs_dp=2.2202730178833008e-06,
                                            legs={k: dict(route) for k in ("main", "pinned_gather", "pinned_dma", "pageable_staged", "pinned_refill_gather")}),

@@ -6,7 +6,7 @@ out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 python __graft_entry__.py > $out/build.log 2>&1 || tail -20 $out/build.log
 if [ -z "${SKIP_TESTS:-}" ]; then
-timeout ${PYTEST_TIMEOUT:-1200} python -m pytest tests -m gpu -q --timeout 300 --timeout-method=thread -p no:cacheprovider ${PYTEST_ARGS:-} > $out/pytest_gpu.log 2>&1
+timeout ${PYTEST_TIMEOUT:-1200} python -m pytest tests -m gpu -q --timeout 300 --timeout-method=thread -p no:cacheprovider ${PYTEST_ARGS:-} ${PYTEST_K:+-k "$PYTEST_K"} > $out/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> $out/pytest_gpu.log
 tail -n ${PYTEST_TAIL:-30} $out/pytest_gpu.log | cut -c1-400
 fi
