@@ -103,7 +103,10 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *                 double-precision evaluation of the frontend (csrc/exact_front.hpp: the reference's definition, its own fp32 DFT basis,
  *                 every sum in double, one rounding), because every one-accumulator fp32 summation is ill-conditioned exactly there
  *                 (carried (h, c) up to 1.2e-4 from float64 against <= 2e-5 on continuous audio; with the option 1e-5).  A pure function
- *                 of the chunk's own samples, identical bits on every route; "0": the fp32 chains everywhere (A/B for tests and studies).
+ *                 of the chunk's own samples, identical bits on every route.  A chunk whose FOUR frames are silent takes the net's constant
+ *                 for a chunk of zeros, evaluated the same way once (the chains make the same rounding error in every silent chunk and the
+ *                 cell state integrates it: 4.6e-5 one chunk into a silence, 1e-5 with the constant).  "0": the fp32 chains everywhere,
+ *                 "edges": without the constant (A/B for tests and studies).
  *                 fp32 frontend only (not with front_mma = bf16x9)
  *   "fused_decimation" = "1" (default) | "0": for sr = 32000 and 48000 the fp32 frontend reads every 2nd / 3rd sample
  *                 itself; "0" forces the separate decimation pass that the higher multiples of 16000 use (A/B for tests)

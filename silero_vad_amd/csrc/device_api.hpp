@@ -53,7 +53,11 @@ struct FrontArgs {
     // [2 ...] ids.
     const RefNet *exact_net;
     int *exact_list;
+    const float *gx_silent;  // [512] gx of a chunk of zeros with zero context (a constant of the net), or null: all-silent chunks keep the
+                             // fp32 chains' value (option exact_transitions=edges; study mode)
 };
+// gx_silent of one net: exact_front.hpp's double-precision evaluation of a chunk of zeros, 512 floats to `out` (device).
+hipError_t launch_exact_silent(int sr, const RefNet *net_dev, float *out, hipStream_t s);
 // Behind a throughput-frontend launch with a.exact_list set: recompute the listed chunks (exact_front.hpp) into a.gx; resets the list.
 template <typename PcmT>
 hipError_t launch_exact_fix(int sr, const FrontArgs &a, hipStream_t s);

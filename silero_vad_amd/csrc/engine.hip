@@ -31,6 +31,7 @@ struct vad_images {
     uint8_t *d_blob = nullptr;                      // canonical container (impl=reference)
     vad::RefNet ref[2] = {};
     vad::RefNet *d_ref = nullptr;                   // the same two structs in device memory (exact_front.hpp reads them from the kernels)
+    float *d_gx_silent = nullptr;                   // [2][512]: each net's gate pre-activations for a chunk of zeros (exact_front.hpp)
     float *d_front4[2] = {}, *d_whh[2] = {}, *d_whh_lat[2] = {}, *d_whh_rows[2] = {}, *d_tables[2] = {};
     uint16_t *d_whh_b9[2] = {}, *d_front_b9[2] = {};
 #if VAD_AB
@@ -54,6 +55,7 @@ struct vad_images {
         }
         if (d_blob) (void)hipFree(d_blob);
         if (d_ref) (void)hipFree(d_ref);
+        if (d_gx_silent) (void)hipFree(d_gx_silent);
     }
 };
 
@@ -72,6 +74,7 @@ struct vad_engine {
     bool rec_b9 = false;                            // recurrence: fp32 MFMA chain (default) | exact bf16 x 9 products (option "rec")
     bool profile = false;
     bool fused_decimation = true;                   // 32 / 48 kHz: decimate inside the frontend's loads (option "fused_decimation")
+    bool exact_all_silent = true;                   // ... and all-silent chunks take the net's constant (false: option exact_transitions=edges, study mode)
     bool exact_transitions = true;                  // chunks with an exactly silent frame beside a non-silent one are evaluated in double
                                                     // (option "exact_transitions"; csrc/exact_front.hpp)
     long lat_tiles = 768;                           // launches of at most this many 16-chunk tiles take the latency form of the frontend
@@ -274,6 +277,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         // chunks with an exactly silent frame beside one that is not: double-precision gx (the product's fp32 frontend only)
         const bool exact = e->exact_transitions && e->enc0 == 2 && !e->front_b9;
         fa.exact_net = exact ? e->img->d_ref + ni : nullptr;
+        fa.gx_silent = exact && e->exact_all_silent ? e->img->d_gx_silent + 512 * ni : nullptr;
         vad::RecArgs ra{};
         ra.whh = e->rec_b9 ? reinterpret_cast<const float *>(e->img->d_whh_b9[ni]) : e->img->d_whh[ni];
         ra.tables = e->img->d_tables[ni];
@@ -488,6 +492,10 @@ int vad_create(const void *weights, size_t nbytes, int device, vad_engine **out)
     }
     if (hipMalloc((void **)&im.d_ref, sizeof(im.ref)) != hipSuccess) return bail(VAD_ERR_ALLOC);
     if (hipMemcpy(im.d_ref, im.ref, sizeof(im.ref), hipMemcpyHostToDevice) != hipSuccess) return bail(VAD_ERR_HIP);
+    if (hipMalloc((void **)&im.d_gx_silent, 2 * 512 * sizeof(float)) != hipSuccess) return bail(VAD_ERR_ALLOC);
+    for (int ni = 0; ni < 2; ++ni)
+        if (vad::launch_exact_silent(ni == 0 ? 16000 : 8000, im.d_ref + ni, im.d_gx_silent + 512 * ni, nullptr) != hipSuccess) return bail(VAD_ERR_HIP);
+    if (hipDeviceSynchronize() != hipSuccess) return bail(VAD_ERR_HIP);
     *out = e;
     return VAD_OK;
 }
@@ -542,6 +550,7 @@ int vad_clone(const vad_engine *src, vad_engine **out) {
     e->front_b9 = src->front_b9;
     e->fuse_step = src->fuse_step;
     e->exact_transitions = src->exact_transitions;
+    e->exact_all_silent = src->exact_all_silent;
     e->gx_cap = src->gx_cap;
     e->trace = src->trace;
     *out = e;
@@ -603,8 +612,9 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         return VAD_OK;
     }
     if (n == "exact_transitions") {                  // "0": every chunk through the fp32 chains (A/B for tests and studies)
-        if (v != "0" && v != "1") return fail(e, VAD_ERR_OPTION, "exact_transitions: 0 | 1");
-        e->exact_transitions = v == "1";
+        if (v != "0" && v != "1" && v != "edges") return fail(e, VAD_ERR_OPTION, "exact_transitions: 0 | 1 (| edges: study mode)");
+        e->exact_transitions = v != "0";
+        e->exact_all_silent = v == "1";
         return VAD_OK;
     }
     if (n == "fused_decimation") {                   // "0": always decimate into scratch first (A/B for tests)
@@ -886,6 +896,7 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     fa.trace = e->trace;
     const bool exact = e->exact_transitions && e->enc0 == 2 && !e->front_b9;
     fa.exact_net = exact ? e->img->d_ref + ni : nullptr;
+    fa.gx_silent = exact && e->exact_all_silent ? e->img->d_gx_silent + 512 * ni : nullptr;
     if (e->front_b9) {
         fa.wfront = reinterpret_cast<const float *>(e->img->d_front_b9[ni]);
         HIP_TRY(e, vad::launch_front_b9<float>(sr, fa, stream));

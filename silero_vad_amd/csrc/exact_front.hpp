@@ -14,8 +14,8 @@
 // The rule (a pure function of the chunk's own samples and context, so a result never depends on the batch it is computed in): a chunk
 // is EXACT if at least one of its four STFT frames has |Y[0..3]| == 0 exactly in fp32 and at least one has not.  (A frame of zero samples
 // has every bin exactly zero, in the FFT as in the DFT; a frame with a non-zero sample whose four lowest bins are all exactly zero is
-// not something audio does, and would only buy that chunk the better arithmetic.  Four silent frames: nothing to cancel, gx is the
-// bias path, the fast kernels are exact there already.)  An exact chunk's gate pre-activations gx[512] are computed here:
+// not something audio does, and would only buy that chunk the better arithmetic.  Four silent frames: the chunk's gx does not depend on
+// any sample -- it is a constant of the net, see silent_chunks below.)  An exact chunk's gate pre-activations gx[512] are computed here:
 // reference definition, dense DFT with the reference's own fp32 basis, every tap, every sum in double, ONE rounding to fp32 at the
 // end (JIT!/vad/utils/pytorch_stft.py:17-34, JIT!/vad/utils/model_utils.py:19-25, the W_ih half of JIT!/torch/nn/modules/rnn.py:69).
 //
@@ -50,6 +50,7 @@ struct ExactWs {                               // LDS workspace of one chunk: 17
 template <int Q, typename PcmT, int DEC>
 __device__ __forceinline__ float exact_sample(const FrontArgs &a, long b, long t, int i) {
     constexpr int N = 16 * Q, C = 2 * Q;
+    if (a.pcm == nullptr) return 0.f;                            // (a chunk of zeros: launch_exact_silent)
     if (t == 0 && i < 0) return a.ctx_in[(size_t)b * C + (C + i)];
     const PcmT *row = reinterpret_cast<const PcmT *>(a.pcm) + (size_t)b * a.ld;
     if (a.tail != nullptr && t == a.T - 1 && i >= 0)
@@ -157,17 +158,27 @@ __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, 
     __syncthreads();
 }
 
-// Which of the 16 chunks of a tile are EXACT (bit j = chunk j), from the four frames' magnitudes in "mag layout": every lane's X[0] is
-// one of the chunk's bins 0..3 (fft_wave.hpp: X[s] = |Y[4 s + P[g]]|), the four lanes j, j + 16, j + 32, j + 48 hold all four.  Four
-// compares per lane; the rest is scalar.  Wave-uniform result.
-__device__ __forceinline__ unsigned exact_chunks(float x0, float x1, float x2, float x3) {
-    auto silent = [](float x) -> unsigned {
+// Which of the 16 chunks of a tile hold silent frames (bit j = chunk j), from the four frames' magnitudes in "mag layout": every lane's
+// X[0] is one of the chunk's bins 0..3 (fft_wave.hpp: X[s] = |Y[4 s + P[g]]|), the four lanes j, j + 16, j + 32, j + 48 hold all four.
+// Four compares per lane; the rest is scalar.  Wave-uniform result.
+//   edge:   some frame silent, some not -> exact_gx
+//   silent: all four frames silent      -> the constant gx_silent[512] (the same double-precision evaluation of a chunk of zeros, done
+//           once per net when the engine is created).  The fp32 chains are not ill-conditioned there, but they make the SAME rounding
+//           error in every silent chunk, and a cell state that integrates a constant offset over a long silence drifts coherently:
+//           4.6e-5 from float64 one chunk into a silence at 16 kHz, 1e-5 with the constant (tools/zero_run_study.py).
+struct SilentMasks {
+    unsigned edge, silent;
+};
+__device__ __forceinline__ SilentMasks silent_chunks(float x0, float x1, float x2, float x3) {
+    auto quiet = [](float x) -> unsigned {
         const unsigned long long m = __ballot(x == 0.0f);
         return (unsigned)(m & (m >> 16) & (m >> 32) & (m >> 48)) & 0xffffu;
     };
-    const unsigned z0 = silent(x0), z1 = silent(x1), z2 = silent(x2), z3 = silent(x3);
-    return (z0 | z1 | z2 | z3) & ~(z0 & z1 & z2 & z3);
+    const unsigned z0 = quiet(x0), z1 = quiet(x1), z2 = quiet(x2), z3 = quiet(x3);
+    const unsigned any = z0 | z1 | z2 | z3, all = z0 & z1 & z2 & z3;
+    return SilentMasks{any & ~all, all};
 }
+constexpr int kExactSilentBit = 1 << 30;       // list entries: chunk id | this bit for an all-silent chunk
 
 }  // namespace
 }  // namespace vad

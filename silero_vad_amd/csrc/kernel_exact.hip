@@ -23,15 +23,16 @@ __global__ void __launch_bounds__(256) exact_fix_kernel(const FrontArgs a) {
     const int n = a.exact_list[0];                       // (stable: the frontend that filled it has finished, nobody resets it before
     __syncthreads();                                     //  every workgroup of this launch has passed its own read)
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int id = a.exact_list[2 + i];
+        const int entry = a.exact_list[2 + i], id = entry & ~kExactSilentBit;
         const long tile = id >> 4;
         const int j = id & 15;
         const long st = tile / a.nt, tl = tile % a.nt;
-        exact_gx<Q, PcmT, DEC>(a, net, st * 16 + j, a.t0 + tl, ws);
+        const bool silent = (entry & kExactSilentBit) != 0;       // workgroup-uniform
+        if (!silent) exact_gx<Q, PcmT, DEC>(a, net, st * 16 + j, a.t0 + tl, ws);
         // gx[tile][row block 32][lane 64][4]: row 16 mb + 4 g + r of chunk j sits at lane 16 g + j, element r (layout.hpp)
         float *gxt = a.gx + (size_t)tile * 32 * 256;
         for (int r = threadIdx.x; r < 512; r += 256)
-            gxt[((size_t)(r >> 4) * 64 + ((r >> 2) & 3) * 16 + j) * 4 + (r & 3)] = ws.gx[r];
+            gxt[((size_t)(r >> 4) * 64 + ((r >> 2) & 3) * 16 + j) * 4 + (r & 3)] = silent ? a.gx_silent[r] : ws.gx[r];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -43,7 +44,25 @@ __global__ void __launch_bounds__(256) exact_fix_kernel(const FrontArgs a) {
     }
 }
 
+template <int Q>
+__global__ void __launch_bounds__(256) exact_silent_kernel(const RefNet *net_dev, float *out) {
+    __shared__ ExactWs<Q> ws;
+    __shared__ RefNet net;
+    if (threadIdx.x == 0) net = *net_dev;
+    __syncthreads();
+    FrontArgs a{};                                       // pcm == nullptr: every sample, the context included, is zero
+    a.T = 2;
+    exact_gx<Q, float, 1>(a, net, 0, 1, ws);
+    for (int r = threadIdx.x; r < 512; r += 256) out[r] = ws.gx[r];
+}
+
 }  // namespace
+
+hipError_t launch_exact_silent(int sr, const RefNet *net_dev, float *out, hipStream_t s) {
+    if (sr == 16000) hipLaunchKernelGGL((exact_silent_kernel<32>), dim3(1), dim3(256), 0, s, net_dev, out);
+    else hipLaunchKernelGGL((exact_silent_kernel<16>), dim3(1), dim3(256), 0, s, net_dev, out);
+    return hipGetLastError();
+}
 
 template <typename PcmT>
 hipError_t launch_exact_fix(int sr, const FrontArgs &a, hipStream_t s) {

@@ -245,9 +245,17 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     // chunks with an exactly silent frame beside one that is not (exact_front.hpp): listed for the fix-up pass (kernel_exact.hip), which
     // overwrites their columns of gx.  Four compares and scalar code; the branch is taken where digital silence begins or ends.
     if (a.exact_list != nullptr) {
-        const unsigned ex = exact_chunks(X0[0], X1[0], X2[0], X3[0]);
-        if (ex != 0 && ln.tile_valid && ln.g == 0 && ((ex >> ln.j) & 1) && bb < a.B)
-            a.exact_list[2 + atomicAdd(a.exact_list, 1)] = (int)(wt * 16 + ln.j);
+        const SilentMasks sm = silent_chunks(X0[0], X1[0], X2[0], X3[0]);
+        const long left = (long)a.B - ln.st * 16;
+        const unsigned take = (sm.edge | (a.gx_silent != nullptr ? sm.silent : 0u)) & (left >= 16 ? 0xffffu : ((1u << left) - 1u));
+        if (take != 0 && ln.tile_valid) {             // wave-uniform; one atomic per tile, the lanes of the listed chunks fill their slots
+            int base = 0;
+            if (ln.lane == 0) base = atomicAdd(a.exact_list, __builtin_popcount(take));
+            base = __shfl(base, 0);
+            if (ln.g == 0 && ((take >> ln.j) & 1))
+                a.exact_list[2 + base + __builtin_popcount(take & ((1u << ln.j) - 1u))] =
+                    (int)(wt * 16 + ln.j) | (((sm.silent >> ln.j) & 1) ? kExactSilentBit : 0);
+        }
     }
 
 #if VAD_F43_EF

@@ -236,10 +236,13 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     const float xn0 = __shfl(X0[Q], ln.j), xn1 = __shfl(X1[Q], ln.j), xn2 = __shfl(X2[Q], ln.j), xn3 = __shfl(X3[Q], ln.j);
     // chunks with an exactly silent frame beside one that is not (exact_front.hpp): their gx is recomputed below, in double (every
     // wave holds all four frames: the same mask in all of them)
-    unsigned exact_mask = 0;
+    unsigned exact_mask = 0, silent_mask = 0;
     if (a.exact_net != nullptr) {
+        const SilentMasks sm = silent_chunks(X0[0], X1[0], X2[0], X3[0]);
         const long left = (long)a.B - ln.st * 16;
-        exact_mask = exact_chunks(X0[0], X1[0], X2[0], X3[0]) & (left >= 16 ? 0xffffu : ((1u << left) - 1u));
+        const unsigned rows = left >= 16 ? 0xffffu : ((1u << left) - 1u);
+        exact_mask = sm.edge & rows;
+        silent_mask = a.gx_silent != nullptr ? sm.silent & rows : 0u;
     }
     // the F(4,3) input transform reads the frames through E = x3 - x1 and F = x2 - x0 (kept in place of x3 and x0)
 #pragma unroll
@@ -386,6 +389,11 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     init_bias<8>(G, tab + tb.b_g + 128 * w, ln);
     run_segment<S_IH, 64, 8>(pp, [&](auto i) VAD_INLINE -> f32x4 & { return G[IC(i) & 7]; },
                              [&](auto kg) VAD_INLINE { return Fe[IC(kg)]; }, gload);
+    if ((silent_mask >> ln.j) & 1) {                               // a chunk of zeros behind a silent context: the net's constant
+        const float *gs = a.gx_silent + 128 * w + 4 * ln.g;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) G[m] = *reinterpret_cast<const f32x4 *>(gs + 16 * m);
+    }
     if (exact_mask != 0) {
         // workgroup-uniform and rare: the tile's EXACT chunks one after the other, all 256 threads on each (exact_front.hpp); the lanes of
         // chunk j then take gate w's 128 rows from the workspace in place of the chain's.  (The workspace lies over the exchange buffers:

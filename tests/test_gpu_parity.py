@@ -2676,7 +2676,7 @@ def test_carried_state_across_mid_stream_zero_runs_vs_float64(model, oracle, gol
             _, _, wst = oracle.forward_audio(part, sr)
             e, o = state_vs_float64(model, part, sr, st, wst, label=f"{tag} zero run from sample {name} of chunk 2, state after chunk {t}", record=rec64,
                                     factor=0.0)
-            assert e < TOL and e <= max(o, 2e-5), (name, t, e, o)
+            assert e < TOL, (name, t, e, o)
         eng.set_option("exact_transitions", "0")
         try:
             _, _, st_off = run_engine(model, rows[:, :3 * n].copy(), sr)
@@ -2696,7 +2696,8 @@ def test_exact_transition_chunks_same_bits_on_every_route(model, golden, tag):
     """The chunks exact_front.hpp takes over -- a silent frame beside one that is not -- through the throughput frontend + fix-up pass,
     the latency frontend, the fused one-kernel step and the small-batch recurrence, fp32 and int16 PCM, with carried context: identical
     probabilities, state and gate pre-activations; against float64 the gate pre-activations of those chunks are exact to fp32 rounding
-    (the fp32 chains: 1e-5 and more); chunks that are not taken over keep their bits when the option is switched off."""
+    (the fp32 chains: 1e-5 and more); so are those of the all-silent chunks (the net's constant); chunks that are not taken over keep
+    their bits when the option is switched off."""
     sr, g = SRS[tag], golden[tag]
     n = chunk_of(sr)
     eng = model.engine
@@ -2754,8 +2755,8 @@ def test_exact_transition_chunks_same_bits_on_every_route(model, golden, tag):
         for t in range(T):
             seg = np.concatenate([fr[b, t * n:t * n + n + n // 8], fr[b, t * n + n + n // 8 - 2:t * n + n - 2:-1][:n // 8]])
             sil = [not seg[m * (n // 4):m * (n // 4) + n // 2].any() for m in range(4)]
-            want[b, t] = any(sil) and not all(sil)
-    assert np.array_equal(taken, want) and 20 < taken.sum() < B * T // 2 and not taken[5].any()
+            want[b, t] = any(sil)                                  # (all four silent: the net's constant for a chunk of zeros)
+    assert np.array_equal(taken, want) and 20 < taken.sum() < B * T // 2 and taken[5].all()
     err_on = np.abs(g_on - g64).max(-1) / np.maximum(1.0, np.abs(g64).max(-1))
     err_off = np.abs(g_off - g64).max(-1) / np.maximum(1.0, np.abs(g64).max(-1))
     assert err_on[taken].max() < 3e-7, float(err_on[taken].max())            # one fp32 rounding of a double result

@@ -34,7 +34,7 @@ def main():
         n = 512 if sr == 16000 else 256
         wav = np.load(ROOT / "tests" / "golden" / f"audio_{tag}.npz")["pcm"].astype(np.float32) / 32768.0
         B, T = 1025, 9
-        for run, where in ((0.5, None), (2.5, None), (4.0, None), (2.0, 1), (2.0, 7), (2.0, n // 8), (2.0, n // 4 + 1), (2.0, n // 2), (2.0, n - 1)):
+        for run, where in ((0.5, None), (2.5, None), (2.0, 1), (2.0, 7), (2.0, n // 8), (2.0, n // 2), (2.0, n - 1)):
             rows = rolled_rows(wav, B, T * n, 4001)
             # first zero sample: anywhere inside chunk 2 (stream 0: its first sample), or the SAME offset `where` in every stream (the
             # shape of a batch of recordings that end one / seven samples into their last chunk)
@@ -52,8 +52,9 @@ def main():
                 den = np.maximum(1.0, np.abs(s64))
                 _, _, so = orc.forward_audio(rows[:, :t * n].copy(), sr)
                 res.setdefault("oracle", []).append(float((np.abs(so - s64) / den).max()))
-                for algo in ("winograd", "winograd2", "direct"):
-                    eng.set_option("enc0", algo)
+                for algo in ("winograd", "winograd2", "direct", "winograd+exact", "winograd+exact+silent"):
+                    eng.set_option("enc0", algo.split("+")[0])
+                    eng.set_option("exact_transitions", {1: "0", 2: "edges", 3: "1"}[len(algo.split("+"))])
                     try:
                         ctx = torch.zeros((B, n // 8), device=dev)
                         st = torch.zeros((2, B, 128), device=dev)
@@ -61,6 +62,7 @@ def main():
                         torch.cuda.synchronize()
                     finally:
                         eng.set_option("enc0", "winograd")
+                        eng.set_option("exact_transitions", "1")
                     res.setdefault(algo, []).append(float((np.abs(st.cpu().numpy() - s64) / den).max()))
             out[f"{tag} zero run of {run} chunks from {'anywhere' if where is None else 'sample ' + str(where)} inside chunk 2"] = {k: [float(f"{v:.3e}") for v in vs] for k, vs in res.items()}
     print(json.dumps(out, indent=1))
