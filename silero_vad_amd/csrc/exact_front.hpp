@@ -29,6 +29,10 @@
 
 #include "device_api.hpp"
 
+#ifndef VAD_NO_EXACT
+#define VAD_NO_EXACT 0           // 1: timing A/B only (tools/variants.py noexact): the frontends without the silent-frame test
+#endif
+
 namespace vad {
 namespace {
 

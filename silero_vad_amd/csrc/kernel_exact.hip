@@ -13,15 +13,18 @@
 namespace vad {
 namespace {
 
-constexpr int kFixGrid = 1024;
+constexpr int kFixGrid = 512;
 
 template <int Q, typename PcmT, int DEC>
 __global__ void __launch_bounds__(256) exact_fix_kernel(const FrontArgs a) {
     __shared__ ExactWs<Q> ws;
     __shared__ RefNet net;
-    if (threadIdx.x == 0) net = *a.exact_net;
     const int n = a.exact_list[0];                       // (stable: the frontend that filled it has finished, nobody resets it before
-    __syncthreads();                                     //  every workgroup of this launch has passed its own read)
+                                                         //  every workgroup of this launch has passed its own read)
+    if ((int)blockIdx.x < n) {                           // (an empty list -- continuous audio -- costs a workgroup one load)
+        if (threadIdx.x == 0) net = *a.exact_net;
+        __syncthreads();
+    }
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int entry = a.exact_list[2 + i], id = entry & ~kExactSilentBit;
         const long tile = id >> 4;

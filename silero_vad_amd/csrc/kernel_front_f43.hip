@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) front_f43_kernel(const FrontArgs a) {
     const float xn0 = __shfl(X0[Q], ln.j), xn1 = __shfl(X1[Q], ln.j), xn2 = __shfl(X2[Q], ln.j), xn3 = __shfl(X3[Q], ln.j);
     // chunks with an exactly silent frame beside one that is not (exact_front.hpp): listed for the fix-up pass (kernel_exact.hip), which
     // overwrites their columns of gx.  Four compares and scalar code; the branch is taken where digital silence begins or ends.
-    if (a.exact_list != nullptr) {
+    if (!VAD_NO_EXACT && a.exact_list != nullptr) {
         const SilentMasks sm = silent_chunks(X0[0], X1[0], X2[0], X3[0]);
         const long left = (long)a.B - ln.st * 16;
         const unsigned take = (sm.edge | (a.gx_silent != nullptr ? sm.silent : 0u)) & (left >= 16 ? 0xffffu : ((1u << left) - 1u));

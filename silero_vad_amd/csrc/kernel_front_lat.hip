@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256, VAD_LAT_WG_PER_CU) front_lat_kernel(const
     // chunks with an exactly silent frame beside one that is not (exact_front.hpp): their gx is recomputed below, in double (every
     // wave holds all four frames: the same mask in all of them)
     unsigned exact_mask = 0, silent_mask = 0;
-    if (a.exact_net != nullptr) {
+    if (!VAD_NO_EXACT && a.exact_net != nullptr) {
         const SilentMasks sm = silent_chunks(X0[0], X1[0], X2[0], X3[0]);
         const long left = (long)a.B - ln.st * 16;
         const unsigned rows = left >= 16 ? 0xffffu : ((1u << left) - 1u);

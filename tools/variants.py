@@ -18,9 +18,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "silero_vad_amd" / "csrc"
 OUT = ROOT / "build" / "variants"
-HIP = ["engine.hip", "kernel_front_f43.hip", "kernel_front_lat.hip", "kernel_front_b9.hip", "kernel_rec.hip", "kernel_rec_small.hip", "kernel_rec_b9.hip", "kernels_ref.hip", "kernel_scan.hip",
-       "kernel_ingest.hip"]
-CPP = ["weights.cpp", "segmenter.cpp", "staging.cpp"]
+sys.path.insert(0, str(ROOT))
+from __graft_entry__ import CPP_SOURCES as CPP, HIP_SOURCES as HIP      # noqa: E402  (the product's translation units)
 
 VARIANTS = {
     "base": [],
@@ -50,6 +49,7 @@ VARIANTS = {
     "nopk_all": [],                                     # every knob unit without packed fp32 (the bf16 x 9 recurrence beside plain VALU only)
     "b9_w4": ["-DVAD_B9_WAVES=4"],                     # bf16 x 9 frontend: two 4-wave workgroups per CU (default: one 8-wave workgroup)
     "pk_b9": [],
+    "noexact": ["-DVAD_NO_EXACT=1"],                   # frontends without the silent-frame test (what does it cost at C2?  profiles/r06_exact.md)
 }
 
 

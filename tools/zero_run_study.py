@@ -9,6 +9,7 @@ against a float64 evaluation of the network, worst entry over streams and units 
     gpurun -- 'python tools/zero_run_study.py > gpurun_out/zero_run_study.json'
 """
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -34,14 +35,22 @@ def main():
         n = 512 if sr == 16000 else 256
         wav = np.load(ROOT / "tests" / "golden" / f"audio_{tag}.npz")["pcm"].astype(np.float32) / 32768.0
         B, T = 1025, 9
-        for run, where in ((0.5, None), (2.5, None), (2.0, 1), (2.0, 7), (2.0, n // 8), (2.0, n // 2), (2.0, n - 1)):
+        only = os.environ.get("ZERO_RUN_ONLY")                 # "dither": just the near-silence rows
+        cases = [(0.5, None, 0), (2.5, None, 0), (2.0, 1, 0), (2.0, 7, 0), (2.0, n // 8, 0), (2.0, n // 2, 0), (2.0, n - 1, 0),
+                 (2.0, 1, 1), (2.0, 7, 1), (2.0, n - 1, 1), (2.0, 1, 8)]
+        for run, where, lsb in cases:
+            if only == "dither" and not lsb:
+                continue
             rows = rolled_rows(wav, B, T * n, 4001)
             # first zero sample: anywhere inside chunk 2 (stream 0: its first sample), or the SAME offset `where` in every stream (the
             # shape of a batch of recordings that end one / seven samples into their last chunk)
             z0 = 2 * n + ((np.arange(B) * 37) % n if where is None else np.full(B, where))
             z1 = z0 + int(run * n)
+            rng = np.random.default_rng(3)
             for b in range(B):
-                rows[b, z0[b]:z1[b]] = 0.0
+                # exact zeros, or NEAR-silence: uniform noise of +-lsb int16 steps (dither, comfort noise) -- not an exact zero, so these
+                # rows stay on the fp32 chains
+                rows[b, z0[b]:z1[b]] = 0.0 if not lsb else rng.integers(-lsb, lsb + 1, size=z1[b] - z0[b]).astype(np.float32) / 32768.0
             x = torch.from_numpy(rows).to(dev)
             f64 = _F64Net(sr, dev)
             res = {}
@@ -64,7 +73,7 @@ def main():
                         eng.set_option("enc0", "winograd")
                         eng.set_option("exact_transitions", "1")
                     res.setdefault(algo, []).append(float((np.abs(st.cpu().numpy() - s64) / den).max()))
-            out[f"{tag} zero run of {run} chunks from {'anywhere' if where is None else 'sample ' + str(where)} inside chunk 2"] = {k: [float(f"{v:.3e}") for v in vs] for k, vs in res.items()}
+            out[f"{tag} {'zero' if not lsb else f'+-{lsb} LSB noise'} run of {run} chunks from {'anywhere' if where is None else 'sample ' + str(where)} inside chunk 2"] = {k: [float(f"{v:.3e}") for v in vs] for k, vs in res.items()}
     print(json.dumps(out, indent=1))
 
 
