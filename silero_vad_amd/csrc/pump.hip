@@ -35,7 +35,7 @@
 // there costs the tick it is waiting for (profiles/r06_pump_one_of_eight.md).
 #include <hip/hip_runtime.h>
 #if defined(__x86_64__)
-#include <emmintrin.h>
+#include <immintrin.h>
 #endif
 #include <linux/futex.h>
 #include <sys/syscall.h>
@@ -122,12 +122,29 @@ inline void cpu_relax() {
 
 // dst <- src, `bytes` a multiple of 16, both 16-byte aligned on the destination side: streaming stores where the ISA has them (the
 // data is bound for the DMA engine, not for this core's cache)
-inline void stream_copy(void *dst, const void *src, size_t bytes) {
 #if defined(__x86_64__)
+__attribute__((target("avx2"))) inline void stream_copy_avx2(void *dst, const void *src, size_t bytes) {
+    const __m256i *s = static_cast<const __m256i *>(src);
+    __m256i *d = static_cast<__m256i *>(dst);
+    for (size_t i = 0; i < bytes / 32; ++i) _mm256_stream_si256(d + i, _mm256_loadu_si256(s + i));
+}
+inline bool have_avx2() {
+    static const bool v = __builtin_cpu_supports("avx2");
+    return v;
+}
+#endif
+// `next`: where the caller will read from next (the following stream's row, tens of KB away: no hardware prefetcher follows that) --
+// its lines are requested while this row is being written
+inline void stream_copy(void *dst, const void *src, size_t bytes, const void *next = nullptr) {
+#if defined(__x86_64__)
+    if (next)
+        for (size_t o = 0; o < bytes; o += 64) _mm_prefetch(static_cast<const char *>(next) + o, _MM_HINT_NTA);
+    if (have_avx2() && bytes % 32 == 0 && (reinterpret_cast<size_t>(dst) & 31) == 0) return stream_copy_avx2(dst, src, bytes);
     const __m128i *s = static_cast<const __m128i *>(src);
     __m128i *d = static_cast<__m128i *>(dst);
     for (size_t i = 0; i < bytes / 16; ++i) _mm_stream_si128(d + i, _mm_loadu_si128(s + i));
 #else
+    (void)next;
     std::memcpy(dst, src, bytes);
 #endif
 }
@@ -532,7 +549,8 @@ long vad_pump_play_gaps(vad_pump *p, const int16_t *rows, long ld, long period, 
                 int16_t *slot = p->slot_pcm(r);
                 if (!pattern) {
                     const long off = (t * N) % period;
-                    for (long b = b0; b < b1; ++b) stream_copy(slot + b * N, rows + b * ld + off, (size_t)N * sizeof(int16_t));
+                    for (long b = b0; b < b1; ++b)
+                        stream_copy(slot + b * N, rows + b * ld + off, (size_t)N * sizeof(int16_t), b + 1 < b1 ? rows + (b + 1) * ld + off : nullptr);
                     mine += b1 - b0;
                 } else {
                     // stream b has a chunk this tick iff its flag says so; its audio advances only then (a late packet delays the
