@@ -777,26 +777,29 @@ def corpus_parity_sample(model, gids, lens, offs, base_page, counts, segs, sr, e
     orc = Oracle()
     first = np.concatenate([[0], np.cumsum(counts)])
     worst, checked, same = 0.0, 0, True
+    k = sr // 16000 if sr > 16000 else 1                            # a raw 32 / 48 kHz corpus: the oracle gets x[::k], like the reference's front door
     for j in np.flatnonzero(gids % every == 0):
         a = base_page[int(offs[j]):int(offs[j]) + int(lens[j])]      # (the arena the corpus run read)
         x = a.to(torch.float32) / 32768.0
         got = model.audio_forward(x[None], sr)[0].numpy()
-        want = orc.audio_forward(x.numpy()[None], sr)[0]
+        xd = np.ascontiguousarray(x.numpy()[::k])
+        want = orc.audio_forward(xd[None], sr // k)[0]
         worst = max(worst, float(np.abs(got - want).max()))
         mine = [{"start": int(p), "end": int(q)} for p, q in segs[first[j]:first[j + 1]]]
-        same = same and mine == segment_probs(want, int(lens[j]), sr)
+        same = same and mine == segment_probs(want, len(xd), sr // k)
         checked += 1
     return {"recordings_checked": checked, "one_in": every, "parity_sample_max_abs_dp": worst,
             "segments_identical_to_oracle_scan": bool(same), "tolerance": 1e-4}
 
 
-def run_corpus(args, rank, world, local, dist, passes):
+def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False):
+    """sr = 48000: the same corpus as RAW 48 kHz recordings (a chunk is 1 536 of their samples: three times the bytes per chunk over
+    the link): nothing decimates on the host, the frontend's loads take every third sample."""
     import numpy as np
     import torch
     from silero_vad_amd import (PackedRecordings, _lib, gather_to_rank0, load_silero_vad, ragged_speech_segments,
                                 refill_speech_segments)
     from silero_vad_amd import streams as S
-    sr = 16000
     dev = torch.device("cuda", local)
     node = _lib.lib().vad_bind_host_to_device(local)            # staging threads + pinned buffers on the GPU's NUMA node
     NUMA_NODE["node"] = node
@@ -804,14 +807,14 @@ def run_corpus(args, rank, world, local, dist, passes):
     model = load_silero_vad(device=local)
     if os.environ.get("VAD_BENCH_REC_FORM"):                # A/B of the recurrence's form (results are bit-identical)
         model.engine.set_option("rec_form", os.environ["VAD_BENCH_REC_FORM"])
-    n = WORK[sr]["chunk"]
+    n = 512 * (sr // 16000)                                  # input samples per chunk
     rng = np.random.default_rng(7)
     base_len = 8 << 20
     tt = np.arange(base_len, dtype=np.float32) / sr
     base = (0.03 * rng.standard_normal(base_len).astype(np.float32)
             + 0.2 * np.sin(2 * np.pi * 170.0 * tt) * (np.sin(2 * np.pi * 0.7 * tt) > 0))
     base_i_page = torch.from_numpy((base * 32767.0).clip(-32768, 32767).astype(np.int16))
-    R = args.recordings
+    R = max(1, args.recordings // (sr // 16000))            # (a pass -- the pinned arena -- holds the same bytes at every rate)
     shard = corpus_shard(rank, world, passes, R, sr, base_len)
     gids = np.concatenate([g for g, _, _ in shard])
     lens = np.concatenate([l for _, l, _ in shard])
@@ -906,7 +909,7 @@ def run_corpus(args, rank, world, local, dist, passes):
     parity = None
     if not args.no_parity:
         parity = corpus_parity_sample(model, gids, lens, offs, base_i, res["counts"], res["segs"], sr)
-    if not args.corpus_main_only:                               # the other ingest routes on 6 passes' worth, for comparison
+    if not (args.corpus_main_only or main_only):                # the other ingest routes on 6 passes' worth, for comparison
         for other in ("window", "gather", "dma"):
             if other != main_mode:
                 legs[f"pinned_{other}"], _ = run_leg(base_i, "buckets", other, short, False)
@@ -925,7 +928,8 @@ def run_corpus(args, rank, world, local, dist, passes):
     out = base_line(args, world, sr, main["value"], main["wall_s"], 1)
     out["ms_per_step"] = round(main["wall_s"] * 1e3, 3)
     full = abs(hours - CORPUS_HOURS_PER_GPU) / CORPUS_HOURS_PER_GPU < 0.05
-    out["config"] = {"workload": f"configs[3]: {'the full' if full else 'a PARTIAL'} per-GPU shard of the 10 000 h corpus -- "
+    out["config"] = {"workload": f"configs[3]{'' if sr == 16000 else f' as RAW {sr // 1000} kHz int16 (x[::{sr // 16000}] in the loads)'}: "
+                                 f"{'the full' if full else 'a PARTIAL'} per-GPU shard of the 10 000 h corpus -- "
                                  f"{passes} x {R} ragged recordings/GPU (20-40 s, {hours:.1f} h of audio per GPU) back to back in a pinned "
                                  "host arena -> one DMA per 2 GiB arena window -> padded batches cut on the GPU (no host copy) -> probs -> "
                                  "segmenter on the GPU -> segment lists to the host -> gathered to rank 0; ONE step = the whole shard; "
@@ -1310,7 +1314,8 @@ def main():
             legs = [("stream", lambda: run_stream(args, rank, world, local, dist, 1000)),
                     ("stream_host", lambda: run_stream_host(args, rank, world, local, dist, 2000)),
                     ("stream_gaps", lambda: run_stream_host(args, rank, world, local, dist, 2000, gaps=0.10)),
-                    ("corpus", lambda: run_corpus(args, rank, world, local, dist, args.corpus_passes))]
+                    ("corpus", lambda: run_corpus(args, rank, world, local, dist, args.corpus_passes)),
+                    ("corpus_48k", lambda: run_corpus(args, rank, world, local, dist, min(6, args.corpus_passes), sr=48000, main_only=True))]
             if world == 1:
                 legs = [("8k", lambda: run_batch(args, 8000, rank, world, local, dist, 100))] + legs + \
                        [("stream_8k", lambda: run_stream(args, rank, world, local, dist, 1000, 8000)),

@@ -94,9 +94,13 @@ def batch_speech_timestamps(audios: Sequence[torch.Tensor], model, sampling_rate
             a = audios[i] if torch.is_tensor(audios[i]) else torch.as_tensor(audios[i])
             while a.dim() > 1 and a.shape[0] == 1:
                 a = a.squeeze(0)
-            local.append(a[::step] if step > 1 else a)
-        lens = [int(a.shape[0]) for a in local]
-        segs = (ragged_speech_segments if scheduler == "buckets" else refill_speech_segments)(local, model, sr, **scan_kw)
+            local.append(a)
+        # The recordings go to the scheduler AS THEY ARE, with the raw rate: every zero-copy route stays open (pinned 48 kHz
+        # recordings are read by the DMA / the gather kernel where they lie) and the frontend's loads take every step-th sample
+        # (streams._rates) -- the reference's x[::step] (utils_vad.py:301-307) without the copy.  Segments come back in samples of
+        # the 16 kHz signal, like the reference's before its final `* step`.
+        lens = [(int(a.shape[0]) + step - 1) // step for a in local]
+        segs = (ragged_speech_segments if scheduler == "buckets" else refill_speech_segments)(local, model, sampling_rate, **scan_kw)
         seconds, res = kwargs.get("return_seconds", False), kwargs.get("time_resolution", 1)
         for r, i in enumerate(mine):
             out = segs[r]

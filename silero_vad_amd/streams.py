@@ -44,6 +44,17 @@ def chunk_size(sr: int) -> int:
     return 512 if sr == 16000 else 256
 
 
+def _rates(sr: int):
+    """(rate of the net that serves `sr`, decimation step k, INPUT samples per chunk): a multiple of 16 kHz runs on the 16 kHz net
+    over every k-th sample (src/silero_vad/utils_vad.py:301-307, JIT!/vad/model/vad_annotator.py:104-112).  The corpus schedulers
+    keep such recordings at their raw rate all the way into HBM -- lengths, buckets, slabs and row pitches count RAW samples, a chunk
+    is 512 k of them -- and the frontend's loads take every k-th sample (csrc/fft_wave.hpp load_vec<SL, DEC>): no decimated copy on
+    the host, none on the device."""
+    if sr > 16000 and sr % 16000 == 0:
+        return 16000, sr // 16000, 512 * (sr // 16000)
+    return sr, 1, chunk_size(sr)
+
+
 # ---- offline: ragged corpora ------------------------------------------------------------------------
 class RaggedPlan:
     """Buckets of recording indices, each processed as one lock-step batch.
@@ -373,7 +384,7 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     Ingest: recordings in pinned host memory go straight to the device batch (vad_upload_rows: no host copy);
     pageable ones are packed into pinned staging by the native threaded copy and copied from there."""
     t_setup = time.perf_counter()
-    n = chunk_size(sampling_rate)
+    n = _rates(sampling_rate)[2]                          # input samples per chunk (512 k for a multiple of 16 kHz)
     as_i16, lengths = _describe(audios)
     dtype = torch.int16 if as_i16 else torch.float32
     esz = 2 if as_i16 else 4
@@ -640,8 +651,9 @@ def ragged_probs(audios: Sequence, model, sampling_rate: int = 16000, max_waste:
     Returns one 1-D CPU float tensor per recording (ceil(len / N) entries), bit-identical to
     ``model.audio_forward(audio[None], sr)[0]`` on that recording alone.  ``audios`` may be float
     tensors in [-1, 1] or int16 PCM (all of one kind).  `model` needs ``audio_forward_device``
-    (HipSileroVAD); staging + H2D of bucket k+1 overlap the kernels of bucket k."""
-    n = chunk_size(sampling_rate)
+    (HipSileroVAD); staging + H2D of bucket k+1 overlap the kernels of bucket k.  `sampling_rate` may be a multiple of 16000: the
+    recordings then stay at their raw rate all the way into HBM (_rates)."""
+    n = _rates(sampling_rate)[2]
     lengths = _describe(audios)[1]
     out: List[torch.Tensor] = [torch.empty(0)] * len(audios)
     for idxs, probs in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes, plan):
@@ -662,8 +674,9 @@ def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
     device_scan (default: on for a GPU model backed by the native engine): the scan runs on the GPU right behind the
     kernels of its bucket (vad_segment_probs_device, one lane per recording) and only counts + segment lists come
     back over PCIe; otherwise the probabilities are copied to the host and scanned by the native threaded scanner.
-    Both give the same segments (one source, csrc/scanner.hpp)."""
-    n = chunk_size(sampling_rate)
+    Both give the same segments (one source, csrc/scanner.hpp).  `sampling_rate` may be a multiple of 16000 (raw recordings, _rates):
+    the segments are then in samples of the 16 kHz signal x[::k], as the reference's scan sees it (utils_vad.py:301-307)."""
+    net_sr, dec, n = _rates(sampling_rate)
     lengths = _describe(audios)[1]
     dev = getattr(model, "device", None)
     on_gpu = dev is not None and torch.device(dev).type == "cuda"
@@ -672,13 +685,13 @@ def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
     counts_all = np.zeros(len(lengths), dtype=np.int64)
     parts = []                                                 # (indices, counts, segs[rows, cap, 2]) per bucket
     if device_scan:
-        params = _segment_params(sampling_rate, **scan_kw)
+        params = _segment_params(net_sr, **scan_kw)
         cap0 = 24                                              # segments per recording copied back optimistically
         lens_t = torch.as_tensor(lengths, dtype=torch.int64)
 
-        def meta(idxs):                                        # [2, n]: chunks and samples of each recording of the bucket
+        def meta(idxs):                                        # [2, n]: chunks and (16 kHz) samples of each recording of the bucket
             lens = lens_t[idxs]
-            return torch.stack([(lens + n - 1) // n, lens])
+            return torch.stack([(lens + n - 1) // n, (lens + dec - 1) // dec])
 
         def post(probs_dev, idxs, both):
             counts, segs = _device_scan(model.engine, probs_dev, both[0], both[1], params, cap0)
@@ -698,7 +711,7 @@ def ragged_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
         for idxs, probs in ragged_buckets(audios, model, sampling_rate, max_waste, max_bytes):
             lens = [lengths[i] for i in idxs]
             t0 = time.perf_counter()
-            segs = segment_probs_batch(probs, [(m + n - 1) // n for m in lens], lens, sampling_rate,
+            segs = segment_probs_batch(probs, [(m + n - 1) // n for m in lens], [(m + dec - 1) // dec for m in lens], net_sr,
                                        threads=threads, **scan_kw)
             cnt = np.asarray([len(sg) for sg in segs], dtype=np.int64)
             arr = np.zeros((len(segs), max(1, int(cnt.max()) if len(cnt) else 1), 2), dtype=np.int64)
@@ -883,8 +896,9 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
     ``model.audio_forward(audio[None], sr)[0]``: the state and context a slot carries from slab to slab are exactly
     what a single call carries from chunk to chunk, and a re-admitted slot starts from zeros like `reset_states()`.
     Staging of slab k+1 (native threaded copy into pinned memory + H2D on a side stream) overlaps the kernels of
-    slab k.  `audios`: float tensors in [-1, 1] or int16 PCM (all of one kind)."""
-    n = chunk_size(sampling_rate)
+    slab k.  `audios`: float tensors in [-1, 1] or int16 PCM (all of one kind); `sampling_rate` may be a multiple of 16000 (raw
+    recordings, _rates: a slab is slab_chunks x 512 k raw samples, the carried context is the 16 kHz net's)."""
+    net_sr, _, n = _rates(sampling_rate)
     eng = model.engine
     dev = torch.device(getattr(eng, "torch_device", None) or torch.device("cuda", eng.device))
     on_gpu = dev.type == "cuda"
@@ -902,7 +916,7 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
         base[i + 1] = base[i] + (plan.n_chunks(i) if lengths[i] > 0 else 0)
     total = int(base[-1])
     out_flat = torch.zeros(total + 1, dtype=torch.float32, device=dev)      # [+1]: sink for the padding chunks
-    ctx = torch.zeros((B, n // 8), dtype=torch.float32, device=dev)
+    ctx = torch.zeros((B, chunk_size(net_sr) // 8), dtype=torch.float32, device=dev)
     state = torch.zeros((2, B, 128), dtype=torch.float32, device=dev)
     done = np.zeros(len(audios), dtype=np.int64)       # chunks of each recording already produced
     cols = np.arange(S, dtype=np.int64)[None, :]
@@ -998,14 +1012,14 @@ def refill_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, 
     """`ragged_speech_segments` over the continuous-refill scheduler: probabilities never leave the GPU; when the last
     slab is done one device scan (vad_segment_probs_device with per-recording row offsets) turns them into segment
     lists, which is all that crosses PCIe on the way back."""
-    n = chunk_size(sampling_rate)
-    lengths = _describe(audios)[1]
+    net_sr, dec, _ = _rates(sampling_rate)
+    lengths = [(m + dec - 1) // dec for m in _describe(audios)[1]]        # in samples of the net's rate: what the scan counts in
     flat, base, plan = refill_probs(audios, model, sampling_rate, slots, slab_chunks, _keep_on_device=True)
     if flat.device.type != "cuda":                                        # CPU stand-in engines (tests)
         probs = [flat[base[i]:base[i + 1]] for i in range(len(audios))]
         from .timestamps import segment_probs
-        return [segment_probs(p, m, sampling_rate, **scan_kw) if m > 0 else [] for p, m in zip(probs, lengths)]
-    params = _segment_params(sampling_rate, **scan_kw)
+        return [segment_probs(p, m, net_sr, **scan_kw) if m > 0 else [] for p, m in zip(probs, lengths)]
+    params = _segment_params(net_sr, **scan_kw)
     nck = torch.from_numpy(np.diff(base))
     meta = torch.stack([nck, torch.tensor(lengths, dtype=torch.int64), torch.from_numpy(base[:-1].copy())]).to(flat.device)
     t0 = time.perf_counter()

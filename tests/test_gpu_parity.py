@@ -2762,3 +2762,46 @@ def test_exact_transition_chunks_same_bits_on_every_route(model, golden, tag):
     assert err_on[taken].max() < 3e-7, float(err_on[taken].max())            # one fp32 rounding of a double result
     assert err_off[taken].max() > 10 * err_on[taken].max()                   # (what the chains left there)
     assert np.array_equal(g_on[~taken], g_off[~taken])
+
+
+# ---- (32) raw 48 kHz corpora: the x[::k] front door on the scheduler routes, without a host copy ----------------------------------------
+@pytest.mark.parametrize("route", ["window", "gather", "refill", "pageable"])
+def test_batch_speech_timestamps_on_raw_48k_recordings(model, golden, monkeypatch, route):
+    """`batch_speech_timestamps(..., sampling_rate=48000)` on 48 kHz int16 recordings.  The reference decimates
+    x[::3] and scans at 16 kHz (src/silero_vad/utils_vad.py:301-307, JIT!/vad/model/vad_annotator.py:104-112); here the recordings
+    stay raw on every route -- one DMA per arena window / the gather kernel over PCIe / the refill scheduler's slabs / (pageable
+    sources) the staging copy of the RAW bytes -- and the frontend's loads take every third sample.  The fixture repeated 3 x must
+    give the reference's own `sr48000` golden segments; the other recordings what the model object's front door gives them one at a
+    time; on the pinned routes NOTHING is copied on the host (STATS stage_s == 0) and the bytes that cross the link are the raw
+    recordings' (h2d_bytes)."""
+    from silero_vad_amd import batch_speech_timestamps, get_speech_timestamps
+    from silero_vad_amd import streams as S
+    wav, pcm = golden["16k"]["wav"], golden["16k"]["pcm_i16"]
+    cuts = [(0, len(pcm)), (100_000, 400_000), (512 * 300 + 77, 512 * 300 + 77 + 250_001), (7, 60_000), (640_000, 960_000)]
+    lens = [3 * (b - a) for a, b in cuts]
+    lens[2] -= 2                                                    # a raw length that is not a multiple of 3
+    offs = np.concatenate([[0], np.cumsum([(m + 7) // 8 * 8 for m in lens])[:-1]])
+    arena = torch.zeros(int(offs[-1] + lens[-1]) + 8, dtype=torch.int16)
+    for (a, b), o, m in zip(cuts, offs, lens):
+        arena[o:o + m] = torch.from_numpy(np.repeat(pcm[a:b], 3)[:m].copy())
+    if route != "pageable":
+        arena = arena.pin_memory()
+    recs = [arena[o:o + m] for o, m in zip(offs, lens)]
+    monkeypatch.setenv("SILERO_VAD_AMD_UPLOAD", {"window": "window", "gather": "gather", "refill": "gather", "pageable": "stage"}[route])
+    S.STATS.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = batch_speech_timestamps(recs, model, sampling_rate=48000, scheduler="refill" if route == "refill" else "buckets")
+        st = dict(S.STATS)
+        want = [get_speech_timestamps(r.to(torch.float32) / 32768.0, model, sampling_rate=48000) for r in recs]
+    assert got[0] == golden["ext"]["16k"]["sr48000"]["out"] and len(got[0]) == 19
+    assert got == want
+    if route != "pageable":
+        assert st.get("stage_s", 0) == 0, st                        # no host-side copy of the audio
+    if route == "window":
+        assert st["h2d_bytes"] == 2 * int(offs[-1] + lens[-1] - offs[0]), st      # exactly the arena span, raw
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        secs = batch_speech_timestamps(recs[:2], model, sampling_rate=48000, return_seconds=True)
+        want_s = [get_speech_timestamps(r.to(torch.float32) / 32768.0, model, sampling_rate=48000, return_seconds=True) for r in recs[:2]]
+    assert secs == want_s
