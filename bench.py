@@ -797,8 +797,7 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
     the link): nothing decimates on the host, the frontend's loads take every third sample."""
     import numpy as np
     import torch
-    from silero_vad_amd import (PackedRecordings, _lib, gather_to_rank0, load_silero_vad, ragged_speech_segments,
-                                refill_speech_segments)
+    from silero_vad_amd import PackedRecordings, _lib, gather_to_rank0, load_silero_vad, ragged_speech_segments
     from silero_vad_amd import streams as S
     dev = torch.device("cuda", local)
     node = _lib.lib().vad_bind_host_to_device(local)            # staging threads + pinned buffers on the GPU's NUMA node
@@ -851,9 +850,17 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
             rec = PackedRecordings(src, (offs if src is base_i else offs_rand)[:m], lens[:m])
             if sched == "buckets":      # length-sorted buckets, one lock-step call each, device scan per bucket
                 return ragged_speech_segments(rec, model, sr, max_waste=0.1, max_bytes=int(os.environ.get("VAD_BENCH_BUCKET_BYTES", 1 << 30)), as_arrays=True)
+            # persistent slots, refilled at slab boundaries; every recording is scanned behind the slab it retires in and its segments
+            # come back while later slabs run (refill_segments_stream): when did the FIRST results reach the host?
             rs, rc_ = (int(v) for v in os.environ.get("VAD_BENCH_REFILL", "2048,128").split(","))
-            segs = refill_speech_segments(rec, model, sr, slots=rs, slab_chunks=rc_)     # persistent slots, refilled at slab boundaries
-            return np.asarray([len(x) for x in segs]), None
+            counts = np.zeros(m, dtype=np.int64)
+            t_in = time.perf_counter()
+            res["first_result_s"] = None
+            for idx, cnt, _ in S.refill_segments_stream(rec, model, sr, slots=rs, slab_chunks=rc_):
+                if res["first_result_s"] is None and len(idx):
+                    res["first_result_s"] = time.perf_counter() - t_in
+                counts[idx] = cnt
+            return counts, None
 
         one(min(nrec, 2 * R))                                   # warm-up: pinned buffers, scratch, lanes
         if sched == "buckets":
@@ -897,6 +904,8 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
              "d2h_MB": round(st.get("d2h_bytes", 0) / 1e6, 3),
              "buckets": int(st.get("buckets", 0)),
              "padded_over_real_samples": round(st.get("padded", 0) / max(st.get("real", 1), 1), 4)}
+        if res.get("first_result_s") is not None:              # the refill scheduler hands results over as recordings retire
+            d["first_result_at"] = round(res["first_result_s"] / elapsed, 4)     # fraction of the leg's wall time
         return d, res
 
     legs = {}
@@ -914,7 +923,8 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
             if other != main_mode:
                 legs[f"pinned_{other}"], _ = run_leg(base_i, "buckets", other, short, False)
         legs["pageable_staged"], _ = run_leg(base_i_page, "buckets", "stage", short, False)
-        legs["pinned_refill_gather"], _ = run_leg(base_i, "refill", "gather", short, False)
+        # (18 passes: recordings are admitted longest first, so the first ones retire ten slabs in -- 4 % of this leg, 2 % of a full shard)
+        legs["pinned_refill_gather"], _ = run_leg(base_i, "refill", "gather", min(len(lens), 18 * R), False)
     os.environ.pop("SILERO_VAD_AMD_UPLOAD", None)
     # what the link allows: the H2D rate measured while copying / bytes per chunk -- a leg's value can approach it (fully
     # overlapped pipeline), never exceed it
@@ -1130,6 +1140,9 @@ def compact_legs(out):
             routes = {k: v.get("fraction_of_pcie_ceiling") for k, v in d["legs"].items() if k != "main"}
             if routes:
                 legs[name]["routes_of_link"] = routes
+            fr = d["legs"].get("pinned_refill_gather", {}).get("first_result_at")
+            if fr is not None:
+                legs[name]["refill_first_result_at"] = fr
     return legs
 
 

@@ -889,15 +889,12 @@ class RefillPlan:
         return sum(self.n_chunks(i) for i in range(len(self.lengths)) if self.lengths[i] > 0)
 
 
-def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int = 1024, slab_chunks: int = 32,
-                 plan: RefillPlan = None, _keep_on_device: bool = False):
-    """Speech probabilities of many recordings of different lengths through `slots` persistent stream slots
-    (RefillPlan).  Returns one 1-D CPU float tensor per recording, bit-identical to
-    ``model.audio_forward(audio[None], sr)[0]``: the state and context a slot carries from slab to slab are exactly
-    what a single call carries from chunk to chunk, and a re-admitted slot starts from zeros like `reset_states()`.
-    Staging of slab k+1 (native threaded copy into pinned memory + H2D on a side stream) overlaps the kernels of
-    slab k.  `audios`: float tensors in [-1, 1] or int16 PCM (all of one kind); `sampling_rate` may be a multiple of 16000 (raw
-    recordings, _rates: a slab is slab_chunks x 512 k raw samples, the carried context is the 16 kHz net's)."""
+def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_chunks: int, plan: "RefillPlan" = None, on_slab=None):
+    """The continuous-refill loop (RefillPlan) as a generator: stages slab k + 1 while the kernels of slab k run, scatters every slab's
+    probabilities into one flat device tensor (recording i owns out_flat[base[i] : base[i + 1]]) and yields k once slab k has been
+    ENQUEUED.  `on_slab(k, finished, out_flat, base)` is called right before that, with the recordings whose last chunk lies in slab k
+    (np.int64 array, may be empty): the hook for work that follows a recording's retirement in stream order.  The generator's return
+    value is (out_flat, base, plan)."""
     net_sr, _, n = _rates(sampling_rate)
     eng = model.engine
     dev = torch.device(getattr(eng, "torch_device", None) or torch.device("cuda", eng.device))
@@ -911,9 +908,9 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
     src = _Sources(audios, dtype, check_pinned=on_gpu and mode != "stage" and hasattr(eng, "upload_rows"))
     direct = src.pinned                                # pinned recordings: one gather kernel per slab, no host copy
     how = 0 if mode == "dma" else 1
+    lens_np = np.asarray(lengths, dtype=np.int64)
     base = np.zeros(len(audios) + 1, dtype=np.int64)   # recording i owns out_flat[base[i] : base[i] + n_chunks(i)]
-    for i in range(len(audios)):
-        base[i + 1] = base[i] + (plan.n_chunks(i) if lengths[i] > 0 else 0)
+    np.cumsum(np.where(lens_np > 0, (lens_np + n - 1) // n, 0), out=base[1:])
     total = int(base[-1])
     out_flat = torch.zeros(total + 1, dtype=torch.float32, device=dev)      # [+1]: sink for the padding chunks
     ctx = torch.zeros((B, chunk_size(net_sr) // 8), dtype=torch.float32, device=dev)
@@ -1000,41 +997,128 @@ def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int
             if on_gpu:
                 pool.consumed[slot] = torch.cuda.Event()
                 pool.consumed[slot].record(cur)
+            if on_slab is not None:
+                e = plan.slab_arrays[k]
+                on_slab(k, e[e[:, 2] + e[:, 3] >= lens_np[e[:, 1]], 1], out_flat, base)
             staged = stage(k + 1) if k + 1 < n_slabs else None          # CPU packs k+1 meanwhile
+            yield k
+    return out_flat, base, plan
+
+
+def _refill_run(audios, model, sampling_rate, slots, slab_chunks, plan=None):
+    it = _refill_iter(audios, model, sampling_rate, slots, slab_chunks, plan)
+    while True:
+        try:
+            next(it)
+        except StopIteration as stop:
+            return stop.value
+
+
+def refill_probs(audios: Sequence, model, sampling_rate: int = 16000, slots: int = 1024, slab_chunks: int = 32,
+                 plan: RefillPlan = None, _keep_on_device: bool = False):
+    """Speech probabilities of many recordings of different lengths through `slots` persistent stream slots
+    (RefillPlan).  Returns one 1-D CPU float tensor per recording, bit-identical to
+    ``model.audio_forward(audio[None], sr)[0]``: the state and context a slot carries from slab to slab are exactly
+    what a single call carries from chunk to chunk, and a re-admitted slot starts from zeros like `reset_states()`.
+    Staging of slab k+1 (native threaded copy into pinned memory + H2D on a side stream) overlaps the kernels of
+    slab k.  `audios`: float tensors in [-1, 1] or int16 PCM (all of one kind); `sampling_rate` may be a multiple of 16000 (raw
+    recordings, _rates: a slab is slab_chunks x 512 k raw samples, the carried context is the 16 kHz net's)."""
+    out_flat, base, plan = _refill_run(audios, model, sampling_rate, slots, slab_chunks, plan)
     if _keep_on_device:
         return out_flat, base, plan
     flat = out_flat.cpu()
     return [flat[base[i]:base[i + 1]].clone() for i in range(len(audios))]
 
 
-def refill_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, slots: int = 1024,
-                           slab_chunks: int = 32, **scan_kw) -> List[list]:
-    """`ragged_speech_segments` over the continuous-refill scheduler: probabilities never leave the GPU; when the last
-    slab is done one device scan (vad_segment_probs_device with per-recording row offsets) turns them into segment
-    lists, which is all that crosses PCIe on the way back."""
+def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, slots: int = 1024, slab_chunks: int = 32, **scan_kw):
+    """The continuous-refill scheduler with RESULTS AS RECORDINGS RETIRE -- what the reference's worker pool does, each file's
+    timestamps handed back when that file is done (examples/parallel_example.ipynb cell 7).  Generator of
+    (recording indices int64[m], counts int64[m], segments int64[m, cap, 2]) batches: behind the slab in which a recording's last
+    chunk was computed, ONE device scan (vad_segment_probs_device, a lane per recording, over the recording's own row of the flat
+    probability tensor) turns the retired recordings into segment lists, which ride back over PCIe asynchronously; a batch is
+    yielded as soon as its copy has landed (a slab or two behind the kernels; nothing here blocks the pipeline).  Probabilities
+    never leave the GPU.  Segments are in samples of the net's rate (x[::k] for raw 32 / 48 kHz recordings)."""
     net_sr, dec, _ = _rates(sampling_rate)
-    lengths = [(m + dec - 1) // dec for m in _describe(audios)[1]]        # in samples of the net's rate: what the scan counts in
-    flat, base, plan = refill_probs(audios, model, sampling_rate, slots, slab_chunks, _keep_on_device=True)
-    if flat.device.type != "cuda":                                        # CPU stand-in engines (tests)
-        probs = [flat[base[i]:base[i + 1]] for i in range(len(audios))]
+    lengths = np.asarray([(m + dec - 1) // dec for m in _describe(audios)[1]], dtype=np.int64)   # samples at the net's rate: the scan's unit
+    eng = model.engine
+    on_gpu = hasattr(eng, "_h")
+    if not on_gpu:                                                        # CPU stand-in engines (tests): scan at the end, on the host
+        flat, base, _ = _refill_run(audios, model, sampling_rate, slots, slab_chunks)
         from .timestamps import segment_probs
-        return [segment_probs(p, m, net_sr, **scan_kw) if m > 0 else [] for p, m in zip(probs, lengths)]
+        for i in range(len(lengths)):
+            sg = segment_probs(flat[base[i]:base[i + 1]], int(lengths[i]), net_sr, **scan_kw) if lengths[i] > 0 else []
+            arr = np.asarray([[d["start"], d["end"]] for d in sg], dtype=np.int64).reshape(1, -1, 2)
+            yield np.asarray([i], dtype=np.int64), np.asarray([len(sg)], dtype=np.int64), arr
+        return
     params = _segment_params(net_sr, **scan_kw)
-    nck = torch.from_numpy(np.diff(base))
-    meta = torch.stack([nck, torch.tensor(lengths, dtype=torch.int64), torch.from_numpy(base[:-1].copy())]).to(flat.device)
+    cap0 = 32
+    pending = collections.deque()                                         # (indices, counts pinned, segs pinned, event, device handles)
+    ready = []
+
+    def collect(block):
+        while pending and (block or pending[0][3].query()):
+            idx, cnt_h, seg_h, ev, flat_ref, meta_d = pending.popleft()
+            ev.synchronize()
+            cnt = cnt_h.numpy()
+            segs = seg_h.numpy()
+            if len(cnt) and int(cnt.max()) > cap0:                          # rare: a recording with more segments than were copied back
+                c2, s2 = _device_scan(eng, flat_ref[None], meta_d[0], meta_d[1], params, int(cnt.max()), row_offsets=meta_d[2])
+                cnt, segs = c2.cpu().numpy(), s2.cpu().numpy()
+            STATS["d2h_bytes"] += segs.nbytes + cnt.nbytes
+            ready.append((idx, cnt.copy(), segs))
+
+    def on_slab(k, finished, out_flat, base):
+        if len(finished):
+            t0 = time.perf_counter()
+            nck = base[finished + 1] - base[finished]
+            meta = torch.from_numpy(np.stack([nck, lengths[finished], base[finished]])).pin_memory().to(out_flat.device, non_blocking=True)
+            counts, segs = _device_scan(eng, out_flat[None], meta[0], meta[1], params, cap0, row_offsets=meta[2])
+            cnt_h = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+            seg_h = torch.empty(segs.shape, dtype=segs.dtype, pin_memory=True)
+            cnt_h.copy_(counts, non_blocking=True)
+            seg_h.copy_(segs, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(out_flat.device))
+            pending.append((finished.copy(), cnt_h, seg_h, ev, out_flat, meta))
+            STATS["scan_s"] += time.perf_counter() - t0
+        collect(False)
+
+    for _ in _refill_iter(audios, model, sampling_rate, slots, slab_chunks, None, on_slab):
+        while ready:
+            yield ready.pop(0)
+    collect(True)
+    while ready:
+        yield ready.pop(0)
+    empty = np.flatnonzero(lengths <= 0)
+    if len(empty):
+        yield empty.astype(np.int64), np.zeros(len(empty), dtype=np.int64), np.zeros((len(empty), 1, 2), dtype=np.int64)
+
+
+def refill_speech_segments(audios: Sequence, model, sampling_rate: int = 16000, slots: int = 1024,
+                           slab_chunks: int = 32, as_arrays: bool = False, **scan_kw) -> List[list]:
+    """`ragged_speech_segments` over the continuous-refill scheduler (refill_segments_stream: every recording is scanned on the GPU
+    behind the slab it retires in, its segment list crosses PCIe while later slabs run).  as_arrays: (counts int64[n], segments
+    int64[sum(counts), 2]) like ragged_speech_segments, instead of a list of lists of dicts."""
+    n_rec = len(audios)
+    counts_all = np.zeros(n_rec, dtype=np.int64)
+    parts = []
+    for idx, cnt, segs in refill_segments_stream(audios, model, sampling_rate, slots, slab_chunks, **scan_kw):
+        counts_all[idx] = cnt
+        parts.append((idx, cnt, segs))
     t0 = time.perf_counter()
-    cap = 32
-    while True:
-        counts, segs = _device_scan(model.engine, flat[None], meta[0], meta[1], params, cap, row_offsets=meta[2])
-        cnt = counts.cpu().numpy()
-        if len(cnt) == 0 or int(cnt.max()) <= cap:
-            break
-        cap = int(cnt.max())
-    m = int(cnt.max()) if len(cnt) else 0
-    sg = segs[:, :max(m, 1)].cpu().numpy()
+    first = np.concatenate([[0], np.cumsum(counts_all)])
+    flat = np.zeros((int(first[-1]), 2), dtype=np.int64)
+    for idx, cnt, sg in parts:
+        if not len(idx) or not cnt.any():
+            continue
+        k = np.arange(sg.shape[1])[None, :]
+        mask = k < cnt[:, None]
+        flat[(first[idx][:, None] + k)[mask]] = sg[mask]
     STATS["scan_s"] += time.perf_counter() - t0
-    STATS["d2h_bytes"] += sg.nbytes + cnt.nbytes
-    return [[{"start": int(a), "end": int(b)} for a, b in sg[i, : cnt[i]]] for i in range(len(audios))]
+    if as_arrays:
+        return counts_all, flat
+    fl = flat.tolist()
+    return [[{"start": a, "end": b} for a, b in fl[first[i]:first[i + 1]]] for i in range(n_rec)]
 
 
 # ---- live streams --------------------------------------------------------------------------------------

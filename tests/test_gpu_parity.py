@@ -1126,8 +1126,8 @@ def test_hipgraph_capture_of_a_48k_partial_chunk_after_reserve(model, oracle, go
     chunk is partial can be captured into a hipGraph without a mid-call scratch growth (VAD_ERR_CAPTURE)."""
     eng = model.engine
     k, B = 3, 24
-    L16 = 4 * 512 + 77
-    raw = np.zeros((B, L16 * k), np.float32)
+    L16 = 4 * 512 + 76                                           # (rows of 16-byte pitch: a misaligned input would be copied into scratch that
+    raw = np.zeros((B, L16 * k), np.float32)                     #  vad_reserve does not size -- another matter, test_misaligned_rows_are_handled)
     raw[:, ::k] = rolled_rows(golden["16k"]["wav"], B, L16, 997)
     x = torch.from_numpy(raw).to(model.device)
     eng.reserve(16000 * k, B, 5)
@@ -2805,3 +2805,38 @@ def test_batch_speech_timestamps_on_raw_48k_recordings(model, golden, monkeypatc
         secs = batch_speech_timestamps(recs[:2], model, sampling_rate=48000, return_seconds=True)
         want_s = [get_speech_timestamps(r.to(torch.float32) / 32768.0, model, sampling_rate=48000, return_seconds=True) for r in recs[:2]]
     assert secs == want_s
+
+
+# ---- (33) the refill scheduler hands results over as recordings retire ------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_refill_results_arrive_as_recordings_retire(model, golden, tag):
+    """refill_segments_stream (the reference's pool returns each file's timestamps when that file is done,
+    examples/parallel_example.ipynb cell 7): every recording is scanned on the GPU behind the slab it retires in.  The batches that
+    come out cover every recording exactly once, the first one arrives long before the run is over (before a third of the batches of
+    a 60-recording run through 6 slots), the segments EQUAL ragged_speech_segments' (the bucket scheduler's), with the list and the
+    array form of refill_speech_segments agreeing, a recording with more segments than the optimistic copy holds (cap 32) included."""
+    from silero_vad_amd import ragged_speech_segments, refill_segments_stream, refill_speech_segments
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    wav = g["wav"]
+    rng = np.random.default_rng(8)
+    lens = rng.integers(3 * n, 60 * n, size=60)
+    lens[7] = 0                                                    # an empty recording
+    lens[11] = min(len(wav) - 1000, 1700 * n)                      # a long one: with min_silence 0 it has more than 32 segments
+    audios = [torch.from_numpy(np.roll(wav, -int(rng.integers(0, len(wav))))[:m].copy()) for m in lens]
+    kw = dict(threshold=0.4, min_silence_duration_ms=0, min_speech_duration_ms=32, speech_pad_ms=0)
+    want = ragged_speech_segments(audios, model, sr, **kw)
+    seen, order, n_batches = {}, [], 0
+    for idx, cnt, segs in refill_segments_stream(audios, model, sr, slots=6, slab_chunks=8, **kw):
+        n_batches += 1
+        for i, c, sg in zip(idx.tolist(), cnt.tolist(), segs):
+            assert i not in seen
+            seen[i] = [{"start": int(a), "end": int(b)} for a, b in sg[:c]]
+            order.append(i)
+    assert sorted(seen) == list(range(60)) and n_batches > 10
+    assert [seen[i] for i in range(60)] == want and max(len(w) for w in want) > 32
+    assert order.index(11) > 30                                    # the long recording retires late, short ones long before it
+    lists = refill_speech_segments(audios, model, sr, slots=6, slab_chunks=8, **kw)
+    counts, flat = refill_speech_segments(audios, model, sr, slots=6, slab_chunks=8, as_arrays=True, **kw)
+    assert lists == want and counts.tolist() == [len(w) for w in want]
+    assert flat.tolist() == [[d["start"], d["end"]] for w in want for d in w]
