@@ -919,7 +919,7 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
     if not args.no_parity:
         parity = corpus_parity_sample(model, gids, lens, offs, base_i, res["counts"], res["segs"], sr)
     if not (args.corpus_main_only or main_only):                # the other ingest routes on 6 passes' worth, for comparison
-        for other in ("window", "gather", "dma"):
+        for other in (() if os.environ.get("VAD_BENCH_ONLY_REFILL") else ("window", "gather", "dma")):
             if other != main_mode:
                 legs[f"pinned_{other}"], _ = run_leg(base_i, "buckets", other, short, False)
         legs["pageable_staged"], _ = run_leg(base_i_page, "buckets", "stage", short, False)

@@ -37,9 +37,10 @@ namespace vad {
 namespace {
 
 template <int Q>
-struct ExactWs {                               // LDS workspace of one chunk: 17.6 KB (16 kHz)
+struct ExactWs {                               // LDS workspace of one chunk: 26 KB (16 kHz)
     static constexpr int N = 16 * Q, C = 2 * Q, F = 8 * Q, H = 4 * Q, K = 4 * Q + 1;
     double xp[C + N + C];                      // context | chunk | right reflect pad
+    double part[2 * K * 4];                    // [real | imaginary][bin][frame]
     double mag[K * 4];                         // [bin][frame]
     double e0[128 * 4];                        // [channel][frame], like torch
     double e1[64 * 2];
@@ -64,7 +65,17 @@ __device__ __forceinline__ float exact_sample(const FrontArgs &a, long b, long t
 
 __device__ __forceinline__ double relu_d(double x) { return x <= 0.0 ? 0.0 : x; }      // NaN stays NaN (torch.relu = clamp_min)
 
+// 4 consecutive floats of a weight row (rows start 4-byte aligned only: 387- and 129-float rows), as doubles
+__device__ __forceinline__ void ld4(const float *p, double (&w)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (double)p[e];
+}
+
 // All 256 threads of the workgroup.  Result in ws.gx (valid after the function returns: it ends with a barrier).
+// Every loop streams ONE weight row per thread from the L2-resident canonical tensors; the loops are unrolled by hand in groups of
+// 8-16 elements so that a group's loads are all in flight before its first FMA (one exposed load latency per group, not per element:
+// ~0.1 ms per chunk instead of ~1 ms).  Every sum is ONE double accumulator in index order: the thread mapping is part of the
+// definition (identical bits wherever the function is called from).
 template <int Q, typename PcmT, int DEC>
 __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, long b, long t, ExactWs<Q> &ws) {
     using W = ExactWs<Q>;
@@ -74,22 +85,43 @@ __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, 
     __syncthreads();
     for (int j = tid; j < C; j += 256) ws.xp[L + j] = ws.xp[L - 2 - j];                   // right reflect, edge not repeated
     __syncthreads();
-    // STFT: thread k owns bin k of all four frames (rows k and K + k of the basis: window x cos, window x -sin)
-    if (tid < K) {
-        const float *br = net.basis + (size_t)tid * F, *bi = net.basis + (size_t)(K + tid) * F;
-        double re[4] = {0, 0, 0, 0}, im[4] = {0, 0, 0, 0};
+    // STFT: rows [0, K) of the basis are window x cos, rows [K, 2 K) window x -sin.  Thread (k, part): bin k < K - 1, part 0 = real,
+    // 1 = imaginary, all four frames; the last bin (Nyquist) is done by threads 0 and 1 in a second round.
+    {
+        double acc[4];
+        auto row_dot = [&](const float *row) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = 0.0;
 #pragma clang loop unroll(disable)
-        for (int n = 0; n < F; ++n) {
-            const double c = (double)br[n], s = (double)bi[n];
+            for (int n0 = 0; n0 < F; n0 += 16) {
+                float w[16];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const double x = ws.xp[m * H + n];
-                re[m] = fma(c, x, re[m]);
-                im[m] = fma(s, x, im[m]);
+                for (int e = 0; e < 16; ++e) w[e] = row[n0 + e];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const double c = (double)w[e];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = fma(c, ws.xp[m * H + n0 + e], acc[m]);
+                }
             }
-        }
+        };
+        double *part_buf = ws.part;
+        const int k = tid >> 1, part = tid & 1;
+        if (k < K - 1) {
+            row_dot(net.basis + (size_t)(part * K + k) * F);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) ws.mag[tid * 4 + m] = sqrt(re[m] * re[m] + im[m] * im[m]);
+            for (int m = 0; m < 4; ++m) part_buf[(part * K + k) * 4 + m] = acc[m];
+        }
+        if (tid < 2) {
+            row_dot(net.basis + (size_t)(tid * K + K - 1) * F);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) part_buf[(tid * K + K - 1) * 4 + m] = acc[m];
+        }
+        __syncthreads();
+        for (int i = tid; i < K * 4; i += 256) {
+            const double re = part_buf[i], im = part_buf[K * 4 + i];
+            ws.mag[i] = sqrt(re * re + im * im);
+        }
     }
     __syncthreads();
     // encoder 0: K -> 128 channels, stride 1, 4 -> 4 frames.  Thread (o, half): frames 2 half, 2 half + 1 of output channel o
@@ -97,9 +129,7 @@ __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, 
         const int o = tid & 127, u0 = 2 * (tid >> 7);
         const float *w = net.ew[0] + (size_t)o * K * 3;
         double acc[2] = {0, 0};
-#pragma clang loop unroll(disable)
-        for (int i = 0; i < K; ++i) {
-            const double w0 = (double)w[3 * i], w1 = (double)w[3 * i + 1], w2 = (double)w[3 * i + 2];
+        auto taps = [&](int i, double w0, double w1, double w2) {
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
                 const int u = u0 + d;
@@ -107,7 +137,17 @@ __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, 
                 acc[d] = fma(w1, ws.mag[i * 4 + u], acc[d]);
                 if (u < 3) acc[d] = fma(w2, ws.mag[i * 4 + u + 1], acc[d]);
             }
+        };
+        static_assert((K - 1) % 4 == 0, "input channels in groups of four, the last one apart");
+#pragma clang loop unroll(disable)
+        for (int i0 = 0; i0 < K - 1; i0 += 4) {
+            float v[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) v[e] = w[3 * i0 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) taps(i0 + e, (double)v[3 * e], (double)v[3 * e + 1], (double)v[3 * e + 2]);
         }
+        taps(K - 1, (double)w[3 * (K - 1)], (double)w[3 * (K - 1) + 1], (double)w[3 * (K - 1) + 2]);
         const double bias = (double)net.eb[0][o];
         ws.e0[o * 4 + u0] = relu_d(acc[0] + bias);
         ws.e0[o * 4 + u0 + 1] = relu_d(acc[1] + bias);
@@ -119,12 +159,18 @@ __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, 
         const float *w = net.ew[1] + (size_t)o * 128 * 3;
         double acc = 0;
 #pragma clang loop unroll(disable)
-        for (int i = 0; i < 128; ++i)
+        for (int i0 = 0; i0 < 128; i0 += 4) {
+            float v[12];
 #pragma unroll
-            for (int tau = 0; tau < 3; ++tau) {
-                const int v = 2 * u + tau - 1;
-                if (v >= 0 && v < 4) acc = fma((double)w[3 * i + tau], ws.e0[i * 4 + v], acc);
-            }
+            for (int e = 0; e < 12; ++e) v[e] = w[3 * i0 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tau = 0; tau < 3; ++tau) {
+                    const int fr = 2 * u + tau - 1;
+                    if (fr >= 0 && fr < 4) acc = fma((double)v[3 * e + tau], ws.e0[(i0 + e) * 4 + fr], acc);
+                }
+        }
         ws.e1[o * 2 + u] = relu_d(acc + (double)net.eb[1][o]);
     }
     __syncthreads();
@@ -133,9 +179,15 @@ __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, 
         const float *w = net.ew[2] + (size_t)tid * 64 * 3;
         double acc = 0;
 #pragma clang loop unroll(disable)
-        for (int i = 0; i < 64; ++i) {
-            acc = fma((double)w[3 * i + 1], ws.e1[i * 2], acc);
-            acc = fma((double)w[3 * i + 2], ws.e1[i * 2 + 1], acc);
+        for (int i0 = 0; i0 < 64; i0 += 4) {
+            float v[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) v[e] = w[3 * i0 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = fma((double)v[3 * e + 1], ws.e1[(i0 + e) * 2], acc);
+                acc = fma((double)v[3 * e + 2], ws.e1[(i0 + e) * 2 + 1], acc);
+            }
         }
         ws.e2[tid] = relu_d(acc + (double)net.eb[2][tid]);
     }
@@ -145,7 +197,13 @@ __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, 
         const float *w = net.ew[3] + (size_t)tid * 64 * 3;
         double acc = 0;
 #pragma clang loop unroll(disable)
-        for (int i = 0; i < 64; ++i) acc = fma((double)w[3 * i + 1], ws.e2[i], acc);
+        for (int i0 = 0; i0 < 64; i0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = w[3 * (i0 + e) + 1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fma((double)v[e], ws.e2[i0 + e], acc);
+        }
         ws.e3[tid] = relu_d(acc + (double)net.eb[3][tid]);
     }
     __syncthreads();
@@ -156,7 +214,13 @@ __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, 
         const float *w = net.w_ih + (size_t)r * 128;
         double acc = 0;
 #pragma clang loop unroll(disable)
-        for (int j = 0; j < 128; ++j) acc = fma((double)w[j], ws.e3[j], acc);
+        for (int j0 = 0; j0 < 128; j0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = w[j0 + e];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc = fma((double)v[e], ws.e3[j0 + e], acc);
+        }
         ws.gx[r] = (float)(acc + (double)net.b_ih[r] + (double)net.b_hh[r]);
     }
     __syncthreads();

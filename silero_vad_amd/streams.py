@@ -1062,23 +1062,38 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
             cnt = cnt_h.numpy()
             segs = seg_h.numpy()
             if len(cnt) and int(cnt.max()) > cap0:                          # rare: a recording with more segments than were copied back
-                c2, s2 = _device_scan(eng, flat_ref[None], meta_d[0], meta_d[1], params, int(cnt.max()), row_offsets=meta_d[2])
-                cnt, segs = c2.cpu().numpy(), s2.cpu().numpy()
+                with torch.cuda.stream(side["stream"]):
+                    c2, s2 = _device_scan(eng, flat_ref[None], meta_d[0], meta_d[1], params, int(cnt.max()), row_offsets=meta_d[2])
+                    cnt, segs = c2.cpu().numpy(), s2.cpu().numpy()
             STATS["d2h_bytes"] += segs.nbytes + cnt.nbytes
             ready.append((idx, cnt.copy(), segs))
 
+    side = {}
+
     def on_slab(k, finished, out_flat, base):
         if len(finished):
+            # The scan of the recordings that retired in this slab runs on a SIDE stream, behind the slab's kernels by event: one lane per
+            # recording walks ~1 000 probabilities one after the other (2-5 ms for the few dozen recordings of a slab) -- on the
+            # compute stream that would stand between this slab's kernels and the next slab's (measured: the leg became compute-bound,
+            # 0.81 of the link); beside them it is one wave.
             t0 = time.perf_counter()
+            dev = out_flat.device
+            cur = torch.cuda.current_stream(dev)
+            if "stream" not in side:
+                side["stream"] = torch.cuda.Stream(dev)
+            done_k = torch.cuda.Event()
+            done_k.record(cur)
+            side["stream"].wait_event(done_k)
             nck = base[finished + 1] - base[finished]
-            meta = torch.from_numpy(np.stack([nck, lengths[finished], base[finished]])).pin_memory().to(out_flat.device, non_blocking=True)
-            counts, segs = _device_scan(eng, out_flat[None], meta[0], meta[1], params, cap0, row_offsets=meta[2])
-            cnt_h = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
-            seg_h = torch.empty(segs.shape, dtype=segs.dtype, pin_memory=True)
-            cnt_h.copy_(counts, non_blocking=True)
-            seg_h.copy_(segs, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(out_flat.device))
+            with torch.cuda.stream(side["stream"]):
+                meta = torch.from_numpy(np.stack([nck, lengths[finished], base[finished]])).pin_memory().to(dev, non_blocking=True)
+                counts, segs = _device_scan(eng, out_flat[None], meta[0], meta[1], params, cap0, row_offsets=meta[2])
+                cnt_h = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+                seg_h = torch.empty(segs.shape, dtype=segs.dtype, pin_memory=True)
+                cnt_h.copy_(counts, non_blocking=True)
+                seg_h.copy_(segs, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side["stream"])
             pending.append((finished.copy(), cnt_h, seg_h, ev, out_flat, meta))
             STATS["scan_s"] += time.perf_counter() - t0
         collect(False)
@@ -1089,6 +1104,8 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
     collect(True)
     while ready:
         yield ready.pop(0)
+    if "stream" in side:                                                  # later work on the caller's stream is ordered behind the scans
+        torch.cuda.current_stream().wait_stream(side["stream"])
     empty = np.flatnonzero(lengths <= 0)
     if len(empty):
         yield empty.astype(np.int64), np.zeros(len(empty), dtype=np.int64), np.zeros((len(empty), 1, 2), dtype=np.int64)

@@ -2822,8 +2822,11 @@ def test_refill_results_arrive_as_recordings_retire(model, golden, tag):
     rng = np.random.default_rng(8)
     lens = rng.integers(3 * n, 60 * n, size=60)
     lens[7] = 0                                                    # an empty recording
-    lens[11] = min(len(wav) - 1000, 1700 * n)                      # a long one: with min_silence 0 it has more than 32 segments
     audios = [torch.from_numpy(np.roll(wav, -int(rng.integers(0, len(wav))))[:m].copy()) for m in lens]
+    # a long one with more than 32 segments (the optimistic copy holds 32): bursts of speech between stretches of silence
+    burst = [np.concatenate([wav[(40 + 9 * i) * n:(46 + 9 * i) * n], np.zeros(6 * n, np.float32)]) for i in range(60)]
+    audios[11] = torch.from_numpy(np.concatenate(burst))
+    lens[11] = len(audios[11])
     kw = dict(threshold=0.4, min_silence_duration_ms=0, min_speech_duration_ms=32, speech_pad_ms=0)
     want = ragged_speech_segments(audios, model, sr, **kw)
     seen, order, n_batches = {}, [], 0
