@@ -378,6 +378,11 @@ int  vad_upload_rows(vad_engine *e, const void *const *rows, const long *lens, l
 int  vad_host_register(void *p, size_t bytes);
 int  vad_host_unregister(void *p);
 
+/* The continuous-refill schedule of silero_vad_amd/streams.py RefillPlan (the reference's padded lock-step batch, tuning/utils.py:146-160,
+ * with rows retired and re-admitted): recording q (in admission order) occupies a stream slot for need[q] time slabs; at every slab
+ * boundary every free slot, lowest first, takes the next recording.  Writes the slab at which q is admitted and its slot.  Host only. */
+int  vad_refill_schedule(const long *need, long n, long slots, long *start, long *slot);
+
 /* Do two streams of the engine's device run BESIDE each other?  The HIP runtime maps streams onto a handful of hardware queues
  * (GPU_MAX_HW_QUEUES, 4 by default; which stream lands where depends on the order in which the process' streams were first
  * used), and two streams on one queue execute their kernels one after the other whatever the events say.  A pipeline that wants

@@ -847,20 +847,17 @@ class RefillPlan:
             raise ValueError("slots and slab_chunks must be positive")
         width = self.slab_chunks * self.chunk
         lens = np.asarray(self.lengths, dtype=np.int64)
-        queue = np.asarray(sorted((i for i, n in enumerate(self.lengths) if n > 0), key=lambda i: -self.lengths[i]),
-                           dtype=np.int64)
-        self.empty = [i for i, n in enumerate(self.lengths) if n <= 0]
-        need = (lens[queue] + width - 1) // width            # slabs each recording occupies its slot for
-        # event-driven form of "at every slab boundary, every free slot (in slot order) takes the next recording":
-        # a heap of (slab at which the slot becomes free, slot)
-        import heapq
-        free = [(0, sl) for sl in range(self.slots)]
+        live = np.flatnonzero(lens > 0)
+        queue = live[np.argsort(-lens[live], kind="stable")]  # longest first, ties in input order
+        self.empty = np.flatnonzero(lens <= 0).tolist()
+        need = np.ascontiguousarray((lens[queue] + width - 1) // width)   # slabs each recording occupies its slot for
+        # event-driven form of "at every slab boundary, every free slot (in slot order) takes the next recording": a heap of (slab at
+        # which the slot becomes free, slot) -- native (vad_refill_schedule: a corpus shard has 10^5 recordings)
         start = np.zeros(len(queue), dtype=np.int64)
         slot = np.zeros(len(queue), dtype=np.int64)
-        for q in range(len(queue)):
-            t, sl = heapq.heappop(free)
-            start[q], slot[q] = t, sl
-            heapq.heappush(free, (t + int(need[q]), sl))
+        lp = ctypes.POINTER(ctypes.c_long)
+        if lib().vad_refill_schedule(need.ctypes.data_as(lp), len(queue), self.slots, start.ctypes.data_as(lp), slot.ctypes.data_as(lp)):
+            raise ValueError("vad_refill_schedule: bad arguments")
         # one row per (recording, slab it is active in): [slot, recording, first sample, samples, reset]
         reps = np.repeat(np.arange(len(queue)), need)
         j = np.arange(len(reps)) - np.repeat(np.cumsum(need) - need, need)          # 0 .. need-1 within a recording
@@ -895,6 +892,7 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
     ENQUEUED.  `on_slab(k, finished, out_flat, base)` is called right before that, with the recordings whose last chunk lies in slab k
     (np.int64 array, may be empty): the hook for work that follows a recording's retirement in stream order.  The generator's return
     value is (out_flat, base, plan)."""
+    t_setup = time.perf_counter()
     net_sr, _, n = _rates(sampling_rate)
     eng = model.engine
     dev = torch.device(getattr(eng, "torch_device", None) or torch.device("cuda", eng.device))
@@ -982,6 +980,7 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
             return d, ev, i, m_d[: B * S], m_d[B * S:]
 
         n_slabs = len(plan.slab_arrays)
+        STATS["setup_s"] += time.perf_counter() - t_setup
         staged = stage(0) if n_slabs else None
         for k in range(n_slabs):
             x, ev, slot, idx, rs = staged
@@ -1057,10 +1056,11 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
 
     def collect(block):
         while pending and (block or pending[0][3].query()):
-            idx, cnt_h, seg_h, ev, flat_ref, meta_d = pending.popleft()
+            idx, bufs, m, ev, flat_ref, meta_d = pending.popleft()
             ev.synchronize()
-            cnt = cnt_h.numpy()
-            segs = seg_h.numpy()
+            cnt = bufs[1][:m].numpy().copy()
+            segs = bufs[2][:m].numpy().copy()
+            side["free"].append(bufs)
             if len(cnt) and int(cnt.max()) > cap0:                          # rare: a recording with more segments than were copied back
                 with torch.cuda.stream(side["stream"]):
                     c2, s2 = _device_scan(eng, flat_ref[None], meta_d[0], meta_d[1], params, int(cnt.max()), row_offsets=meta_d[2])
@@ -1068,7 +1068,20 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
             STATS["d2h_bytes"] += segs.nbytes + cnt.nbytes
             ready.append((idx, cnt.copy(), segs))
 
-    side = {}
+    side = {"free": []}                                                  # page-locked result buffers, recycled (a pinned allocation per
+                                                                          # slab costs milliseconds and can wait for the device)
+
+    def pinned_set(m):
+        """(meta int64[3, m], counts int64[m], segs int64[m, cap0, 2]) in page-locked memory, from the free list when one is big enough"""
+        for i, bufs in enumerate(side["free"]):
+            if bufs[0].shape[1] >= m:
+                side["free"].pop(i)
+                break
+        else:
+            cap = max(64, 1 << int(np.ceil(np.log2(max(m, 1)))))
+            bufs = (torch.empty((3, cap), dtype=torch.int64, pin_memory=True), torch.empty((cap,), dtype=torch.int64, pin_memory=True),
+                    torch.empty((cap, cap0, 2), dtype=torch.int64, pin_memory=True))
+        return bufs
 
     def on_slab(k, finished, out_flat, base):
         if len(finished):
@@ -1084,17 +1097,19 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
             done_k = torch.cuda.Event()
             done_k.record(cur)
             side["stream"].wait_event(done_k)
-            nck = base[finished + 1] - base[finished]
+            m = len(finished)
+            bufs = pinned_set(m)
+            bufs[0][0, :m] = torch.from_numpy(base[finished + 1] - base[finished])
+            bufs[0][1, :m] = torch.from_numpy(lengths[finished])
+            bufs[0][2, :m] = torch.from_numpy(base[finished])
             with torch.cuda.stream(side["stream"]):
-                meta = torch.from_numpy(np.stack([nck, lengths[finished], base[finished]])).pin_memory().to(dev, non_blocking=True)
+                meta = bufs[0][:, :m].to(dev, non_blocking=True)
                 counts, segs = _device_scan(eng, out_flat[None], meta[0], meta[1], params, cap0, row_offsets=meta[2])
-                cnt_h = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
-                seg_h = torch.empty(segs.shape, dtype=segs.dtype, pin_memory=True)
-                cnt_h.copy_(counts, non_blocking=True)
-                seg_h.copy_(segs, non_blocking=True)
+                bufs[1][:m].copy_(counts, non_blocking=True)
+                bufs[2][:m].copy_(segs, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(side["stream"])
-            pending.append((finished.copy(), cnt_h, seg_h, ev, out_flat, meta))
+            pending.append((finished.copy(), bufs, m, ev, out_flat, meta))
             STATS["scan_s"] += time.perf_counter() - t0
         collect(False)
 
