@@ -914,6 +914,8 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
     if os.environ.get("VAD_BENCH_CORPUS_PRELEG"):               # diagnostic: one short leg BEFORE the main one (order dependence)
         pre = os.environ["VAD_BENCH_CORPUS_PRELEG"]
         legs[f"pre_{pre}"], _ = run_leg(base_i, "buckets", pre, short, False)
+    if os.environ.get("VAD_BENCH_REFILL_FIRST"):               # diagnostic: the refill leg before anything else has run (order dependence)
+        legs["pre_refill"], _ = run_leg(base_i, "refill", "gather", min(len(lens), 18 * R), False)
     legs["main"], res = run_leg(base_i, "buckets", main_mode, len(lens), True)
     parity = None
     if not args.no_parity:

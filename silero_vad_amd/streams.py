@@ -36,6 +36,7 @@ from ._lib import lib
 # stage_s host packing into pinned memory, h2d_bytes / h2d_s the H2D copies themselves (hipEvents on the copy
 # stream), scan_s the native segmenter, buckets, padded / real samples staged.
 STATS = collections.defaultdict(float)
+TRACE = None             # bring-up: set to a list to collect (slab, t before on_slab, t after, t after stage) from the refill loop
 
 
 def chunk_size(sr: int) -> int:
@@ -146,19 +147,27 @@ def _distinct_queue_stream(engine, device, others, tries=12):
     """A torch stream whose kernels demonstrably run BESIDE those of every stream in `others` (vad_streams_overlap).  torch hands out
     streams from a pool, the HIP runtime maps them onto ~4 hardware queues in the order of their first use, and two streams on one
     queue serialise: an upload kernel that lands on a compute lane's queue alternates with the lane instead of overlapping it -- the
-    scattered-pinned routes then read half the link (profiles/r05_ingest_queues.md).  Candidates that collide are kept alive until the
-    search is over (a dropped one would be handed out again) and then returned to the pool."""
-    rejected = []
+    scattered-pinned routes then read half the link (profiles/r05_ingest_queues.md).  torch's pool hands its streams out round-robin
+    whatever is still alive, so the search simply asks for the next one; every candidate, the last one included, is probed, and when
+    none of `tries` candidates runs beside all of `others` the best one found is returned and STATS["stream_collisions"] says so (the
+    caller's pipeline is then correct but partly serial).  The probe synchronises the streams involved (~1 ms per pair): it is skipped
+    -- a plain new stream is returned -- while the current stream is being captured into a graph."""
     st = torch.cuda.Stream(device)
-    if engine is None or not hasattr(engine, "streams_overlap"):
+    if engine is None or not hasattr(engine, "streams_overlap") or torch.cuda.is_current_stream_capturing():
         return st
-    for _ in range(tries):
-        if all(engine.streams_overlap(o, st) for o in others):
+    best, best_hits = st, -1
+    for k in range(tries):
+        hits = sum(1 for o in others if engine.streams_overlap(o, st))
+        if hits > best_hits:
+            best, best_hits = st, hits
+        if hits == len(others):
             break
-        rejected.append(st)
-        st = torch.cuda.Stream(device)
-    STATS["stream_retries"] += len(rejected)
-    return st
+        STATS["stream_retries"] += 1
+        if k + 1 < tries:
+            st = torch.cuda.Stream(device)
+    if best_hits < len(others):
+        STATS["stream_collisions"] += 1
+    return best
 
 
 def _compute_lanes(model, want):
@@ -996,10 +1005,14 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
             if on_gpu:
                 pool.consumed[slot] = torch.cuda.Event()
                 pool.consumed[slot].record(cur)
+            t_a = time.perf_counter()
             if on_slab is not None:
                 e = plan.slab_arrays[k]
                 on_slab(k, e[e[:, 2] + e[:, 3] >= lens_np[e[:, 1]], 1], out_flat, base)
+            t_b = time.perf_counter()
             staged = stage(k + 1) if k + 1 < n_slabs else None          # CPU packs k+1 meanwhile
+            if TRACE is not None:
+                TRACE.append((k, t_a, t_b, time.perf_counter()))
             yield k
     return out_flat, base, plan
 
@@ -1093,7 +1106,11 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
             dev = out_flat.device
             cur = torch.cuda.current_stream(dev)
             if "stream" not in side:
-                side["stream"] = torch.cuda.Stream(dev)
+                # (on a hardware queue of its own: a scan that lands on the upload's or the compute stream's queue serialises with it
+                #  -- measured as 3.4 ms holes in the upload stream every time a wave of recordings retires, 0.79 instead of 0.90 of
+                #  the link, depending on which streams the process happened to create before)
+                pool = getattr(model, "_stage_pool", None)
+                side["stream"] = _distinct_queue_stream(eng, dev, [cur] + ([pool.stream] if pool is not None else []))
             done_k = torch.cuda.Event()
             done_k.record(cur)
             side["stream"].wait_event(done_k)
