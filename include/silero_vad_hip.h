@@ -133,7 +133,8 @@ int  vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ct
  * `stream` (record an event behind the call and wait for it before reading host_prob).  May be issued inside a stream capture: the
  * three operations then become one hipGraph (what StreamPool replays per tick).
  *   host_pcm   host [B][N], PAGE-LOCKED; elem_size 2 = int16 (scaled by 1/32768 in the kernel's loads), 4 = fp32
- *   dev_pcm    dev  [B][N] of the same element type: staging the caller owns (16-byte aligned)
+ *   dev_pcm    dev  [B][N] of the same element type: staging the caller owns (16-byte aligned); or NULL: no copy -- the kernel reads
+ *              host_pcm through the device's view of it (for a handful of streams: a B = 1 call is 2 KB)
  *   dev_prob   dev  [B], or NULL: the kernel then stores the probabilities straight into host_prob (no device copy, no D2H operation)
  *   host_prob  host [B], page-locked                                                                                            */
 int  vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, void *dev_pcm, float *ctx, float *state,

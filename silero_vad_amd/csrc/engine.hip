@@ -684,7 +684,7 @@ int vad_step_host_present(vad_engine *e, int sr, int B, const void *host_pcm, si
     if (e->host_only) return fail(e, VAD_ERR_NO_DEVICE, "host-only engine");
     const int ni = net_index(sr);
     if (ni < 0) return fail(e, VAD_ERR_SAMPLE_RATE, "Supported sampling rates: [8000, 16000]");
-    if (B < 0 || (elem_size != 2 && elem_size != 4) || (B > 0 && (!host_pcm || !dev_pcm || !ctx || !state || !host_prob)) ||
+    if (B < 0 || (elem_size != 2 && elem_size != 4) || (B > 0 && (!host_pcm || !ctx || !state || !host_prob)) ||
         (host_present && !dev_present))
         return fail(e, VAD_ERR_ARG, "bad argument");
     if (host_present && e->impl_reference) return fail(e, VAD_ERR_OPTION, "impl=reference has no present[] form");
@@ -703,7 +703,19 @@ int vad_step_host_present(vad_engine *e, int sr, int B, const void *host_pcm, si
         }
         out = static_cast<float *>(dv);
     }
-    HIP_TRY(e, hipMemcpyAsync(dev_pcm, host_pcm, (size_t)B * N * elem_size, hipMemcpyHostToDevice, stream));
+    if (dev_pcm) {
+        HIP_TRY(e, hipMemcpyAsync(dev_pcm, host_pcm, (size_t)B * N * elem_size, hipMemcpyHostToDevice, stream));
+    } else {
+        // dev_pcm == NULL: the kernel reads the chunks where they lie, through the device's view of the page-locked host buffer -- no copy
+        // operation at all.  Right for a handful of streams (a B = 1 model call moves 2 KB: the copy engine's setup costs more than the
+        // read), wrong for thousands (every lane's load would be a PCIe round trip).
+        void *dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, const_cast<void *>(host_pcm), 0) != hipSuccess || !dv) {
+            (void)hipGetLastError();
+            return fail(e, VAD_ERR_ARG, "vad_step_host: host_pcm is not page-locked memory the runtime knows");
+        }
+        dev_pcm = dv;
+    }
     int rc;
     if (host_present) {
         HIP_TRY(e, hipMemcpyAsync(dev_present, host_present, (size_t)B, hipMemcpyHostToDevice, stream));

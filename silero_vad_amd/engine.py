@@ -160,7 +160,10 @@ class Engine:
         B = host_pcm.shape[0]
         s = self._stream() if stream is None else ctypes.c_void_p(stream)
         dp = None if dev_prob is None else dev_prob.data_ptr()
-        if host_present is None:
+        if dev_pcm is None:         # no staging copy: the kernel reads the page-locked chunks where they lie (a handful of streams)
+            self._check(self._L.vad_step_host(self._h, sr, B, host_pcm.data_ptr(), host_pcm.element_size(), None,
+                                              ctx.data_ptr(), state.data_ptr(), dp, host_prob.data_ptr(), s))
+        elif host_present is None:
             self._check(self._L.vad_step_host(self._h, sr, B, host_pcm.data_ptr(), host_pcm.element_size(), dev_pcm.data_ptr(),
                                               ctx.data_ptr(), state.data_ptr(), dp, host_prob.data_ptr(), s))
         else:
@@ -201,6 +204,7 @@ class HipSileroVAD:
         self.precision = "fp32"
         self.device = getattr(self.engine, "torch_device", None) or torch.device("cuda", self.engine.device)
         self.sample_rates = [8000, 16000]
+        self._small = None           # page-locked (chunk, probability) buffers of the B <= 16 call path (__call__)
         self.reset_states()
 
     def _device_ctx(self):
@@ -286,6 +290,22 @@ class HipSileroVAD:
             raise ValueError(_MSG_SAMPLES.format(n_net))
         batch_size = x.shape[0]
         self._ensure_state(sr, batch_size)
+        if home.type == "cpu" and self.device.type == "cuda" and sr_raw == sr and batch_size <= 16 and hasattr(self.engine, "_h"):
+            # What every unmodified caller does -- `model(chunk, sr).item()` on a CPU chunk, once per 32 ms (src/silero_vad/utils_vad.py:
+            # 324-336, :528): the chunk is copied (2 KB) into the model's own page-locked buffer, ONE launch reads it from there and writes
+            # the probability into page-locked memory, one stream wait.  No H2D operation, no D2H operation, no device tensor made.
+            sm = self._small
+            if sm is None or sm[0].shape[1] != num_samples or sm[0].dtype != (torch.int16 if x.dtype == torch.int16 else torch.float32):
+                sm = self._small = (torch.empty((16, num_samples), dtype=torch.int16 if x.dtype == torch.int16 else torch.float32, pin_memory=True),
+                                    torch.empty((16,), dtype=torch.float32, pin_memory=True))
+            pcm, prob = sm[0][:batch_size], sm[1][:batch_size]
+            pcm.copy_(x)
+            stream = torch.cuda.current_stream(self.device)
+            self.engine.step_host(pcm, None, sr, self._context, self._state, None, prob, stream.cuda_stream)
+            stream.synchronize()
+            self._last_sr = sr
+            self._last_batch_size = batch_size
+            return prob.clone().unsqueeze(1)
         with self._device_ctx():
             xd = self._to_device(x)
             if xd.dtype == torch.int16:
