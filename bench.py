@@ -925,8 +925,9 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
             if other != main_mode:
                 legs[f"pinned_{other}"], _ = run_leg(base_i, "buckets", other, short, False)
         legs["pageable_staged"], _ = run_leg(base_i_page, "buckets", "stage", short, False)
-        # (18 passes: recordings are admitted longest first, so the first ones retire ten slabs in -- 4 % of this leg, 2 % of a full shard)
-        legs["pinned_refill_gather"], _ = run_leg(base_i, "refill", "gather", min(len(lens), 18 * R), False)
+        # (the whole shard: recordings are admitted longest first, so the first ones retire ten slabs in -- 2-3 % of a full shard's wall time,
+        #  setup included; on six passes that would be 11 %)
+        legs["pinned_refill_gather"], _ = run_leg(base_i, "refill", "gather", len(lens), False)
     os.environ.pop("SILERO_VAD_AMD_UPLOAD", None)
     # what the link allows: the H2D rate measured while copying / bytes per chunk -- a leg's value can approach it (fully
     # overlapped pipeline), never exceed it

@@ -113,6 +113,11 @@ struct vad_engine {
     hipStream_t dma_stream[kDmaStreams] = {};
     hipEvent_t dma_fork = nullptr, dma_join[kDmaStreams] = {};
 
+    // vad_step_host: the device's view of the caller's page-locked buffers, remembered (a B = 1 caller hands over the same two buffers
+    // 30 times a second for hours; resolving one costs a runtime call)
+    const void *map_host[2] = {nullptr, nullptr};
+    void *map_dev[2] = {nullptr, nullptr};
+
     // profiling: 3 events per (call, slab), read back lazily by vad_kernel_times
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -694,14 +699,21 @@ int vad_step_host_present(vad_engine *e, int sr, int B, const void *host_pcm, si
     HIP_TRY(e, hipSetDevice(e->device));
     // dev_prob == NULL: the kernel stores the B probabilities straight into the page-locked host buffer (4 B per stream over the link,
     // visible to the host once the stream has passed the call) -- no device buffer, no second copy
+    auto mapped = [&](int k, const void *hp) -> void * {
+        if (e->map_host[k] == hp && e->map_dev[k]) return e->map_dev[k];
+        void *dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, const_cast<void *>(hp), 0) != hipSuccess || !dv) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        e->map_host[k] = hp;
+        e->map_dev[k] = dv;
+        return dv;
+    };
     float *out = dev_prob;
     if (!out) {
-        void *dv = nullptr;
-        if (hipHostGetDevicePointer(&dv, host_prob, 0) != hipSuccess || !dv) {
-            (void)hipGetLastError();
-            return fail(e, VAD_ERR_ARG, "vad_step_host: host_prob is not page-locked memory the runtime knows");
-        }
-        out = static_cast<float *>(dv);
+        out = static_cast<float *>(mapped(0, host_prob));
+        if (!out) return fail(e, VAD_ERR_ARG, "vad_step_host: host_prob is not page-locked memory the runtime knows");
     }
     if (dev_pcm) {
         HIP_TRY(e, hipMemcpyAsync(dev_pcm, host_pcm, (size_t)B * N * elem_size, hipMemcpyHostToDevice, stream));
@@ -709,12 +721,8 @@ int vad_step_host_present(vad_engine *e, int sr, int B, const void *host_pcm, si
         // dev_pcm == NULL: the kernel reads the chunks where they lie, through the device's view of the page-locked host buffer -- no copy
         // operation at all.  Right for a handful of streams (a B = 1 model call moves 2 KB: the copy engine's setup costs more than the
         // read), wrong for thousands (every lane's load would be a PCIe round trip).
-        void *dv = nullptr;
-        if (hipHostGetDevicePointer(&dv, const_cast<void *>(host_pcm), 0) != hipSuccess || !dv) {
-            (void)hipGetLastError();
-            return fail(e, VAD_ERR_ARG, "vad_step_host: host_pcm is not page-locked memory the runtime knows");
-        }
-        dev_pcm = dv;
+        dev_pcm = mapped(1, host_pcm);
+        if (!dev_pcm) return fail(e, VAD_ERR_ARG, "vad_step_host: host_pcm is not page-locked memory the runtime knows");
     }
     int rc;
     if (host_present) {

@@ -295,13 +295,22 @@ class HipSileroVAD:
             # 324-336, :528): the chunk is copied (2 KB) into the model's own page-locked buffer, ONE launch reads it from there and writes
             # the probability into page-locked memory, one stream wait.  No H2D operation, no D2H operation, no device tensor made.
             sm = self._small
-            if sm is None or sm[0].shape[1] != num_samples or sm[0].dtype != (torch.int16 if x.dtype == torch.int16 else torch.float32):
-                sm = self._small = (torch.empty((16, num_samples), dtype=torch.int16 if x.dtype == torch.int16 else torch.float32, pin_memory=True),
-                                    torch.empty((16,), dtype=torch.float32, pin_memory=True))
-            pcm, prob = sm[0][:batch_size], sm[1][:batch_size]
+            dt = torch.int16 if x.dtype == torch.int16 else torch.float32
+            if sm is None or sm[2] != (num_samples, dt, batch_size):
+                # (buffers of 16 rows, views of the caller's batch size: made once per (rate, dtype, B), not per call)
+                if sm is None or sm[2][:2] != (num_samples, dt):
+                    full = (torch.empty((16, num_samples), dtype=dt, pin_memory=True), torch.empty((16,), dtype=torch.float32, pin_memory=True))
+                else:
+                    full = sm[3]
+                sm = self._small = (full[0][:batch_size], full[1][:batch_size], (num_samples, dt, batch_size), full)
+            pcm, prob = sm[0], sm[1]
             pcm.copy_(x)
             stream = torch.cuda.current_stream(self.device)
-            self.engine.step_host(pcm, None, sr, self._context, self._state, None, prob, stream.cuda_stream)
+            eng = self.engine
+            rc = eng._L.vad_step_host(eng._h, sr, batch_size, pcm.data_ptr(), pcm.element_size(), None, self._context.data_ptr(),
+                                      self._state.data_ptr(), None, prob.data_ptr(), ctypes.c_void_p(stream.cuda_stream))
+            if rc:
+                eng._check(rc)
             stream.synchronize()
             self._last_sr = sr
             self._last_batch_size = batch_size

@@ -2011,6 +2011,20 @@ def test_small_batch_recurrence_is_bit_identical(model, oracle, golden, tag):
         x16 = torch.from_numpy((rows * 32768.0).clip(-32768, 32767).astype(np.int16))
         (q1, _, t1), (q2, _, t2) = both(lambda: run_engine(model, x16, sr))
         assert np.array_equal(q1, q2) and np.array_equal(t1, t2)
+    # ARBITRARY caller-supplied (h, c) at large B (advisor r05: the bound for states a caller hands over, not only for states the network
+    # produced): random states of the size the network's own states have (|h| < 1 as o * tanh(c) makes it, c ~ N(0, 0.5)), B = 257 and
+    # 1 025 -- both forms identical bits; against float64 the engine inside the contract or within 1.5 x the oracle
+    for B, T in ((257, 5), (1025, 3)):
+        rows = rolled_rows(g["wav"], B, T * n, 4001)
+        c0 = (0.5 * rng.standard_normal((B, 128))).astype(np.float32)
+        h0 = (np.tanh(c0) * rng.uniform(0.05, 0.95, (B, 128))).astype(np.float32)
+        st0 = np.stack([h0, c0])
+        ctx0 = (0.1 * rng.standard_normal((B, n // 8))).astype(np.float32)
+        (p1, c1, s1), (p2, c2, s2) = both(lambda: run_engine(model, rows, sr, state=st0, ctx=ctx0))
+        assert np.array_equal(p1, p2) and np.array_equal(s1, s2)
+        want, _, wst = oracle.forward_audio(rows, sr, state=st0, ctx=ctx0)
+        assert np.abs(p2 - want).max() < TIGHT
+        state_vs_float64(model, rows, sr, s2, wst, state=st0, ctx=ctx0, label=f"{tag} B={B} T={T} random caller-supplied state", record=rec64)
     _dump_state_rows(rec64, f"small_batch_recurrence_{tag}")
     # time slabs (a scratch cap that cuts the 300 steps into pieces) are transparent to it too
     rows = rolled_rows(g["wav"], 1, 300 * n, 977)
