@@ -45,6 +45,7 @@
 #include <atomic>
 #include <chrono>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -129,7 +130,11 @@ __attribute__((target("avx2"))) inline void stream_copy_avx2(void *dst, const vo
     for (size_t i = 0; i < bytes / 32; ++i) _mm256_stream_si256(d + i, _mm256_loadu_si256(s + i));
 }
 inline bool have_avx2() {
-    static const bool v = __builtin_cpu_supports("avx2");
+    static const bool v = __builtin_cpu_supports("avx2") && !std::getenv("SILERO_VAD_AMD_PUMP_SSE2");     // (A/B knob)
+    return v;
+}
+inline bool want_prefetch() {
+    static const bool v = !std::getenv("SILERO_VAD_AMD_PUMP_NO_PREFETCH");                                    // (A/B knob)
     return v;
 }
 #endif
@@ -137,7 +142,7 @@ inline bool have_avx2() {
 // its lines are requested while this row is being written
 inline void stream_copy(void *dst, const void *src, size_t bytes, const void *next = nullptr) {
 #if defined(__x86_64__)
-    if (next)
+    if (next && want_prefetch())
         for (size_t o = 0; o < bytes; o += 64) _mm_prefetch(static_cast<const char *>(next) + o, _MM_HINT_NTA);
     if (have_avx2() && bytes % 32 == 0 && (reinterpret_cast<size_t>(dst) & 31) == 0) return stream_copy_avx2(dst, src, bytes);
     const __m128i *s = static_cast<const __m128i *>(src);
@@ -161,15 +166,21 @@ inline void stream_fence() {
 struct Gate {
     std::atomic<uint32_t> seq{0};
     std::atomic<int> sleepers{0};
-    static constexpr double kSpinMs = 0.020;
+    static double spin_ms() {
+        static const double v = [] {
+            const char *s = std::getenv("SILERO_VAD_AMD_PUMP_SPIN_US");                                       // (A/B knob)
+            return s ? std::atof(s) * 1e-3 : 0.020;
+        }();
+        return v;
+    }
 
     template <class Cond>
     void wait(Cond cond) {
-        const double t0 = now_ms();
+        const double t0 = now_ms(), limit = spin_ms();
         for (int i = 0;; ++i) {
             if (cond()) return;
             cpu_relax();
-            if ((i & 63) == 63 && now_ms() - t0 > kSpinMs) break;
+            if ((i & 63) == 63 && now_ms() - t0 > limit) break;
         }
         for (;;) {
             sleepers.fetch_add(1, std::memory_order_seq_cst);

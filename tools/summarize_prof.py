@@ -17,7 +17,7 @@ from pathlib import Path
 
 def short(name):
     for key in ("front_f43_kernel", "front_lat_kernel", "front_b9_kernel", "rec_b9_kernel", "front_wino_kernel", "front_kernel", "rec_kernel", "rec_skew_kernel", "ref_forward_kernel",
-                "gather_rows_kernel", "scan_kernel", "unpack_gx"):
+                "gather_rows_kernel", "scan_kernel", "unpack_gx", "exact_fix_kernel", "carry_absent_kernel"):
         if key in name:
             return name[name.index(key):].split("(")[0]
     return None
