@@ -4,10 +4,12 @@
  * header must be valid C and every entry point it uses must resolve); on a GPU box tests/test_gpu_parity.py also runs it: it streams
  * int16 chunks of `pcm_file` through vad_step_host (page-locked buffers from vad_host_register) and vad_iterator_feed and prints the
  * probabilities and events, which the test compares with the Python path's.
- *     client <weights> <pcm_int16_file> <sr> <streams> [pump]
+ *     client <weights> <pcm_int16_file> <sr> <streams> [pump | gaps]
  * With `pump` the same loop runs on the native pump (vad_pump_create / slot / submit / poll / probs): the client writes the chunks into
  * the pump's page-locked ring, keeps two ticks in flight and prints each tick's probabilities and events as it is retired -- no HIP
- * call of its own at all.                                                                                                       */
+ * call of its own at all.  With `gaps` the streams do not arrive in lock step: stream b has no chunk at tick t when
+ * (7 t + 13 b) % 10 == 0, the client sets its flag to 0 (vad_pump_present / vad_pump_submit_present) and the stream's audio waits for
+ * its next tick -- what a caller of the reference does by not calling its model (src/silero_vad/utils_vad.py:507-549).            */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,10 +32,11 @@ static void *dev_zeros(size_t bytes) {
 }
 
 /* the pump route: stream b plays the recording from offset b * 7919 (circular), two ticks in flight */
-static int run_pump(vad_engine *e, const int16_t *pcm, long samples, int sr, int B, int N, long T) {
+static int run_pump(vad_engine *e, const int16_t *pcm, long samples, int sr, int B, int N, long T, int gaps) {
     vad_pump_params prm;
     vad_pump *p = NULL;
     vad_iter_event *ev = (vad_iter_event *)calloc((size_t)B, sizeof(vad_iter_event));
+    long *delivered = (long *)calloc((size_t)B, sizeof(long));      /* chunks stream b has handed over so far */
     long t, done = 0;
     int rc, R = 0;
     vad_pump_params_default(&prm, sr, B);
@@ -47,10 +50,15 @@ static int run_pump(vad_engine *e, const int16_t *pcm, long samples, int sr, int
     for (t = 0; t <= T; ++t) {
         if (t < T) {
             int16_t *slot = vad_pump_slot(p, (int)(t % R));
+            uint8_t *flags = vad_pump_present(p, (int)(t % R));
             int b, i;
-            for (b = 0; b < B; ++b)
-                for (i = 0; i < N; ++i) slot[(size_t)b * N + i] = pcm[((long)b * 7919 + t * N + i) % samples];
-            if ((rc = vad_pump_submit(p, (int)(t % R))) != VAD_OK) {
+            for (b = 0; b < B; ++b) {
+                flags[b] = (uint8_t)!(gaps && (7 * t + 13 * b) % 10 == 0);
+                if (!flags[b]) continue;                     /* no chunk this tick: the slot keeps whatever it holds */
+                for (i = 0; i < N; ++i) slot[(size_t)b * N + i] = pcm[((long)b * 7919 + delivered[b] * N + i) % samples];
+                ++delivered[b];
+            }
+            if ((rc = gaps ? vad_pump_submit_present(p, (int)(t % R), flags) : vad_pump_submit(p, (int)(t % R))) != VAD_OK) {
                 fprintf(stderr, "vad_pump_submit: %s\n", vad_pump_last_error(p));
                 return 1;
             }
@@ -75,6 +83,7 @@ static int run_pump(vad_engine *e, const int16_t *pcm, long samples, int sr, int
     if (vad_pump_poll(p, 1, ev, B, NULL) != VAD_PUMP_IDLE) return 1;
     vad_pump_destroy(p);
     free(ev);
+    free(delivered);
     return 0;
 }
 
@@ -111,8 +120,8 @@ int main(int argc, char **argv) {
     if (fread(pcm, 2, (size_t)samples, f) != (size_t)samples) return 66;
     fclose(f);
     const long T = samples / N;
-    if (argc > 5 && strcmp(argv[5], "pump") == 0) {
-        rc = run_pump(e, pcm, samples, sr, B, N, T);
+    if (argc > 5 && (strcmp(argv[5], "pump") == 0 || strcmp(argv[5], "gaps") == 0)) {
+        rc = run_pump(e, pcm, samples, sr, B, N, T, strcmp(argv[5], "gaps") == 0);
         vad_destroy(e);
         return rc;
     }

@@ -562,6 +562,45 @@ def test_plain_c_client_streams_chunks_to_events(model, golden, tag, route, tmp_
         assert np.abs(probs[:T].T - want).max() < TIGHT
 
 
+def test_plain_c_client_with_streams_that_miss_ticks(model, golden, tmp_path):
+    """The same C99 client with `gaps`: stream b has no chunk at tick t when (7 t + 13 b) % 10 == 0 -- it clears the stream's flag in
+    vad_pump_present and submits with vad_pump_submit_present.  Every stream's delivered chunks give the probabilities of its own
+    gap-free audio bit for bit (the engine's [B, T] entry on each stream's own chunk sequence), its slot reads -1 at the ticks it
+    missed, and its events EQUAL a per-stream VADIterator over the B = 1 model fed only its own chunks."""
+    import subprocess
+    from test_abi import build_c_client
+    from silero_vad_amd import VADIterator, _lib
+    sr, g = 16000, golden["16k"]
+    n, B = 512, 3
+    pcm = g["pcm_i16"]
+    raw = tmp_path / "pcm.raw"
+    pcm.tofile(raw)
+    exe = build_c_client(tmp_path)
+    T = len(pcm) // n
+    r = subprocess.run([str(exe), str(_lib.WEIGHTS_PATH), str(raw), str(sr), str(B), "gaps"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    probs = np.array([[float(v) for v in l.split()[2:]] for l in r.stdout.splitlines() if l.startswith("P ")], dtype=np.float32)
+    assert probs.shape == (T, B)
+    tt = np.arange(T)
+    for b in range(B):
+        on = (7 * tt + 13 * b) % 10 != 0
+        assert (probs[~on, b] == -1.0).all() and 0.05 < (~on).mean() < 0.15
+        D = int(on.sum())
+        row = np.roll(pcm, -b * 7919)[:D * n]
+        st = torch.zeros((2, 1, 128), device=model.device)
+        ctx = torch.zeros((1, n // 8), device=model.device)
+        want = model.engine.forward_audio(torch.from_numpy(row[None].copy()).to(model.device), sr, ctx, st).cpu().numpy()[0]
+        if os.environ.get("SILERO_VAD_AMD_TEST_ARITH", "fp32") == "fp32":
+            assert np.array_equal(probs[on, b], want), b
+        else:
+            assert np.abs(probs[on, b] - want).max() < TIGHT
+        model.reset_states()
+        one = VADIterator(model, sampling_rate=sr)
+        ref = [e for k in range(D) if (e := one(torch.from_numpy(row[k * n:(k + 1) * n].astype(np.float32) / 32768.0)))]
+        got = [{l.split()[3]: int(l.split()[4])} for l in r.stdout.splitlines() if l.startswith("E ") and l.split()[2] == str(b)]
+        assert got == ref and len(ref) > 10, b
+
+
 @pytest.mark.parametrize("tag", ["16k", "8k"])
 def test_ragged_corpus_equals_single_recording_runs(model, oracle, golden, tag):
     """configs[3] plumbing: recordings of different lengths bucketed into lock-step batches give
