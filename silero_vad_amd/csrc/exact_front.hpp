@@ -120,7 +120,8 @@ __device__ __forceinline__ void exact_gx(const FrontArgs &a, const RefNet &net, 
         __syncthreads();
         for (int i = tid; i < K * 4; i += 256) {
             const double re = part_buf[i], im = part_buf[K * 4 + i];
-            ws.mag[i] = sqrt(re * re + im * im);
+            ws.mag[i] = sqrt(fma(re, re, im * im));                 // (written out: nothing is left to the compiler's contraction, which
+                                                                    //  may differ between the kernels this function is inlined into)
         }
     }
     __syncthreads();
