@@ -859,6 +859,7 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
             for idx, cnt, _ in S.refill_segments_stream(rec, model, sr, slots=rs, slab_chunks=rc_):
                 if res["first_result_s"] is None and len(idx):
                     res["first_result_s"] = time.perf_counter() - t_in
+                    res["first_result_slabs"] = int(S.STATS.get("buckets", 0))      # slabs handed to the GPU by then
                 counts[idx] = cnt
             return counts, None
 
@@ -905,7 +906,8 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
              "buckets": int(st.get("buckets", 0)),
              "padded_over_real_samples": round(st.get("padded", 0) / max(st.get("real", 1), 1), 4)}
         if res.get("first_result_s") is not None:              # the refill scheduler hands results over as recordings retire
-            d["first_result_at"] = round(res["first_result_s"] / elapsed, 4)     # fraction of the leg's wall time
+            d["first_result_at"] = round(res["first_result_s"] / elapsed, 4)     # fraction of the leg's wall time (planning included)
+            d["first_result_after_slabs"] = [res.get("first_result_slabs"), int(st.get("buckets", 0))]   # ... of the shard's slabs
         return d, res
 
     legs = {}
