@@ -4,6 +4,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -117,6 +118,7 @@ struct vad_engine {
     // 30 times a second for hours; resolving one costs a runtime call)
     const void *map_host[2] = {nullptr, nullptr};
     void *map_dev[2] = {nullptr, nullptr};
+    unsigned long map_gen = 0;                       // ... valid while no page-locked range has been released since (g_unmap_gen)
 
     // profiling: 3 events per (call, slab), read back lazily by vad_kernel_times
     std::vector<hipEvent_t> ev_pool;
@@ -130,6 +132,9 @@ int fail(vad_engine *e, int code, const std::string &msg) {
     if (e) e->err = msg;
     return code;
 }
+// bumped by vad_host_unregister: device views of host buffers that engines remember (vad_step_host) are dropped
+std::atomic<unsigned long> g_unmap_gen{1};
+
 int hip_fail(vad_engine *e, hipError_t rc, const char *what) {
     return fail(e, VAD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(rc));
 }
@@ -700,6 +705,11 @@ int vad_step_host_present(vad_engine *e, int sr, int B, const void *host_pcm, si
     // dev_prob == NULL: the kernel stores the B probabilities straight into the page-locked host buffer (4 B per stream over the link,
     // visible to the host once the stream has passed the call) -- no device buffer, no second copy
     auto mapped = [&](int k, const void *hp) -> void * {
+        const unsigned long gen = g_unmap_gen.load(std::memory_order_acquire);
+        if (e->map_gen != gen) {                     // a range was unregistered since: what is remembered may point at nothing
+            e->map_host[0] = e->map_host[1] = nullptr;
+            e->map_gen = gen;
+        }
         if (e->map_host[k] == hp && e->map_dev[k]) return e->map_dev[k];
         void *dv = nullptr;
         if (hipHostGetDevicePointer(&dv, const_cast<void *>(hp), 0) != hipSuccess || !dv) {
@@ -990,6 +1000,7 @@ int vad_host_unregister(void *p) {
         std::lock_guard<std::mutex> g(g_reg_mutex);
         g_registered.erase(static_cast<const uint8_t *>(p));
     }
+    g_unmap_gen.fetch_add(1, std::memory_order_release);
     return hipHostUnregister(p) == hipSuccess ? VAD_OK : VAD_ERR_HIP;
 }
 

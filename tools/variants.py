@@ -49,7 +49,8 @@ VARIANTS = {
     "nopk_all": [],                                     # every knob unit without packed fp32 (the bf16 x 9 recurrence beside plain VALU only)
     "b9_w4": ["-DVAD_B9_WAVES=4"],                     # bf16 x 9 frontend: two 4-wave workgroups per CU (default: one 8-wave workgroup)
     "pk_b9": [],
-    "noexact": ["-DVAD_NO_EXACT=1"],                   # frontends without the silent-frame test (what does it cost at C2?  profiles/r06_exact.md)
+    "noexact": ["-DVAD_NO_EXACT=1"],
+    "gather128": ["-DVAD_GATHER_WAVES=128"], "gather192": ["-DVAD_GATHER_WAVES=192"], "gather64": ["-DVAD_GATHER_WAVES=64"],   # ingest kernel's footprint                   # frontends without the silent-frame test (what does it cost at C2?  profiles/r06_exact.md)
 }
 
 
