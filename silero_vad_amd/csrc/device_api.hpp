@@ -85,6 +85,13 @@ struct CellArgs {
 };
 template <typename PcmT>
 hipError_t launch_step_lat(int sr, const FrontArgs &a, const CellArgs &c, hipStream_t s);
+// The same ONE step with one workgroup per STREAM and every sum formed on the VALU in the MFMA program's order (kernel_step_one.hip):
+// identical bits, a third of the time for a handful of streams (a B = 1 model call).  launch_front_one: the frontend half alone (gx in
+// the fragment layout), for the bit-identity tests.
+template <typename PcmT>
+hipError_t launch_step_one(int sr, const FrontArgs &a, const CellArgs &c, hipStream_t s);
+template <typename PcmT>
+hipError_t launch_front_one(int sr, const FrontArgs &a, hipStream_t s);
 // Same function, encoder 0 as two Winograd F(2,3) tiles over the frame pairs, straight-line code (kernel_front_wino.hip);
 // `wfront` points to the F(2,3) image (layout.hpp w_* units).  A/B form, test builds only (VAD_AB; option enc0=winograd2).
 template <typename PcmT>

@@ -78,6 +78,8 @@ struct vad_engine {
     bool exact_all_silent = true;                   // ... and all-silent chunks take the net's constant (false: option exact_transitions=edges, study mode)
     bool exact_transitions = true;                  // chunks with an exactly silent frame beside a non-silent one are evaluated in double
                                                     // (option "exact_transitions"; csrc/exact_front.hpp)
+    int one_max = 8;                                // a ONE-step call of at most this many streams takes the one-workgroup-per-stream kernel
+                                                    // (kernel_step_one.hip; option "step_one": auto | 0 | <max streams>)
     long lat_tiles = 768;                           // launches of at most this many 16-chunk tiles take the latency form of the frontend
                                                     // (option "front": auto | throughput | latency -> 768 | 0 | LONG_MAX)
     long long *trace = nullptr;                     // bring-up: device buffer for VAD_TRACE builds
@@ -308,7 +310,8 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             HIP_TRY(e, hipEventRecord(ev[0], stream));
         }
         const long tiles = (long)((B + 15) / 16) * nt;
-        if (T == 1 && e->fuse_step && !e->rec_b9 && !e->front_b9 && e->enc0 == 2 && tiles <= e->lat_tiles) {
+        const bool one = T == 1 && dec == 1 && B <= e->one_max && !e->rec_b9 && !e->front_b9 && e->enc0 == 2;
+        if (T == 1 && e->fuse_step && !e->rec_b9 && !e->front_b9 && e->enc0 == 2 && (tiles <= e->lat_tiles || one)) {
             // one step, few tiles (a stream pool's tick, a B = 1 call): frontend, LSTM cell and head in ONE kernel, no gx round trip
             vad::CellArgs ca{};
             ca.whh_lat = e->img->d_whh_lat[ni];
@@ -316,7 +319,9 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             ca.probs = probs;
             ca.ldp = ldp;
             ca.present = present;
-            HIP_TRY(e, vad::launch_step_lat<PcmT>(sr, fa, ca, stream));
+            // a handful of streams (the B = 1 call of every unmodified caller): one workgroup per stream, the same sums on the VALU
+            if (one) HIP_TRY(e, vad::launch_step_one<PcmT>(sr, fa, ca, stream));
+            else HIP_TRY(e, vad::launch_step_lat<PcmT>(sr, fa, ca, stream));
             if (prof) {
                 HIP_TRY(e, hipEventRecord(ev[1], stream));
                 HIP_TRY(e, hipEventRecord(ev[2], stream));
@@ -333,7 +338,8 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
         else if (e->enc0 == 0) HIP_TRY(e, vad::launch_front<PcmT>(sr, fa, stream));
         else
 #endif
-        if (tiles <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<PcmT>(sr, fa, stream));
+        if (one) HIP_TRY(e, vad::launch_front_one<PcmT>(sr, fa, stream));       // (fuse_step=0: the one-stream frontend + a recurrence kernel)
+        else if (tiles <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<PcmT>(sr, fa, stream));
         else {
             fa.exact_list = exact ? e->d_exact : nullptr;
             HIP_TRY(e, vad::launch_front_f43<PcmT>(sr, fa, stream));
@@ -559,6 +565,7 @@ int vad_clone(const vad_engine *src, vad_engine **out) {
     e->rec_form = src->rec_form;
     e->front_b9 = src->front_b9;
     e->fuse_step = src->fuse_step;
+    e->one_max = src->one_max;
     e->exact_transitions = src->exact_transitions;
     e->exact_all_silent = src->exact_all_silent;
     e->gx_cap = src->gx_cap;
@@ -619,6 +626,16 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         else if (v == "throughput") e->lat_tiles = 0;
         else if (v == "latency") e->lat_tiles = 0x7fffffffL;
         else return fail(e, VAD_ERR_OPTION, "front must be auto|throughput|latency");
+        return VAD_OK;
+    }
+    if (n == "step_one") {                           // one-step calls of at most N streams: one workgroup per stream ("0": never; A/B for tests)
+        if (v == "auto") e->one_max = 8;
+        else {
+            char *end = nullptr;
+            const long k = std::strtol(v.c_str(), &end, 10);
+            if (!end || *end || k < 0 || k > 4096) return fail(e, VAD_ERR_OPTION, "step_one: auto | 0 .. 4096");
+            e->one_max = (int)k;
+        }
         return VAD_OK;
     }
     if (n == "exact_transitions") {                  // "0": every chunk through the fp32 chains (A/B for tests and studies)
@@ -936,7 +953,8 @@ int vad_debug_frontend(vad_engine *e, int sr, int B, long L, const float *pcm, l
     else if (e->enc0 == 0) HIP_TRY(e, vad::launch_front<float>(sr, fa, stream));
     else
 #endif
-    if ((long)((B + 15) / 16) * T <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<float>(sr, fa, stream));
+    if (T == 1 && B <= e->one_max && e->enc0 == 2) HIP_TRY(e, vad::launch_front_one<float>(sr, fa, stream));
+    else if ((long)((B + 15) / 16) * T <= e->lat_tiles) HIP_TRY(e, vad::launch_front_lat<float>(sr, fa, stream));
     else {
         fa.exact_list = exact ? e->d_exact : nullptr;
         HIP_TRY(e, vad::launch_front_f43<float>(sr, fa, stream));

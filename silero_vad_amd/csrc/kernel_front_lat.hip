@@ -82,28 +82,6 @@ __device__ __forceinline__ void run_segment(Pipe &pp, AccF acc, BF bvec, LoadF l
     });
 }
 
-// ---- encoder 1's program for one output row block: 40 blocks = 10 units x 4 k-groups, in the order the one-wave program
-// accumulates them (kernel_front_f43.hip, "encoder 1 fed part by part"; layout.hpp w4_e1) -------------------------------------
-struct E1Blk {
-    int unit, kg, acc, frame, rbg;       // image unit, k-group, 0: out 0 (Z0) 1: out 1 (Z1), STFT frame and global row block of the B operand
-};
-constexpr E1Blk e1_blk(int Q, int idx) {
-    const int n = idx / 4, kg = idx % 4;
-    if (Q == 32) {
-        // per part: [tap1 <- y0 | tap2 <- y1] -> out 0, [tap0 <- y1 | tap1 <- y2] -> out 1, and after every odd part
-        // [tap2 <- y3 of part p-1 | tap2 <- y3 of part p] -> out 1; k-groups 0, 1 carry the first tensor's two row blocks
-        const int parts[10] = {0, 0, 1, 1, 1, 2, 2, 3, 3, 3}, us[10] = {0, 1, 0, 1, 2, 0, 1, 0, 1, 2};
-        const int p = parts[n], u = us[n], first = kg < 2;
-        const int frame = u == 0 ? (first ? 0 : 1) : u == 1 ? (first ? 1 : 2) : 3;
-        const int src = u == 2 ? (first ? p - 1 : p) : p;
-        return E1Blk{vadl::w4_e1(p, u, 32), kg, u == 0 ? 0 : 1, frame, 2 * src + (kg & 1)};
-    }
-    // 8 kHz: per part tap1 <- y0, tap2 <- y1 (out 0); tap0 <- y1, tap1 <- y2, tap2 <- y3 (out 1); k-group = the part's row block
-    const int p = n / 5, u = n % 5;
-    const int fr[5] = {0, 1, 1, 2, 3}, ac[5] = {0, 0, 1, 1, 1};
-    return E1Blk{vadl::w4_e1(p, u, 16), kg, ac[u], fr[u], 4 * p + kg};
-}
-
 #ifndef VAD_LAT_WG_PER_CU
 #define VAD_LAT_WG_PER_CU 1
 #endif

@@ -2896,3 +2896,93 @@ def test_refill_results_arrive_as_recordings_retire(model, golden, tag):
     counts, flat = refill_speech_segments(audios, model, sr, slots=6, slab_chunks=8, as_arrays=True, **kw)
     assert lists == want and counts.tolist() == [len(w) for w in want]
     assert flat.tolist() == [[d["start"], d["end"]] for w in want for d in w]
+
+
+# ---- (34) the one-workgroup-per-stream step (kernel_step_one.hip) against the tile kernels, bit for bit -------------------------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_one_stream_step_is_bit_identical(model, golden, tag):
+    """kernel_step_one.hip forms every sum of a step on the VALU in the order the MFMA program adds its products (what kernel_rec_small.hip
+    does for the recurrence): a B <= 8 step through it must give IDENTICAL bits to the same step through the 16-stream tile kernels
+    (option step_one = 0) -- gate pre-activations, probabilities, carried (h, c) and context, over chains of steps, for fp32 and
+    int16 chunks, random carried state, B = 1 .. 8, with chunks where digital silence begins / ends / lasts (the double-precision
+    routes), a NaN sample (the poison route), present flags, and through the fuse_step = 0 path (its frontend + a recurrence kernel)."""
+    if os.environ.get("SILERO_VAD_AMD_TEST_ARITH", "fp32") != "fp32":
+        pytest.skip("the one-stream kernel serves the fp32 arithmetic")
+    eng = model.engine
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    dev = model.device
+    rng = np.random.default_rng(12)
+    T = 14
+
+    def both(fn):
+        out = []
+        for one in ("0", "auto"):
+            eng.set_option("step_one", one)
+            try:
+                out.append(fn())
+            finally:
+                eng.set_option("step_one", "auto")
+        return out
+
+    for B in (1, 2, 3, 5, 8):
+        rows = rolled_rows(g["wav"], B, T * n, 3001)
+        rows[0, 3 * n + 7: 6 * n + 100] = 0.0                      # a drop to zeros, a silent chunk, a come-back
+        if B > 1:
+            rows[1, 9 * n + 5] = np.nan                            # from chunk 9 on this stream is NaN (and only this one)
+        st0 = (0.3 * rng.standard_normal((2, B, 128))).astype(np.float32)
+        ctx0 = (0.1 * rng.standard_normal((B, n // 8))).astype(np.float32)
+        for dtype in (torch.float32, torch.int16):
+            if dtype == torch.int16:
+                x = torch.from_numpy((np.nan_to_num(rows) * 32768.0).clip(-32768, 32767).astype(np.int16)).to(dev)
+            else:
+                x = torch.from_numpy(rows).to(dev)
+            for fuse in ("1", "0"):
+                def run():
+                    eng.set_option("fuse_step", fuse)
+                    try:
+                        ctx = torch.from_numpy(ctx0).to(dev)
+                        st = torch.from_numpy(st0).to(dev)
+                        ps = []
+                        for t in range(T):
+                            p = torch.full((B,), 7.0, device=dev)
+                            fl = None
+                            if t in (4, 5) and B > 2:
+                                fl = torch.ones(B, dtype=torch.uint8, device=dev)
+                                fl[2] = 0                          # stream 2 misses ticks 4 and 5
+                            eng.step_present(x[:, t * n:(t + 1) * n].contiguous(), sr, ctx, st, p, fl)
+                            ps.append(p.cpu().numpy())
+                        return np.stack(ps, 1), st.cpu().numpy(), ctx.cpu().numpy()
+                    finally:
+                        eng.set_option("fuse_step", "1")
+                (p0, s0, c0), (p1, s1, c1) = both(run)
+                assert np.array_equal(p0, p1, equal_nan=True) and np.array_equal(s0, s1, equal_nan=True) and np.array_equal(c0, c1), (B, dtype, fuse)
+                assert np.isfinite(p1[0]).all()
+                if B > 1 and dtype == torch.float32:               # (int16 PCM cannot carry a NaN)
+                    assert np.isnan(p1[1, 9:]).all() and np.isfinite(p1[1, :9]).all()
+        # the frontend half alone: gate pre-activations of single chunks (first chunk: zero context; a chunk with a silent frame; a silent one)
+        for t in (0, 3, 4, 6, 10):
+            xt = torch.from_numpy(rows[:, t * n:(t + 1) * n].copy()).to(dev)
+            cx = torch.from_numpy(np.ascontiguousarray(rows[:, t * n - n // 8:t * n]) if t else np.zeros((B, n // 8), np.float32)).to(dev)
+            g0, g1 = both(lambda: eng.debug_frontend(xt, sr, cx).cpu().numpy())
+            assert np.array_equal(g0, g1, equal_nan=True), (B, t)
+    # what the kernel is for: the B = 1 call of an unmodified caller is faster through it
+    import json
+    import time
+    chunk = torch.from_numpy(g["wav"][:n].copy())
+    times = {}
+    for one in ("0", "auto"):
+        eng.set_option("step_one", one)
+        try:
+            model.reset_states()
+            for _ in range(50):
+                model(chunk, sr).item()
+            t0 = time.perf_counter()
+            for _ in range(400):
+                model(chunk, sr).item()
+            times[one] = (time.perf_counter() - t0) / 400 * 1e3
+        finally:
+            eng.set_option("step_one", "auto")
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(times, open(f"gpurun_out/step_one_call_ms_{tag}.json", "w"))
+    assert times["auto"] < times["0"], times
