@@ -65,6 +65,52 @@ __device__ __forceinline__ void chain2(float &acc0, float &acc1, const float *w0
             }
 }
 
+// A chain's weights requested AHEAD of their use: the vectors of NKG k-groups of one row.  load() only issues the requests (pinned in
+// place by a scheduling barrier); run() is chain<NKG> over them.  Every layer's weights depend on the thread, not on the data, so each
+// layer is requested while the layer before it computes -- a step is ten dependent phases, and what each of them would otherwise wait
+// for first is an L2 round trip.
+template <int NKG>
+struct WSet {
+    f32x4 a[NKG][4];
+    __device__ __forceinline__ void load(const float *w, long kg_stride) {
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a[kg][g] = *reinterpret_cast<const f32x4 *>(w + kg * kg_stride + g * 64);
+    }
+    __device__ __forceinline__ float run(float acc, const float *x) const {
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc = fmaf(a[kg][g][ks], x[16 * kg + 4 * ks + g], acc);
+        return acc;
+    }
+};
+template <int NKG>
+__device__ __forceinline__ void run2(const WSet<NKG> &A, const WSet<NKG> &B, float &acc0, float &acc1, const float *x0, const float *x1) {
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc0 = fmaf(A.a[kg][g][ks], x0[16 * kg + 4 * ks + g], acc0);
+                acc1 = fmaf(B.a[kg][g][ks], x1[16 * kg + 4 * ks + g], acc1);
+            }
+}
+#define VAD_PIN() __builtin_amdgcn_sched_barrier(0)
+// A workgroup barrier for data exchanged through LDS that does NOT wait for the global loads in flight (__syncthreads would drain
+// the weight requests that were issued ahead on purpose)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// bring-up (option trace_ptr, tools/b1_phase_trace.py): thread 0 of workgroup 0 leaves the shader clock at the phase boundaries
+#define VAD_STAMP(k) do { if (a.trace != nullptr && threadIdx.x == 0 && blockIdx.x == 0) a.trace[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
+
 __device__ __forceinline__ int chain_pos(int ch) { return (ch & ~15) + 4 * (ch & 3) + ((ch >> 2) & 3); }   // channel -> position
 
 template <int Q, typename PcmT, bool CELL>
@@ -108,26 +154,38 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
     ln.sgnB = (ln.g & 1) ? -1.f : 1.f;
     const int w = ln.wave;
 
-    {   // tables -> LDS
-        constexpr int NV = tb.total / 4;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.tables);
-        for (int i = tid; i < NV; i += 256) reinterpret_cast<f32x4 *>(tab)[i] = src[i];
-    }
-    if (CELL && tid < 128) hc[chain_pos(tid)] = cell.state[(size_t)b * 128 + tid];
-    __syncthreads();
-
+    // this thread's rows of encoder 0 (row r, the two matrices of its half first) -- requested before anything else
+    VAD_STAMP(0);
+    const int r = tid & 127, half = tid >> 7, i16 = r & 15;
+    const int part = r / (16 * RB), rbl = (r % (16 * RB)) / 16;
+    const int u0 = part == 0 ? w4_part0(0, Q) : part == 1 ? w4_part0(1, Q) : part == 2 ? w4_part0(2, Q) : w4_part0(3, Q);
+    const float *wb = a.wfront + (size_t)u0 * 4096 + rbl * 256 + i16 * 4;
+    WSet<KG0> W0a, W0b;
     // ---- STFT: wave v, frame v (fft_wave.hpp; the context for the next call is written by load_slice) -------------------------------
     {
         float pcm_s[2 * Q], Xm[Q + 1];
-        load_slice<Q, PcmT, 1>(pcm_s, a, ln, w);
+        load_slice<Q, PcmT, 1>(pcm_s, a, ln, w);                    // (the chunk first: the FFT waits for it and for the tables)
+        VAD_PIN();
+        {   // tables -> LDS
+            constexpr int NV = tb.total / 4;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.tables);
+            for (int i = tid; i < NV; i += 256) reinterpret_cast<f32x4 *>(tab)[i] = src[i];
+        }
+        if (CELL && tid < 128) hc[chain_pos(tid)] = cell.state[(size_t)b * 128 + tid];
+        W0a.load(wb + (size_t)(2 * half) * 4096, RB * 256);
+        W0b.load(wb + (size_t)(2 * half + 1) * 4096, RB * 256);
+        VAD_PIN();
+        lds_barrier();
+        VAD_STAMP(1);
         fft_math<Q>(Xm, pcm_s, tab, ln);
+        VAD_STAMP(2);
         if (ln.j == 0) {
 #pragma unroll
             for (int s = 0; s < Q; ++s) mag[w][4 * s + ln.g] = Xm[s];
             if (ln.g == 0) nyq[w] = Xm[Q];
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         int r = 0;
         if (!VAD_NO_EXACT && a.exact_net != nullptr) {              // exact_front.hpp: silent frames beside frames that are not
@@ -142,8 +200,9 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
         }
         route = r;
     }
-    __syncthreads();
+    lds_barrier();
     const int how = route;
+    VAD_STAMP(3);
     if (how == 1) {
         exact_gx<Q, PcmT, 1>(a, net, b, ln.t, ws);
         for (int r = tid; r < 512; r += 256) gates[r] = ws.gx[r];
@@ -173,27 +232,27 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
             }
             poison_g[tid] = poison_nyq(p0, p1, nyq[0], nyq[1], nyq[2], nyq[3]);
         }
-        __syncthreads();
-        const int r = tid & 127, half = tid >> 7, i16 = r & 15;
+        lds_barrier();
         {
-            const int part = r / (16 * RB), rbl = (r % (16 * RB)) / 16;
-            const int u0 = part == 0 ? w4_part0(0, Q) : part == 1 ? w4_part0(1, Q) : part == 2 ? w4_part0(2, Q) : w4_part0(3, Q);
-            const float *wb = a.wfront + (size_t)u0 * 4096 + rbl * 256 + i16 * 4;
+            WSet<KG0> W0c;                                          // the fifth / sixth matrix of this half: requested before the first four run
+            W0c.load(wb + (size_t)(4 + half) * 4096, RB * 256);
+            VAD_PIN();
             // m1, m2 (half 0) | m3, m4 (half 1): two independent chains per thread
             float ma = 0.f, mb = 0.f;
-            chain2<KG0>(ma, mb, wb + (size_t)(2 * half) * 4096, wb + (size_t)(2 * half + 1) * 4096, RB * 256, tin[2 * half], tin[2 * half + 1]);
+            run2<KG0>(W0a, W0b, ma, mb, tin[2 * half], tin[2 * half + 1]);
             my[2 * half][r] = ma;
             my[2 * half + 1][r] = mb;
-            __syncthreads();
+            lds_barrier();
+            VAD_STAMP(4);
             const float m1 = my[0][r], m2 = my[1][r], m3 = my[2][r], m4 = my[3][r];
             const float sm = m1 + m2, df = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
             // half 0 finishes frames 0 and 1, half 1 frames 3 and 2
             float ya, yb;                                           // ya: the frame that takes a fifth / sixth product chain
             if (half == 0) {
-                ya = chain<KG0>(sm + s2, wb + (size_t)4 * 4096, RB * 256, tin[4]);       // y0 += U0 t0
+                ya = W0c.run(sm + s2, tin[4]);                                           // y0 += U0 t0
                 yb = fmaf(2.f, d2, df);                                                  // y1
             } else {
-                ya = chain<KG0>(fmaf(8.f, d2, df), wb + (size_t)5 * 4096, RB * 256, tin[5]);   // y3 += U5 t5
+                ya = W0c.run(fmaf(8.f, d2, df), tin[5]);                                 // y3 += U5 t5
                 yb = fmaf(4.f, s2, sm);                                                  // y2
             }
             const float *wn = tab + tb.w_nyq + r;                   // [tap][row]
@@ -216,7 +275,8 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
                 e0c[2][chain_pos(r)] = fmaxf(yb + bias, 0.f);
             }
         }
-        __syncthreads();
+        lds_barrier();
+        VAD_STAMP(5);
         // ---- encoder 1: 64 rows x two outputs, the 40-block program of front_common.hpp e1_blk ----------------------------------------
         if (tid < 128) {
             const int ro = tid & 63, o = tid >> 6, wr = ro >> 4, i = ro & 15;
@@ -228,7 +288,16 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
             });
             e1c[o][chain_pos(ro)] = fmaxf(z + tab[tb.b_e1 + ro], 0.f);
         }
-        __syncthreads();
+        lds_barrier();
+        VAD_STAMP(6);
+        // (the 512 gate rows' W_ih weights -- rows tid and tid + 256 -- are requested here, two layers ahead)
+        WSet<8> Wi0, Wi1;
+        {
+            const int q0 = tid >> 7, m = (tid >> 4) & 7, i = tid & 15;
+            Wi0.load(a.wfront + (size_t)(T0 + 4 + 4 * q0) * 4096 + m * 256 + i * 4, 8 * 256);
+            Wi1.load(a.wfront + (size_t)(T0 + 4 + 4 * (q0 + 2)) * 4096 + m * 256 + i * 4, 8 * 256);
+            VAD_PIN();
+        }
         // ---- encoder 2 (taps 1, 2 see encoder-1 outputs 0, 1) -----------------------------------------------------------------------------
         if (tid < 64) {
             const int wr = tid >> 4, i = tid & 15;
@@ -238,7 +307,8 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
                 v = chain<1>(v, a.wfront + ((size_t)(T0 + bi / 4) * 16 + (bi % 4) * 4 + wr) * 256 + i * 4, 0, e1c[bi / 4] + 16 * (bi % 4));
             e2c[chain_pos(tid)] = fmaxf(v, 0.f);
         }
-        __syncthreads();
+        lds_barrier();
+        VAD_STAMP(7);
         // ---- encoder 3 (centre tap) -> feat, with the non-finite poison in the k = (0, 0, g) inputs -------------------------------------
         if (tid < 128) {
             const int wr = tid >> 5, m = (tid >> 4) & 1, i = tid & 15;
@@ -249,18 +319,18 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
             if (pos < 4) f = __uint_as_float(__float_as_uint(f) | __float_as_uint(poison_g[pos]));     // positions 0..3 = (kg 0, ks 0, g)
             fec[pos] = f;
         }
-        __syncthreads();
+        lds_barrier();
+        VAD_STAMP(8);
         // ---- W_ih: gate rows tid and tid + 256 ---------------------------------------------------------------------------------------------
         {
             float g0 = tab[tb.b_g + tid], g1 = tab[tb.b_g + tid + 256];
-            const int q0 = tid >> 7, m = (tid >> 4) & 7, i = tid & 15;
-            chain2<8>(g0, g1, a.wfront + (size_t)(T0 + 4 + 4 * q0) * 4096 + m * 256 + i * 4,
-                      a.wfront + (size_t)(T0 + 4 + 4 * (q0 + 2)) * 4096 + m * 256 + i * 4, 8 * 256, fec, fec);
+            run2<8>(Wi0, Wi1, g0, g1, fec, fec);
             gates[tid] = g0;
             gates[tid + 256] = g1;
         }
     }
-    __syncthreads();
+    lds_barrier();
+    VAD_STAMP(9);
     if constexpr (!CELL) {
         // gx[tile][row block 32][lane 64][4] (layout.hpp): row 16 mb + 4 g + r of column j at lane 16 g + j, element r
         float *gxt = a.gx + (size_t)(b >> 4) * 32 * 256;
@@ -273,11 +343,12 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
             const int q0 = tid >> 7, m = (tid >> 4) & 7, i = tid & 15;
             chain2<8>(g0, g1, cell.whh_lat + ((size_t)q0 * 64 + m) * 256 + i * 4, cell.whh_lat + ((size_t)(q0 + 2) * 64 + m) * 256 + i * 4,
                       8 * 256, hc, hc);
-            __syncthreads();
+            lds_barrier();
             gates[tid] = g0;
             gates[tid + 256] = g1;
         }
-        __syncthreads();
+        lds_barrier();
+        VAD_STAMP(10);
         const bool present = cell.present == nullptr || cell.present[b] != 0;
         if (tid < 128) {
             const float c0 = cell.state[((size_t)a.B + b) * 128 + tid];
@@ -290,7 +361,7 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
                 cell.state[((size_t)a.B + b) * 128 + tid] = cn;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < 32) {                                             // (row block rb, lane group g): units 16 rb + 4 g + r, r ascending
             const int rb = tid >> 2, g = tid & 3;
             float part = 0.f;
@@ -298,15 +369,16 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
             for (int r = 0; r < 4; ++r) part = fmaf(0.5f * tab[tb.w_out + 16 * rb + 4 * g + r], relu2_f(hnew[16 * rb + 4 * g + r]), part);
             pg[tid] = part;
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < 8) pb[tid] = (pg[4 * tid] + pg[4 * tid + 1]) + (pg[4 * tid + 2] + pg[4 * tid + 3]);
-        __syncthreads();
+        lds_barrier();
         if (tid == 0 && present) {
             float p = tab[tb.b_out];
 #pragma unroll
             for (int ww = 0; ww < 8; ++ww) p += pb[ww];
             cell.probs[(size_t)b * cell.ldp + a.t0] = sigmoid_f(p);
         }
+        VAD_STAMP(11);
     }
 }
 
