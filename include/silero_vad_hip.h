@@ -140,6 +140,15 @@ int  vad_step(vad_engine *e, int sr, int B, const float *pcm, long ld, float *ct
 int  vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, void *dev_pcm, float *ctx, float *state,
                    float *dev_prob, float *host_prob, void *stream);
 
+/* vad_step_host(dev_pcm = NULL, dev_prob = NULL) that RETURNS WHEN THE B PROBABILITIES ARE IN host_prob: the blocking call every
+ * unmodified caller of the reference makes, `model(chunk, sr).item()` once per 32 ms (src/silero_vad/utils_vad.py:324-336
+ * get_speech_timestamps, :528 VADIterator.__call__; examples/cpp/silero-vad-onnx.cpp:103-142 around session.Run).  The kernels store a
+ * stream's probability as their last act, so the call waits for the B slots themselves to change (a bounded spin on the page-locked
+ * memory; hipStreamSynchronize if they have not after 0.4 ms) instead of for the stream's completion signal.  ctx / state are device
+ * buffers as in vad_step; later work on `stream` is ordered behind the step as usual.                                          */
+int  vad_step_host_sync(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, float *ctx, float *state, float *host_prob,
+                        void *stream);
+
 /* vad_step with the two contexts apart and either PCM type, all on the device: reads ctx_in, writes the next context to ctx_out
  * (a second buffer: the kernel may not write where other waves still read), so that a caller that alternates two context buffers
  * pays no device-to-device copy per step.  The functional form once more -- the ONNX graph's inputs and outputs are distinct

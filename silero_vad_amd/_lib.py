@@ -60,6 +60,7 @@ SYMBOLS = {
     "vad_geometry": (c_int, [c_int, POINTER(c_int), POINTER(c_int)]),
     "vad_set_option": (c_int, [c_void_p, c_char_p, c_char_p]),
     "vad_step": (c_int, [c_void_p, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vad_step_host_sync": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vad_step_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vad_step_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vad_step_present": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

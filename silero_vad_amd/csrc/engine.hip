@@ -1,6 +1,8 @@
 // engine.hip -- the C ABI (include/silero_vad_hip.h): engine lifetime, scratch, kernel launches.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <sched.h>
 
 #include <algorithm>
@@ -762,6 +764,51 @@ int vad_step_host_present(vad_engine *e, int sr, int B, const void *host_pcm, si
     }
     if (rc) return rc;
     if (dev_prob) HIP_TRY(e, hipMemcpyAsync(host_prob, dev_prob, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, stream));
+    return VAD_OK;
+}
+
+// The blocking form: what `model(chunk, sr)` is to its caller.  The kernels store each stream's probability into the page-locked buffer
+// as their LAST act (after the state and the context), so the host does not need the stream's completion signal -- the end-of-kernel
+// cache release, the signal write and the runtime's handling of it are several microseconds of a 40 us call: the slots are filled with a
+// bit pattern no kernel produces by itself, and the host reads them until every one has changed.  Bounded: a slot that has not changed
+// after kSpinNs (a long batch, a debugger, or an input whose NaN payload is the pattern) is settled by hipStreamSynchronize.
+namespace {
+constexpr uint32_t kProbPending = 0xFFF0DEADu;       // a negative NaN with a payload: results are in [0, 1] or NaN computed on the device
+constexpr long kSpinNs = 400 * 1000;
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+}  // namespace
+
+int vad_step_host_sync(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, float *ctx, float *state, float *host_prob,
+                       void *stream_v) {
+    if (!e) return VAD_ERR_ARG;
+    if (B > 0 && host_prob) {
+        volatile uint32_t *slot = reinterpret_cast<volatile uint32_t *>(host_prob);
+        for (int b = 0; b < B; ++b) slot[b] = kProbPending;
+        std::atomic_thread_fence(std::memory_order_seq_cst);     // the slots are marked before the launch is rung in
+    }
+    const int rc = vad_step_host_present(e, sr, B, host_pcm, elem_size, nullptr, ctx, state, nullptr, host_prob, nullptr, nullptr, stream_v);
+    if (rc || B == 0) return rc;
+    const volatile uint32_t *slot = reinterpret_cast<const volatile uint32_t *>(host_prob);
+    const auto t0 = std::chrono::steady_clock::now();
+    int b = 0;
+    for (unsigned it = 0;; ++it) {
+        while (b < B && slot[b] != kProbPending) ++b;
+        if (b == B) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return VAD_OK;
+        }
+        cpu_relax();
+        if ((it & 255) == 255 && std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > kSpinNs) break;
+    }
+    HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream_v));
     return VAD_OK;
 }
 
