@@ -310,8 +310,8 @@ class HipSileroVAD:
                     full = (torch.empty((16, num_samples), dtype=dt, pin_memory=True), torch.empty((16,), dtype=torch.float32, pin_memory=True))
                 else:
                     full = sm[3]
-                sm = self._small = (full[0][:batch_size], full[1][:batch_size], (num_samples, dt, batch_size), full)
-            pcm, prob = sm[0], sm[1]
+                sm = self._small = (full[0][:batch_size], full[1][:batch_size].unsqueeze(1), (num_samples, dt, batch_size), full)
+            pcm, prob = sm[0], sm[1]                # prob: the [B, 1] view of the page-locked slots
             pcm.copy_(x)
             eng = self.engine
             # (vad_step_host_sync returns when the probabilities are in `prob`: it watches the page-locked slots, not the stream)
@@ -321,7 +321,7 @@ class HipSileroVAD:
                 eng._check(rc)
             self._last_sr = sr
             self._last_batch_size = batch_size
-            return prob.clone().unsqueeze(1)
+            return prob.clone()
         with self._device_ctx():
             xd = self._to_device(x)
             if xd.dtype == torch.int16:

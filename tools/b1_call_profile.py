@@ -15,7 +15,7 @@ print("full call+item us", t(lambda: m(c, 16000).item()))
 print("front_door", t(lambda: m._front_door(c, 16000)))
 x = c.unsqueeze(0)
 print("ensure_state", t(lambda: m._ensure_state(16000, 1)))
-pcm, prob = m._small[0][:1], m._small[1][:1]
+pcm, prob = m._small[0][:1], m._small[1][:1, 0]
 print("slices", t(lambda: (m._small[0][:1], m._small[1][:1])))
 print("copy_", t(lambda: pcm.copy_(x)))
 print("current_stream", t(lambda: torch.cuda.current_stream(m.device)))
