@@ -140,6 +140,30 @@ def test_refill_plan_covers_every_sample_once():
         assert plan.padded_chunks() >= plan.real_chunks()
 
 
+def test_refill_plan_retires_something_early():
+    """Longest-first admission alone retires nothing before the longest recordings end; a sixteenth of the slots start with the
+    shortest recordings instead, without lengthening the schedule."""
+    from silero_vad_amd import RefillPlan
+    rng = np.random.default_rng(5)
+    lengths = [int(v) for v in rng.integers(20 * 512, 900 * 512, size=4000)]
+    slots, slab = 128, 16
+    plan = RefillPlan(lengths, slots, slab, 512)
+    width = slab * 512
+    need = {i: (m + width - 1) // width for i, m in enumerate(lengths)}
+    first_retired = None
+    seen = {}
+    for k, entries in enumerate(plan.slabs):
+        for sl, rec, at, take, reset in entries:
+            seen[rec] = seen.get(rec, 0) + 1
+            if seen[rec] == need[rec] and first_retired is None:
+                first_retired = k
+    shortest = min(need.values())
+    assert first_retired == shortest - 1                                   # the shortest recording runs from slab 0
+    assert first_retired < max(need.values()) // 4
+    # the schedule is no longer than longest-first's lower bound allows: total work / slots, rounded up, plus one recording's tail
+    assert len(plan.slab_arrays) <= -(-sum(need.values()) // slots) + max(need.values())
+
+
 @pytest.mark.parametrize("sr", [16000, 8000])
 def test_refill_equals_one_recording_at_a_time(oracle, sr):
     """The scheduler's carried state / per-slot reset protocol, driven with the oracle behind the engine's Python
