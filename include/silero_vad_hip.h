@@ -398,6 +398,12 @@ int  vad_host_unregister(void *p);
  * with rows retired and re-admitted): recording q (in admission order) occupies a stream slot for need[q] time slabs; at every slab
  * boundary every free slot, lowest first, takes the next recording.  Writes the slab at which q is admitted and its slot.  Host only. */
 int  vad_refill_schedule(const long *need, long n, long slots, long *start, long *slot);
+/* ... and the schedule as the table the stager walks: one row of five longs per (recording, slab it is active in) -- slot, recording,
+ * first sample, samples, reset flag -- ordered by slab, then by slot; cuts[k] .. cuts[k + 1] (n_slabs + 1 entries) are slab k's rows.
+ * Queue entry q is recording rec[q] of len[q] samples; width = samples per slab; rows has room for sum(need) rows.  Returns the number
+ * of rows, or -VAD_ERR_ARG.  Host only.                                                                                           */
+long vad_refill_table(const long *need, const long *start, const long *slot, const long *rec, const long *len, long n, long slots,
+                      long width, long n_slabs, long *rows, long *cuts);
 
 /* Do two streams of the engine's device run BESIDE each other?  The HIP runtime maps streams onto a handful of hardware queues
  * (GPU_MAX_HW_QUEUES, 4 by default; which stream lands where depends on the order in which the process' streams were first

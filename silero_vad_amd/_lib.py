@@ -104,6 +104,7 @@ SYMBOLS = {
     "vad_upload_rows": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_long), c_long, c_long, c_size_t, c_void_p, c_int,
                                 c_void_p]),
     "vad_refill_schedule": (c_int, [POINTER(c_long), c_long, c_long, POINTER(c_long), POINTER(c_long)]),
+    "vad_refill_table": (c_long, [POINTER(c_long)] * 5 + [c_long, c_long, c_long, c_long, POINTER(c_long), POINTER(c_long)]),
     "vad_streams_overlap": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vad_host_register": (c_int, [c_void_p, c_size_t]),
     "vad_host_unregister": (c_int, [c_void_p]),

@@ -171,6 +171,13 @@ class Engine:
                                                       ctx.data_ptr(), state.data_ptr(), dp, host_prob.data_ptr(), host_present.data_ptr(),
                                                       dev_present.data_ptr(), s))
 
+    def step_host_sync(self, host_pcm, sr, ctx, state, host_prob, stream=None):
+        """vad_step_host_sync: the step on page-locked chunks read in place, returning when the B probabilities are in `host_prob`
+        (the blocking `model(chunk, sr)` of the reference's callers; the wait watches the page-locked slots, not the stream)."""
+        s = self._stream() if stream is None else ctypes.c_void_p(stream)
+        self._check(self._L.vad_step_host_sync(self._h, sr, host_pcm.shape[0], host_pcm.data_ptr(), host_pcm.element_size(),
+                                               ctx.data_ptr(), state.data_ptr(), host_prob.data_ptr(), s))
+
     def upload_rows(self, rows, lens, n, width, elem_size, dst, how=0):
         """Ragged rows in PINNED host memory -> dst[n, width] on the GPU, zero padded, on the current stream
         (vad_upload_rows; how 0: copy engines, 1: gather kernel).  rows / lens: ctypes arrays."""

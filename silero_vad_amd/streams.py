@@ -143,7 +143,7 @@ class _StagePool:
         return i
 
 
-def _distinct_queue_stream(engine, device, others, tries=12):
+def _distinct_queue_stream(engine, device, others, tries=12, priority=0):
     """A torch stream whose kernels demonstrably run BESIDE those of every stream in `others` (vad_streams_overlap).  torch hands out
     streams from a pool, the HIP runtime maps them onto ~4 hardware queues in the order of their first use, and two streams on one
     queue serialise: an upload kernel that lands on a compute lane's queue alternates with the lane instead of overlapping it -- the
@@ -152,7 +152,7 @@ def _distinct_queue_stream(engine, device, others, tries=12):
     none of `tries` candidates runs beside all of `others` the best one found is returned and STATS["stream_collisions"] says so (the
     caller's pipeline is then correct but partly serial).  The probe synchronises the streams involved (~1 ms per pair): it is skipped
     -- a plain new stream is returned -- while the current stream is being captured into a graph."""
-    st = torch.cuda.Stream(device)
+    st = torch.cuda.Stream(device, priority=priority)
     if engine is None or not hasattr(engine, "streams_overlap") or torch.cuda.is_current_stream_capturing():
         return st
     best, best_hits = st, -1
@@ -164,7 +164,7 @@ def _distinct_queue_stream(engine, device, others, tries=12):
             break
         STATS["stream_retries"] += 1
         if k + 1 < tries:
-            st = torch.cuda.Stream(device)
+            st = torch.cuda.Stream(device, priority=priority)
     if best_hits < len(others):
         STATS["stream_collisions"] += 1
     return best
@@ -851,12 +851,11 @@ class RefillPlan:
     shortest (so that results start to flow at once)."""
 
     def __init__(self, lengths: Sequence[int], slots: int, slab_chunks: int, chunk: int):
-        self.lengths = [int(n) for n in lengths]
+        lens = self.lengths = np.ascontiguousarray(lengths, dtype=np.int64).reshape(-1)     # (an array: a shard has 10^5 recordings)
         self.slots, self.slab_chunks, self.chunk = int(slots), int(slab_chunks), int(chunk)
         if self.slots < 1 or self.slab_chunks < 1:
             raise ValueError("slots and slab_chunks must be positive")
         width = self.slab_chunks * self.chunk
-        lens = np.asarray(self.lengths, dtype=np.int64)
         live = np.flatnonzero(lens > 0)
         queue = live[np.argsort(-lens[live], kind="stable")]  # longest first, ties in input order
         # ... except that a sixteenth of the slots START with the shortest recordings: with the longest in every slot nothing retires
@@ -876,16 +875,18 @@ class RefillPlan:
         lp = ctypes.POINTER(ctypes.c_long)
         if lib().vad_refill_schedule(need.ctypes.data_as(lp), len(queue), self.slots, start.ctypes.data_as(lp), slot.ctypes.data_as(lp)):
             raise ValueError("vad_refill_schedule: bad arguments")
-        # one row per (recording, slab it is active in): [slot, recording, first sample, samples, reset]
-        reps = np.repeat(np.arange(len(queue)), need)
-        j = np.arange(len(reps)) - np.repeat(np.cumsum(need) - need, need)          # 0 .. need-1 within a recording
-        at = j * width
-        rows = np.stack([slot[reps], queue[reps], at, np.minimum(width, lens[queue[reps]] - at), (j == 0).astype(np.int64)], 1)
-        slab_of = start[reps] + j
-        order = np.lexsort((rows[:, 0], slab_of))                                    # by slab, then by slot
-        rows, slab_of = rows[order], slab_of[order]
-        n_slabs = int(slab_of[-1]) + 1 if len(slab_of) else 0
-        cuts = np.searchsorted(slab_of, np.arange(n_slabs + 1))
+        # one row per (recording, slab it is active in): [slot, recording, first sample, samples, reset], by slab, then by slot (native:
+        # 1.3 M rows for a shard -- vad_refill_table)
+        n_slabs = int((start + need).max()) if len(queue) else 0
+        rows = np.empty((int(need.sum()), 5), dtype=np.int64)
+        cuts = np.zeros(n_slabs + 1, dtype=np.int64)
+        rec = np.ascontiguousarray(queue, dtype=np.int64)
+        qlen = np.ascontiguousarray(lens[queue])
+        got = lib().vad_refill_table(need.ctypes.data_as(lp), start.ctypes.data_as(lp), slot.ctypes.data_as(lp), rec.ctypes.data_as(lp),
+                                     qlen.ctypes.data_as(lp), len(queue), self.slots, width, n_slabs, rows.ctypes.data_as(lp),
+                                     cuts.ctypes.data_as(lp))
+        if got != len(rows):
+            raise ValueError("vad_refill_table: bad arguments")
         # the schedule as arrays (slot, recording, first sample, samples, reset flag) per slab, for the vectorised stager
         self.slab_arrays = [rows[cuts[k]:cuts[k + 1]] for k in range(n_slabs)]
 
@@ -895,13 +896,14 @@ class RefillPlan:
         return [[(int(a), int(b), int(c), int(d), bool(e)) for a, b, c, d, e in arr] for arr in self.slab_arrays]
 
     def n_chunks(self, i: int) -> int:
-        return (self.lengths[i] + self.chunk - 1) // self.chunk
+        return (int(self.lengths[i]) + self.chunk - 1) // self.chunk
 
     def padded_chunks(self) -> int:
         return len(self.slab_arrays) * self.slots * self.slab_chunks
 
     def real_chunks(self) -> int:
-        return sum(self.n_chunks(i) for i in range(len(self.lengths)) if self.lengths[i] > 0)
+        live = self.lengths[self.lengths > 0]
+        return int(((live + self.chunk - 1) // self.chunk).sum())
 
 
 def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_chunks: int, plan: "RefillPlan" = None, on_slab=None):
@@ -917,14 +919,14 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
     on_gpu = dev.type == "cuda"
     as_i16, lengths = _describe(audios)
     dtype, esz = (torch.int16, 2) if as_i16 else (torch.float32, 4)
-    slots = max(1, min(int(slots), sum(1 for m in lengths if m > 0)))
-    plan = plan or RefillPlan(lengths, slots, slab_chunks, n)
+    lens_np = np.asarray(lengths, dtype=np.int64).reshape(-1)
+    slots = max(1, min(int(slots), int((lens_np > 0).sum())))
+    plan = plan or RefillPlan(lens_np, slots, slab_chunks, n)
     B, S, width = plan.slots, plan.slab_chunks, plan.slab_chunks * n
     mode = _upload_mode()
     src = _Sources(audios, dtype, check_pinned=on_gpu and mode != "stage" and hasattr(eng, "upload_rows"))
     direct = src.pinned                                # pinned recordings: one gather kernel per slab, no host copy
     how = 0 if mode == "dma" else 1
-    lens_np = np.asarray(lengths, dtype=np.int64)
     base = np.zeros(len(audios) + 1, dtype=np.int64)   # recording i owns out_flat[base[i] : base[i] + n_chunks(i)]
     np.cumsum(np.where(lens_np > 0, (lens_np + n - 1) // n, 0), out=base[1:])
     total = int(base[-1])
@@ -940,9 +942,10 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
             cur = torch.cuda.current_stream(dev)
             if pool is None:
                 pool = model._stage_pool = _StagePool(dev)
-                pool.stream = _distinct_queue_stream(getattr(model, "engine", None), dev, [cur])    # the upload beside the slab's kernels
+                pool.stream = _distinct_queue_stream(getattr(model, "engine", None), dev, [cur],    # the upload beside the slab's kernels
+                                                     priority=int(os.environ.get("SILERO_VAD_AMD_UPLOAD_PRIORITY", "0")))
         STATS["padded"] += plan.padded_chunks() * n
-        STATS["real"] += sum(m for m in lengths if m > 0)
+        STATS["real"] += int(lens_np[lens_np > 0].sum())
 
         ptr0 = src.ptr
         if on_gpu and hasattr(eng, "reserve"):
@@ -1060,7 +1063,7 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
     yielded as soon as its copy has landed (a slab or two behind the kernels; nothing here blocks the pipeline).  Probabilities
     never leave the GPU.  Segments are in samples of the net's rate (x[::k] for raw 32 / 48 kHz recordings)."""
     net_sr, dec, _ = _rates(sampling_rate)
-    lengths = np.asarray([(m + dec - 1) // dec for m in _describe(audios)[1]], dtype=np.int64)   # samples at the net's rate: the scan's unit
+    lengths = (np.asarray(_describe(audios)[1], dtype=np.int64).reshape(-1) + dec - 1) // dec     # samples at the net's rate: the scan's unit
     eng = model.engine
     on_gpu = hasattr(eng, "_h")
     if not on_gpu:                                                        # CPU stand-in engines (tests): scan at the end, on the host

@@ -2986,3 +2986,46 @@ def test_one_stream_step_is_bit_identical(model, golden, tag):
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(times, open(f"gpurun_out/step_one_call_ms_{tag}.json", "w"))
     assert times["auto"] < times["0"], times
+
+
+# ---- (35) the blocking host call: vad_step_host_sync against vad_step_host + a stream wait ----------------------------------------------
+@pytest.mark.parametrize("tag", ["16k", "8k"])
+def test_step_host_sync_returns_the_same_bits_as_step_host_and_a_stream_wait(model, golden, tag):
+    """vad_step_host_sync watches the page-locked probability slots instead of the stream (the kernels store a stream's probability last):
+    over chains of steps it must hand back EXACTLY what vad_step_host + synchronize does -- probabilities, carried state and context --
+    for B = 1 (one-stream kernel), 8, 9 and 16 (tile kernels), fp32 and int16 chunks, and a stream whose input turns NaN (its
+    probability is NaN: a slot that changes to NaN has changed)."""
+    eng = model.engine
+    sr, g = SRS[tag], golden[tag]
+    n = chunk_of(sr)
+    dev = model.device
+    T = 10
+    for B, dtype in ((1, torch.float32), (1, torch.int16), (8, torch.float32), (9, torch.int16), (16, torch.float32)):
+        rows = rolled_rows(g["wav"], B, T * n, 2111)
+        if B > 1 and dtype == torch.float32:
+            rows[1, 4 * n + 3] = np.nan
+        if dtype == torch.int16:
+            rows = np.clip(np.round(rows * 32768.0), -32768, 32767).astype(np.int16)
+        x = torch.from_numpy(rows)
+        res = []
+        for sync in (False, True):
+            pcm = torch.empty((B, n), dtype=dtype, pin_memory=True)
+            prob = torch.empty((B,), dtype=torch.float32, pin_memory=True)
+            ctx = torch.zeros((B, n // 8), dtype=torch.float32, device=dev)
+            st = torch.zeros((2, B, 128), dtype=torch.float32, device=dev)
+            out = np.empty((T, B), dtype=np.float32)
+            for t in range(T):
+                pcm.copy_(x[:, t * n:(t + 1) * n])
+                if sync:
+                    eng.step_host_sync(pcm, sr, ctx, st, prob)
+                else:
+                    eng.step_host(pcm, None, sr, ctx, st, None, prob)
+                    torch.cuda.synchronize()
+                out[t] = prob.numpy()
+            torch.cuda.synchronize()
+            res.append((out, st.cpu().numpy(), ctx.cpu().numpy()))
+        (p0, s0, c0), (p1, s1, c1) = res
+        assert p0.tobytes() == p1.tobytes() and s0.tobytes() == s1.tobytes() and c0.tobytes() == c1.tobytes(), (tag, B, dtype)
+        if B > 1 and dtype == torch.float32:
+            assert np.isnan(p1[4:, 1]).all() and np.isfinite(np.delete(p1, 1, axis=1)).all()
+        assert np.isfinite(p1[:4]).all() and (p1[:4] >= 0).all() and (p1[:4] <= 1).all()

@@ -140,6 +140,36 @@ def test_refill_plan_covers_every_sample_once():
         assert plan.padded_chunks() >= plan.real_chunks()
 
 
+def test_refill_table_equals_its_numpy_definition():
+    """vad_refill_table (native, two counting passes) against the definition it replaced: repeat every queue entry over its slabs, sort
+    the rows by (slab, slot)."""
+    import ctypes
+    from silero_vad_amd._lib import lib
+    rng = np.random.default_rng(9)
+    lp = ctypes.POINTER(ctypes.c_long)
+    for n, slots, width in ((0, 3, 1024), (1, 1, 512), (300, 7, 2048), (2000, 64, 4096)):
+        lens = rng.integers(1, 40 * width // 3, size=n).astype(np.int64)
+        rec = rng.permutation(n).astype(np.int64)
+        need = np.ascontiguousarray((lens + width - 1) // width)
+        start, slot = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+        assert lib().vad_refill_schedule(need.ctypes.data_as(lp), n, slots, start.ctypes.data_as(lp), slot.ctypes.data_as(lp)) == 0
+        n_slabs = int((start + need).max()) if n else 0
+        rows = np.empty((int(need.sum()), 5), dtype=np.int64)
+        cuts = np.zeros(n_slabs + 1, dtype=np.int64)
+        got = lib().vad_refill_table(need.ctypes.data_as(lp), start.ctypes.data_as(lp), slot.ctypes.data_as(lp), rec.ctypes.data_as(lp),
+                                     lens.ctypes.data_as(lp), n, slots, width, n_slabs, rows.ctypes.data_as(lp), cuts.ctypes.data_as(lp))
+        assert got == len(rows)
+        reps = np.repeat(np.arange(n), need)
+        j = np.arange(len(reps)) - np.repeat(np.cumsum(need) - need, need)
+        at = j * width
+        want = np.stack([slot[reps], rec[reps], at, np.minimum(width, lens[reps] - at), (j == 0).astype(np.int64)], 1).reshape(-1, 5)
+        slab_of = start[reps] + j
+        order = np.lexsort((want[:, 0], slab_of))
+        assert np.array_equal(rows, want[order])
+        assert np.array_equal(cuts, np.searchsorted(slab_of[order], np.arange(n_slabs + 1)))
+    assert lib().vad_refill_table(None, None, None, None, None, 1, 1, 512, 1, None, cuts.ctypes.data_as(lp)) < 0
+
+
 def test_refill_plan_retires_something_early():
     """Longest-first admission alone retires nothing before the longest recordings end; a sixteenth of the slots start with the
     shortest recordings instead, without lengthening the schedule."""
