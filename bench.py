@@ -1016,7 +1016,7 @@ def run_plumbing(args, local, sr=16000):
     secs = len(wav) / sr
     return {"workload": f"configs[0]: the reference's fixture ({secs:.0f} s, {sr // 1000} kHz) through the reference's per-chunk protocol, B = 1",
             "per_call_latency_ms": {"eager_model_call_item": eager_ms, "hipgraph_step_item": graph_ms,
-                                    "note": "host chunk in -> float out, median of 400 calls (H2D of the chunk, one fused kernel, D2H of the probability)"},
+                                    "note": "host chunk in -> float out, median of 400 calls.  eager: 2 KB into page-locked memory, ONE kernel (one workgroup per stream) that reads it in place and stores the probability into page-locked memory, the call returns when that slot has changed (vad_step_host_sync); hipgraph: a 1-stream StreamPool tick (H2D, fused step, D2H, stream wait)"},
             f"get_speech_timestamps_{secs:.0f}s": {"segments": len(ts_fast), "one_call_fast_path_ms": round(fast_s * 1e3, 2),
                                                   "per_chunk_protocol_ms": round(chunk_s * 1e3, 1), "chunks": chunks,
                                                   "per_chunk_protocol_ms_per_chunk": round(chunk_s * 1e3 / chunks, 4),

@@ -151,7 +151,8 @@ int  vad_step_host(vad_engine *e, int sr, int B, const void *host_pcm, size_t el
  * get_speech_timestamps, :528 VADIterator.__call__; examples/cpp/silero-vad-onnx.cpp:103-142 around session.Run).  The kernels store a
  * stream's probability as their last act, so the call waits for the B slots themselves to change (a bounded spin on the page-locked
  * memory; hipStreamSynchronize if they have not after 0.4 ms) instead of for the stream's completion signal.  ctx / state are device
- * buffers as in vad_step; later work on `stream` is ordered behind the step as usual.                                          */
+ * buffers as in vad_step; later work on `stream` is ordered behind the step as usual.  A blocking call: not inside a stream capture
+ * (capture vad_step_host).                                                                                                      */
 int  vad_step_host_sync(vad_engine *e, int sr, int B, const void *host_pcm, size_t elem_size, float *ctx, float *state, float *host_prob,
                         void *stream);
 
