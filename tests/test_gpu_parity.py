@@ -3029,3 +3029,57 @@ def test_step_host_sync_returns_the_same_bits_as_step_host_and_a_stream_wait(mod
         if B > 1 and dtype == torch.float32:
             assert np.isnan(p1[4:, 1]).all() and np.isfinite(np.delete(p1, 1, axis=1)).all()
         assert np.isfinite(p1[:4]).all() and (p1[:4] >= 0).all() and (p1[:4] <= 1).all()
+
+
+# ---- (36) the remembered B = 1 call (HipSileroVAD.__call__) against the general path ------------------------------------------------------
+def test_remembered_model_call_equals_the_general_path(model, golden):
+    """`model(chunk, sr)` remembers a B = 1 CPU call and issues the next identical-looking one without the front-door checks.  Drive two
+    model objects with the same mixed sequence -- 1-D and [1, n] chunks, float32 / int16 / float64, a second stream, reset_states, a
+    caller-replaced state, an 8 kHz interlude, a B = 2 call -- one of them with the memory wiped before every call: same bits."""
+    from silero_vad_amd import load_silero_vad
+    a = load_silero_vad(device=model.device.index or 0)
+    b = load_silero_vad(device=model.device.index or 0)
+    wav16, wav8 = golden["16k"]["wav"], golden["8k"]["wav"]
+    side = torch.cuda.Stream(model.device)
+    seq = []
+    for t in range(6):
+        seq.append(("call", torch.from_numpy(wav16[t * 512:(t + 1) * 512].copy()), 16000))
+    seq.append(("call", torch.from_numpy(wav16[6 * 512:7 * 512].copy()).unsqueeze(0), 16000))
+    seq.append(("call", torch.from_numpy((wav16[7 * 512:8 * 512] * 32767).astype(np.int16)), 16000))
+    seq.append(("call", torch.from_numpy((wav16[8 * 512:9 * 512] * 32767).astype(np.int16)), 16000))
+    seq.append(("call", torch.from_numpy(wav16[9 * 512:10 * 512].astype(np.float64)), 16000))
+    seq.append(("side", torch.from_numpy(wav16[10 * 512:11 * 512].copy()), 16000))
+    seq.append(("call", torch.from_numpy(wav16[11 * 512:12 * 512].copy()), 16000))
+    seq.append(("state", None, None))
+    seq.append(("call", torch.from_numpy(wav16[12 * 512:13 * 512].copy()), 16000))
+    seq.append(("call", torch.from_numpy(wav16[13 * 512:14 * 512].copy()), 16000))
+    seq.append(("reset", None, None))
+    for t in range(3):
+        seq.append(("call", torch.from_numpy(wav8[t * 256:(t + 1) * 256].copy()), 8000))
+    seq.append(("call", torch.from_numpy(wav16[:1024].reshape(2, 512).copy()), 16000))
+    seq.append(("call", torch.from_numpy(wav16[1024:1536].copy()), 16000))
+    seq.append(("call", torch.from_numpy(wav16[1536:2048].copy()), 16000))
+    outs = []
+    for m, wipe in ((a, False), (b, True)):
+        got = []
+        used = 0
+        for what, x, sr in seq:
+            if wipe:
+                m._fast = None
+            if what == "reset":
+                m.reset_states()
+            elif what == "state":
+                m._state = (m._state * 0.5).clone()
+            elif what == "side":
+                with torch.cuda.stream(side):
+                    got.append(m(x, sr).numpy().copy())
+                side.synchronize()
+            else:
+                used += m._fast is not None
+                got.append(m(x, sr).numpy().copy())
+        torch.cuda.synchronize()
+        outs.append((got, m._state.cpu().numpy(), m._context.cpu().numpy(), used))
+    (ga, sa, ca, ua), (gb, sb, cb, ub) = outs
+    assert ub == 0 and ua >= 8                                      # the remembered call was actually taken, and never on the wiped model
+    assert len(ga) == len(gb) and all(x.shape == y.shape and x.tobytes() == y.tobytes() for x, y in zip(ga, gb))
+    assert sa.tobytes() == sb.tobytes() and ca.tobytes() == cb.tobytes()
