@@ -270,6 +270,7 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
     const long slab = e->slab_steps;
     const bool prof = e->profile;
     if (prof) e->prof_calls++;
+    bool ctx_in_place = false;                           // the kernel wrote the next context into `ctx` itself (one-stream fused step)
     for (long t0 = 0; t0 < T; t0 += slab) {
         const long nt = std::min(slab, T - t0);
         vad::FrontArgs fa{};
@@ -321,9 +322,15 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
             ca.probs = probs;
             ca.ldp = ldp;
             ca.present = present;
-            // a handful of streams (the B = 1 call of every unmodified caller): one workgroup per stream, the same sums on the VALU
-            if (one) HIP_TRY(e, vad::launch_step_one<PcmT>(sr, fa, ca, stream));
-            else HIP_TRY(e, vad::launch_step_lat<PcmT>(sr, fa, ca, stream));
+            // a handful of streams (the B = 1 call of every unmodified caller): one workgroup per stream, the same sums on the VALU --
+            // and the context in place (one workgroup owns the stream: no second buffer, no copy operation behind the kernel)
+            if (one) {
+                if (!ctx_next) {
+                    fa.ctx_out = ctx;
+                    ctx_in_place = true;
+                }
+                HIP_TRY(e, vad::launch_step_one<PcmT>(sr, fa, ca, stream));
+            } else HIP_TRY(e, vad::launch_step_lat<PcmT>(sr, fa, ca, stream));
             if (prof) {
                 HIP_TRY(e, hipEventRecord(ev[1], stream));
                 HIP_TRY(e, hipEventRecord(ev[2], stream));
@@ -361,8 +368,8 @@ int forward_core(vad_engine *e, int sr, int dec, int B, long L, const PcmT *pcm,
     }
     // rows without a chunk this tick: the step kernels left their (h, c) and probability alone; carry their context over and mark
     // their probability slot (kernel_present.hip)
-    if (present) HIP_TRY(e, vad::launch_carry_absent(present, ctx, ctx_next ? ctx_next : e->d_ctx_new, C, probs, ldp, B, stream));
-    if (!ctx_next) HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (present) HIP_TRY(e, vad::launch_carry_absent(present, ctx, ctx_next ? ctx_next : ctx_in_place ? nullptr : e->d_ctx_new, C, probs, ldp, B, stream));
+    if (!ctx_next && !ctx_in_place) HIP_TRY(e, hipMemcpyAsync(ctx, e->d_ctx_new, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return VAD_OK;
 }
 

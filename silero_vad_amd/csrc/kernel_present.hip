@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) carry_absent_kernel(const uint8_t *__rest
     const int v = (int)(i - b * vec_per_row);
     if (b >= B || present[b]) return;
     const size_t off = (size_t)b * vec_per_row + v;
-    reinterpret_cast<f32x4 *>(ctx_out)[off] = reinterpret_cast<const f32x4 *>(ctx_in)[off];
+    if (ctx_out != nullptr) reinterpret_cast<f32x4 *>(ctx_out)[off] = reinterpret_cast<const f32x4 *>(ctx_in)[off];     // (null: the step kernel left the absent rows' context where it was)
     if (v == 0) probs[(size_t)b * ldp] = VAD_PROB_ABSENT;
 }
 

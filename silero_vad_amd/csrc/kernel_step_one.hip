@@ -196,9 +196,15 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
     // exchange through LDS (the wave's own 2 KB), every lane runs the in-lane Q-point FFT.
     float *sbuf = reinterpret_cast<float *>(&ws) + (w * 4 + ln.g) * SL;                                     // [wave][g][2Q] samples
     f32x2 *zbuf = reinterpret_cast<f32x2 *>(reinterpret_cast<float *>(&ws) + 4 * 4 * SL) + w * 4 * Q;       // [wave][g][Q]
+    // The context for the next call is slice 8 (frame 3, lane group 2).  With a second buffer load_slice stores it as the tile kernels do;
+    // IN PLACE (ctx_out == ctx_in: what vad_step hands over -- no second buffer, no 256-byte copy operation behind the kernel) it is
+    // taken from the exchange buffer once every wave has its samples and stored behind the frontend, for a stream that has a chunk this tick.
+    const bool ctx_inplace = a.ctx_out != nullptr && a.ctx_out == a.ctx_in;
     {
         float pcm_s[SL];
-        load_slice<Q, PcmT, 1>(pcm_s, a, ln, w);                    // (the context for the next call is written by load_slice)
+        FrontArgs al = a;
+        if (ctx_inplace) al.ctx_out = nullptr;
+        load_slice<Q, PcmT, 1>(pcm_s, al, ln, w);
         VAD_PIN();
         {   // tables -> LDS
             constexpr int NV = tb.total / 4;
@@ -214,6 +220,8 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
     }
     lds_barrier();
     VAD_STAMP(1);
+    f32x4 ctx_new{};                                               // (kept in registers: the double-precision route reads the OLD context)
+    if (ctx_inplace && tid < SL / 4) ctx_new = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(&ws) + (3 * 4 + 2) * SL)[tid];
     {
         const int q = ln.j & (H - 1);
         const float *win = tab + tb.window + SL * ln.g;
@@ -509,6 +517,11 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
         g0 = tab[tb.b_g + tid];
         g1 = tab[tb.b_g + tid + 256];
         run2<8>(Wi0, Wi1, g0, g1, fec, fec);
+    }
+    if (ctx_inplace && tid < SL / 4) {
+        bool here = true;
+        if constexpr (CELL) here = cell.present == nullptr || cell.present[b] != 0;
+        if (here) reinterpret_cast<f32x4 *>(a.ctx_out + (size_t)b * SL)[tid] = ctx_new;
     }
     if constexpr (!CELL) {
         // gx[tile][row block 32][lane 64][4] (layout.hpp): row 16 mb + 4 g + r of column j at lane 16 g + j, element r
