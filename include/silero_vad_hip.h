@@ -108,11 +108,12 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *                 cell state integrates it: 4.6e-5 one chunk into a silence, 1e-5 with the constant).  "0": the fp32 chains everywhere,
  *                 "edges": without the constant (A/B for tests and studies).
  *                 fp32 frontend only (not with front_mma = bf16x9)
- *   "step_one"  = "auto" (default: 8) | "0".."4096": a ONE-step call of at most this many streams (the B = 1 `model(chunk, sr)` of every
- *                 unmodified caller) takes one workgroup per STREAM (csrc/kernel_step_one.hip: every sum of the step as an fmaf chain
- *                 on the VALU in the MFMA program's summation order, read from the same packed weight images -- bit-identical to the
- *                 tile kernels, 25 us instead of 32 for B = 1 because no matrix instruction computes 16 columns for one stream);
- *                 "0": the 16-stream tile kernels for every batch (A/B for tests)
+ *   "step_one"  = "auto" (default: 256, the number of CUs) | "0".."4096": a ONE-step call of at most this many streams (the B = 1
+ *                 `model(chunk, sr)` of every unmodified caller; a tick of a small stream pool) takes one workgroup per STREAM
+ *                 (csrc/kernel_step_one.hip: every sum of the step as an fmaf chain on the VALU in the MFMA program's summation order,
+ *                 read from the same packed weight images -- bit-identical to the tile kernels; 25.0-26.5 us for 1..256 streams against
+ *                 31.4-34.2 us, because no matrix instruction computes 16 columns for one stream and every stream has a CU to itself;
+ *                 beyond one workgroup per CU the tile kernels win); "0": the 16-stream tile kernels for every batch (A/B for tests)
  *   "fused_decimation" = "1" (default) | "0": for sr = 32000 and 48000 the fp32 frontend reads every 2nd / 3rd sample
  *                 itself; "0" forces the separate decimation pass that the higher multiples of 16000 use (A/B for tests)
  *   "profile"   = "0" | "1"   record hipEvents around each kernel (vad_kernel_times)

@@ -80,7 +80,7 @@ struct vad_engine {
     bool exact_all_silent = true;                   // ... and all-silent chunks take the net's constant (false: option exact_transitions=edges, study mode)
     bool exact_transitions = true;                  // chunks with an exactly silent frame beside a non-silent one are evaluated in double
                                                     // (option "exact_transitions"; csrc/exact_front.hpp)
-    int one_max = 8;                                // a ONE-step call of at most this many streams takes the one-workgroup-per-stream kernel
+    int one_max = 256;                              // a ONE-step call of at most this many streams takes the one-workgroup-per-stream kernel
                                                     // (kernel_step_one.hip; option "step_one": auto | 0 | <max streams>)
     long lat_tiles = 768;                           // launches of at most this many 16-chunk tiles take the latency form of the frontend
                                                     // (option "front": auto | throughput | latency -> 768 | 0 | LONG_MAX)
@@ -638,7 +638,7 @@ int vad_set_option(vad_engine *e, const char *name, const char *value) {
         return VAD_OK;
     }
     if (n == "step_one") {                           // one-step calls of at most N streams: one workgroup per stream ("0": never; A/B for tests)
-        if (v == "auto") e->one_max = 8;
+        if (v == "auto") e->one_max = 256;           // one workgroup per CU: 25.0-26.5 us for 1..256 streams, the tile kernels 31.4-34.2 (512: 47.7 / 34.4)
         else {
             char *end = nullptr;
             const long k = std::strtol(v.c_str(), &end, 10);

@@ -8,11 +8,11 @@ from silero_vad_amd import load_silero_vad
 m = load_silero_vad(device=0)
 eng = m.engine
 for sr, n in ((16000, 512), (8000, 256)):
-    for B in (1, 2, 4, 8):
+    for B in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512):
         x = torch.randn((B, n), device=m.device) * 0.1
         ctx = torch.zeros((B, n // 8), device=m.device); st = torch.zeros((2, B, 128), device=m.device); p = torch.empty((B,), device=m.device)
         res = {}
-        for one in ("0", "auto"):
+        for one in ("0", "4096"):
             eng.set_option("step_one", one)
             for _ in range(50): eng.step(x, sr, ctx, st, p)
             torch.cuda.synchronize()
@@ -23,4 +23,4 @@ for sr, n in ((16000, 512), (8000, 256)):
             eng.set_option("profile", "0")
             res[one] = round(f / c * 1e3, 2)
         eng.set_option("step_one", "auto")
-        print(sr, "B", B, "kernel us: tile", res["0"], "one-stream", res["auto"])
+        print(sr, "B", B, "kernel us: tile", res["0"], "one-stream", res["4096"])
