@@ -7,9 +7,13 @@
 //     (tools/ubench/mfma_order.hip: 1 048 576 of 1 048 576 outputs), k-groups ascending -- so that the same fmaf chain gives the SAME
 //     BITS: position 16 kg + 4 r + g of the chain is hidden unit 16 kg + 4 g + r (layout.hpp "whh_rows");
 //   * h_{t-1} lies in LDS in chain order and is read as broadcast 16-byte vectors; per step and stream 128 fmaf per thread;
-//   * the four gates of a unit meet in LDS; 32 threads per stream -- thread (w, g) holds units 16 w + 4 g + r, r < 4, exactly what a
-//     lane of rec_kernel holds -- do the pointwise update with the same formulas (activations.hpp) and reduce the head's dot
-//     product in rec_kernel's order: fmaf chain over r, ((p0 + p1) + (p2 + p3)) over g, then w = 0..7 onto the bias.
+//   * the four gates of a unit meet in LDS; 128 threads per stream do the pointwise update, one unit each, with the same formulas
+//     (activations.hpp); 32 threads per stream -- thread (w, g) holds units 16 w + 4 g + r, r < 4, exactly what a lane of rec_kernel
+//     holds -- reduce the head's dot product in rec_kernel's order: fmaf chain over r, ((p0 + p1) + (p2 + p3)) over g, then w = 0..7 onto
+//     the bias -- one step behind, beside the next step's products (the head is not on the recurrence's critical path).
+//   What bounds a step is the LDS pipe, not the VALU: every wave reads all of h as 32 broadcast 16-byte vectors per stream and step (8
+//   waves x 32 x 8 cycles = 2 048 of a step's ~2 300 cycles).  Two rows per thread with packed fmas halve the waves but need 256 weight
+//   registers a thread -- half of them AGPRs the VALU cannot read directly: measured 1.6 x slower.
 // Every workgroup carries 1, 2 or 4 streams -- as few as put B streams on the chip's 256 CUs at once -- and a step costs 1.21 / 1.67 /
 // 2.65 us against rec_kernel's 4.34 whatever the batch: a single 60 s file 8.1 -> 2.3 ms, a bucket of 300 recordings 1.7 us per step.
 // The engine takes this kernel for B <= 1 024 (option "rec_form" = auto | mfma); above that rec_kernel's 16 streams per CU win.
@@ -48,23 +52,43 @@ __global__ void __launch_bounds__(512, 1) rec_small_kernel(const RecArgs a) {
     const int w = n >> 4, g = (n >> 2) & 3, r = n & 3;
     const float *gxp = a.gx + ((size_t)(b0 >> 4) * a.nt * 32) * 256 + ((size_t)(8 * q + w) * 64 + g * 16 + (b0 & 15)) * 4 + r;   // + t * 32 * 256 + 4 j
 
-    // pointwise role: thread (pj, pw, pg) holds units 16 pw + 4 pg + rr of stream pj
-    const bool pt = tid < 32 * NB;
-    const int pj = tid >> 5, pw = (tid & 31) >> 2, pg = tid & 3;
+    // pointwise role: thread (pj, pu) holds unit pu of stream pj -- one unit per thread (128 threads per stream): the five activations of a
+    // unit are ~100 dependent VALU instructions, and this phase sits between two barriers on the critical path of every step
+    const bool pt = tid < 128 * NB;
+    const int pj = tid >> 7, pu = tid & 127, ppos = (pu & ~15) + 4 * (pu & 3) + ((pu >> 2) & 3);      // chain position of unit pu
     const long pb = b0 + (pj < nb ? pj : nb - 1);          // this thread's stream (clamped: lanes of missing streams compute, never store)
     const bool pvalid = pt && pj < nb && (a.present == nullptr || a.present[pb] != 0);   // (an absent row keeps its state: vad_step_present)
-    f32x4 h = {0.f, 0.f, 0.f, 0.f}, c = h, wo = h;
-    float bo = 0.f;
-    size_t soff = 0;
+    float h = 0.f, c = 0.f;
     if (pt) {
-        soff = (size_t)pb * 128 + 16 * pw + 4 * pg;
-        h = *reinterpret_cast<const f32x4 *>(a.state + soff);
-        c = *reinterpret_cast<const f32x4 *>(a.state + (size_t)a.B * 128 + soff);
-        wo = 0.5f * *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * pw + 4 * pg);   // halved: relu2_f (activations.hpp)
-        bo = a.tables[NTAB_BOUT];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) hs[0][pj][16 * pw + 4 * rr + pg] = h[rr];
+        h = a.state[(size_t)pb * 128 + pu];
+        c = a.state[((size_t)a.B + pb) * 128 + pu];
+        hs[0][pj][ppos] = h;
     }
+    // head role: thread (hj, hw, hg) holds units 16 hw + 4 hg + rr, rr < 4, of stream hj -- what a lane of rec_kernel holds -- and forms the
+    // head's dot product in rec_kernel's order from the h the pointwise threads left in LDS.  Off the critical path: the head of step t
+    // is formed at the start of step t + 1, beside the other waves' matrix-vector products.
+    const bool ht = tid < 32 * NB;
+    const int hj = tid >> 5, hw = (tid & 31) >> 2, hg = tid & 3;
+    const long hb = b0 + (hj < nb ? hj : nb - 1);
+    const bool hvalid = ht && hj < nb && hw == 0 && hg == 0 && (a.present == nullptr || a.present[hb] != 0);
+    f32x4 wo = {0.f, 0.f, 0.f, 0.f};
+    float bo = 0.f;
+    if (ht) {
+        wo = 0.5f * *reinterpret_cast<const f32x4 *>(a.tables + NTAB_WOUT + 16 * hw + 4 * hg);   // halved: relu2_f (activations.hpp)
+        bo = a.tables[NTAB_BOUT];
+    }
+    auto head = [&](int buf, long t) {
+        if (!ht) return;
+        float part = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) part = fmaf(wo[rr], relu2_f(hs[buf][hj][16 * hw + 4 * rr + hg]), part);
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        float p = bo;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) p += __shfl(part, (tid & 32) + 4 * ww);
+        if (hvalid) a.probs[(size_t)hb * a.ldp + a.t0 + t] = sigmoid_f(p);
+    };
     float gnext[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) gnext[j] = gxp[4 * (j < nb ? j : nb - 1)];
@@ -72,6 +96,7 @@ __global__ void __launch_bounds__(512, 1) rec_small_kernel(const RecArgs a) {
 
     for (long t = 0; t < a.nt; ++t) {
         const int cur = (int)(t & 1);
+        if (t > 0) head(cur, t - 1);                       // hs[cur] = h_{t-1}: the output of the step before
         float acc[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = gnext[j];
@@ -92,37 +117,17 @@ __global__ void __launch_bounds__(512, 1) rec_small_kernel(const RecArgs a) {
         for (int j = 0; j < NB; ++j) gs[j][q][n] = acc[j];
         __syncthreads();
         if (pt) {
-            const int u0 = 16 * pw + 4 * pg;
-            const f32x4 gi = *reinterpret_cast<const f32x4 *>(&gs[pj][0][u0]), gf = *reinterpret_cast<const f32x4 *>(&gs[pj][1][u0]);
-            const f32x4 gg4 = *reinterpret_cast<const f32x4 *>(&gs[pj][2][u0]), go = *reinterpret_cast<const f32x4 *>(&gs[pj][3][u0]);
-            float th[4];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const float ig = sigmoid_f(gi[rr]), fg = sigmoid_f(gf[rr]), gg = tanh_f(gg4[rr]);
-                const float cn = fmaf(fg, c[rr], ig * gg);
-                c[rr] = cn;
-                th[rr] = tanh_f(cn);
-            }
-            float part = 0.f;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                h[rr] = sigmoid_f(go[rr]) * th[rr];
-                part = fmaf(wo[rr], relu2_f(h[rr]), part);
-            }
-            part += __shfl_xor(part, 1);
-            part += __shfl_xor(part, 2);
-            float p = bo;
-#pragma unroll
-            for (int ww = 0; ww < 8; ++ww) p += __shfl(part, (tid & 32) + 4 * ww);
-            if (pvalid && pw == 0 && pg == 0) a.probs[(size_t)pb * a.ldp + a.t0 + t] = sigmoid_f(p);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) hs[cur ^ 1][pj][16 * pw + 4 * rr + pg] = h[rr];
+            const float ig = sigmoid_f(gs[pj][0][pu]), fg = sigmoid_f(gs[pj][1][pu]), gg = tanh_f(gs[pj][2][pu]);
+            c = fmaf(fg, c, ig * gg);
+            h = sigmoid_f(gs[pj][3][pu]) * tanh_f(c);
+            hs[cur ^ 1][pj][ppos] = h;
         }
         __syncthreads();
     }
+    head((int)(a.nt & 1), a.nt - 1);
     if (pvalid) {
-        *reinterpret_cast<f32x4 *>(a.state + soff) = h;
-        *reinterpret_cast<f32x4 *>(a.state + (size_t)a.B * 128 + soff) = c;
+        a.state[(size_t)pb * 128 + pu] = h;
+        a.state[((size_t)a.B + pb) * 128 + pu] = c;
     }
 }
 
