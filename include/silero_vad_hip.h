@@ -84,7 +84,7 @@ int  vad_geometry(int sr, int *chunk, int *context);
  *                 exact), but a different summation: opt-in; measured against a float64 recurrence by the GPU suite
  *   "rec_form"  = "auto" (default) | "mfma": the fp32 recurrence has two forms with bit-identical results -- 16 streams per CU on the
  *                 matrix pipe (csrc/kernel_rec.hip: 4.3 us per step whatever the batch) and, for B <= 1024, W_hh h as fmaf chains on the
- *                 VALU in the MFMA chain's summation order, 1-4 streams per CU (csrc/kernel_rec_small.hip: 1.2-2.7 us per step; a file
+ *                 VALU in the MFMA chain's summation order, 1-4 streams per CU (csrc/kernel_rec_small.hip: 1.0-2.6 us per step; a file
  *                 at a time).  "mfma" forces the first (tests; callers that overlap several calls and want a call on few CUs)
  *   "front_mma" = "fp32" (default) | "bf16x9": the same for the frontend's matrix products (encoders 0-3 and W_ih): the fp32 MFMA
  *                 chain, or exact bf16 x 9 piece products (csrc/kernel_front_b9.hip; FFT, Winograd transforms, Nyquist update,

@@ -11,11 +11,13 @@
 //     (activations.hpp); 32 threads per stream -- thread (w, g) holds units 16 w + 4 g + r, r < 4, exactly what a lane of rec_kernel
 //     holds -- reduce the head's dot product in rec_kernel's order: fmaf chain over r, ((p0 + p1) + (p2 + p3)) over g, then w = 0..7 onto
 //     the bias -- one step behind, beside the next step's products (the head is not on the recurrence's critical path).
-//   What bounds a step is the LDS pipe, not the VALU: every wave reads all of h as 32 broadcast 16-byte vectors per stream and step (8
-//   waves x 32 x 8 cycles = 2 048 of a step's ~2 300 cycles).  Two rows per thread with packed fmas halve the waves but need 256 weight
-//   registers a thread -- half of them AGPRs the VALU cannot read directly: measured 1.6 x slower.
-// Every workgroup carries 1, 2 or 4 streams -- as few as put B streams on the chip's 256 CUs at once -- and a step costs 1.21 / 1.67 /
-// 2.65 us against rec_kernel's 4.34 whatever the batch: a single 60 s file 8.1 -> 2.3 ms, a bucket of 300 recordings 1.7 us per step.
+//   h reaches the fmas through DPP row broadcasts from 8 registers per lane, not through 32 broadcast LDS reads per thread and step: those
+//   kept the LDS pipe busy for 2 048 of a step's ~2 300 cycles (8 waves x 32 x 8), twice what the VALU needs.  (Two rows per thread with
+//   packed fmas halve the waves instead but need 256 weight registers a thread -- half of them AGPRs the VALU cannot read directly:
+//   measured 1.6 x slower.)
+// Every workgroup carries 1, 2 or 4 streams -- as few as put B streams on the chip's 256 CUs at once -- and a step costs 1.04 (one file;
+// 1.37 with 256 of them) / 1.70 / 2.62 us against rec_kernel's 4.34 whatever the batch (tools/rec_small_time.py): a single 60 s file
+// 8.1 -> 1.94 ms.
 // The engine takes this kernel for B <= 1 024 (option "rec_form" = auto | mfma); above that rec_kernel's 16 streams per CU win.
 // (reference: aten::lstm_cell, JIT!/torch/nn/modules/rnn.py:69, gate order i,f,g,o; JIT!/vad/model/vad_annotator.py:170-187; head
 //  JIT!/torch/nn/modules/container/___torch_mangle_7.py:10-19.)
@@ -29,6 +31,21 @@ namespace vad {
 namespace {
 
 using f32x4 = float __attribute__((ext_vector_type(4)));
+
+// acc = fma(h of lane I of this 16-lane row, w, acc): v_fmac_f32 with its first operand through DPP row_newbcast (gfx90a+)
+template <int I>
+__device__ __forceinline__ void fmac_bcast(float &acc, float h, float w) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h), "v"(w), "n"(I));
+}
+// the 16 chain positions 16 v .. 16 v + 15 of every stream of the workgroup, the streams' chains interleaved instruction by instruction
+template <int NB, int I = 0>
+__device__ __forceinline__ void fmac_row(float (&acc)[NB], const float (&hreg)[NB][8], const float (&W)[128], const int v) {
+    if constexpr (I < 16) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fmac_bcast<I>(acc[j], hreg[j][v], W[16 * v + I]);
+        fmac_row<NB, I + 1>(acc, hreg, W, v);
+    }
+}
 
 template <int NB, int NTAB_WOUT, int NTAB_BOUT>
 __global__ void __launch_bounds__(512, 1) rec_small_kernel(const RecArgs a) {
@@ -104,15 +121,17 @@ __global__ void __launch_bounds__(512, 1) rec_small_kernel(const RecArgs a) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) gnext[j] = gxp[(size_t)(t + 1) * 32 * 256 + 4 * (j < nb ? j : nb - 1)];
         }
+        // h as 8 registers per stream: lane l of every 16-lane row holds h[16 v + l % 16] in register v, and the fma takes its h operand
+        // through the data-parallel-primitive path -- row_newbcast:i hands lane i of the row to all 16 lanes -- so the chain
+        // acc = fma(h[k], W[k], acc), k ascending, costs 128 VALU instructions and 8 four-byte LDS reads per thread, not 32 broadcast
+        // 16-byte reads: those were 8 waves x 32 x 8 cycles = 2 048 cycles of LDS pipe per step, twice the VALU's 1 024
+        float hreg[NB][8];
 #pragma unroll
-        for (int m = 0; m < 32; ++m) {
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const f32x4 hv = *reinterpret_cast<const f32x4 *>(&hs[cur][j][4 * m]);
+            for (int v = 0; v < 8; ++v) hreg[j][v] = hs[cur][j][16 * v + (tid & 15)];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j] = fmaf(W[4 * m + e], hv[e], acc[j]);
-            }
-        }
+        for (int v = 0; v < 8; ++v) fmac_row<NB>(acc, hreg, W, v);
 #pragma unroll
         for (int j = 0; j < NB; ++j) gs[j][q][n] = acc[j];
         __syncthreads();
