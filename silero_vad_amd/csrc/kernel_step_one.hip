@@ -510,13 +510,28 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
             if (pos < 4) f = __uint_as_float(__float_as_uint(f) | __float_as_uint(poison_g[pos]));     // positions 0..3 = (kg 0, ks 0, g)
             fec[pos] = f;
         }
-        if constexpr (CELL) ask(Wh0, wh0);
         lds_barrier();
         VAD_STAMP(7);
-        // ---- W_ih: gate rows tid and tid + 256 ---------------------------------------------------------------------------------------------
+        // ---- W_ih: gate rows tid and tid + 256.  The first row's W_hh is asked for BETWEEN the k-groups: a vector-memory request waits until
+        // the CU's memory path has room for it, so a block of 32 requests stops the wave for as long as the path needs for them (~4 000
+        // cycles); spread over the chain they are taken while the wave computes.
         g0 = tab[tb.b_g + tid];
         g1 = tab[tb.b_g + tid + 256];
-        run2<8>(Wi0, Wi1, g0, g1, fec, fec);
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+            if constexpr (CELL) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Wh0.a[kg][g] = *reinterpret_cast<const f32x4 *>(wh0 + kg * (8 * 256) + g * 64);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    g0 = fmaf(Wi0.a[kg][g][ks], fec[16 * kg + 4 * ks + g], g0);
+                    g1 = fmaf(Wi1.a[kg][g][ks], fec[16 * kg + 4 * ks + g], g1);
+                }
+            VAD_PIN();
+        }
     }
     if (ctx_inplace && tid < SL / 4) {
         bool here = true;
@@ -532,10 +547,18 @@ __global__ void __launch_bounds__(256) step_one_kernel(const FrontArgs a, const 
     } else {
         // ---- the LSTM cell: the gate chains continue into W_hh h_{t-1}; pointwise; head (kernel_front_lat.hip's order) ---------------------
         VAD_PIN();
-        Wh1.load(wh1, 8 * 256);
-        VAD_PIN();
         VAD_STAMP(8);
-        g0 = Wh0.run(g0, hc);
+        // (the second row's W_hh between the k-groups of the first row's chain, likewise)
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Wh1.a[kg][g] = *reinterpret_cast<const f32x4 *>(wh1 + kg * (8 * 256) + g * 64);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) g0 = fmaf(Wh0.a[kg][g][ks], hc[16 * kg + 4 * ks + g], g0);
+            VAD_PIN();
+        }
         gates[tid] = g0;
         g1 = Wh1.run(g1, hc);
         gates[tid + 256] = g1;
