@@ -41,6 +41,9 @@ __device__ __forceinline__ void fmac_bcast(float &acc, float h, float w) {
 template <int NB, int I = 0>
 __device__ __forceinline__ void fmac_row(float (&acc)[NB], const float (&hreg)[NB][8], const float (&W)[128], const int v) {
     if constexpr (I < 16) {
+        // (a DPP operand must not have been written by the VALU in the two instructions before: h comes straight from LDS loads, but the
+        //  hazard recogniser does not look into inline assembly, so the distance is made explicit once per row)
+        if constexpr (I == 0) asm volatile("s_nop 1");
 #pragma unroll
         for (int j = 0; j < NB; ++j) fmac_bcast<I>(acc[j], hreg[j][v], W[16 * v + I]);
         fmac_row<NB, I + 1>(acc, hreg, W, v);
