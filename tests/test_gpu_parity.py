@@ -8,6 +8,7 @@ Everything here needs a real MI355X:  python -m pytest tests -m gpu
 """
 import ctypes
 import os
+import sys
 import warnings
 
 import numpy as np
@@ -3090,3 +3091,14 @@ def test_remembered_model_call_equals_the_general_path(model, golden):
     assert ub == 0 and ua >= 8                                      # the remembered call was actually taken, and never on the wiped model
     assert len(ga) == len(gb) and all(x.shape == y.shape and x.tobytes() == y.tobytes() for x, y in zip(ga, gb))
     assert sa.tobytes() == sb.tobytes() and ca.tobytes() == cb.tobytes()
+
+
+# ---- (37) twenty thousand blocking calls in a row ---------------------------------------------------------------------------------------------
+def test_many_blocking_calls_equal_one_audio_forward_bit_for_bit():
+    """tools/call_stress.py, short: 20 000 `model(chunk, sr).item()` calls (vad_step_host_sync: the host watches the page-locked slot, not
+    the stream) over speech with digital silences at random places must give the bits of ONE audio_forward of the same signal -- no call
+    may return before its probability has landed, none may see its predecessor's."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "call_stress.py"), "20000"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "identical to one audio_forward: True" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
