@@ -4,7 +4,8 @@
  * header must be valid C and every entry point it uses must resolve); on a GPU box tests/test_gpu_parity.py also runs it: it streams
  * int16 chunks of `pcm_file` through vad_step_host (page-locked buffers from vad_host_register) and vad_iterator_feed and prints the
  * probabilities and events, which the test compares with the Python path's.
- *     client <weights> <pcm_int16_file> <sr> <streams> [pump | gaps]
+ *     client <weights> <pcm_int16_file> <sr> <streams> [sync | pump | gaps]
+ * With `sync` every tick is ONE blocking vad_step_host_sync (chunks read in place, probabilities stored into the page-locked buffer).
  * With `pump` the same loop runs on the native pump (vad_pump_create / slot / submit / poll / probs): the client writes the chunks into
  * the pump's page-locked ring, keeps two ticks in flight and prints each tick's probabilities and events as it is retired -- no HIP
  * call of its own at all.  With `gaps` the streams do not arrive in lock step: stream b has no chunk at tick t when
@@ -126,6 +127,7 @@ int main(int argc, char **argv) {
         return rc;
     }
 
+    const int blocking = argc > 5 && strcmp(argv[5], "sync") == 0;
     /* page-locked ingest buffer and probability buffer (what an audio server's network threads would write / read) */
     int16_t *host_pcm = (int16_t *)calloc((size_t)B * N, 2);
     float *host_prob = (float *)calloc((size_t)B, sizeof(float));
@@ -152,12 +154,18 @@ int main(int argc, char **argv) {
         /* stream b plays the recording from offset b * 7919 (circular), chunk by chunk */
         for (int b = 0; b < B; ++b)
             for (int i = 0; i < N; ++i) host_pcm[(size_t)b * N + i] = pcm[((long)b * 7919 + t * N + i) % samples];
-        rc = vad_step_host(e, sr, B, host_pcm, 2, dev_pcm, ctx, state, NULL, host_prob, NULL);
+        if (blocking) {
+            /* the blocking call (what session.Run is to the reference's client): the kernel reads host_pcm in place and stores the
+             * probabilities into host_prob; the call returns when they are there -- no staging buffer, no HIP call in the client */
+            rc = vad_step_host_sync(e, sr, B, host_pcm, 2, ctx, state, host_prob, NULL);
+        } else {
+            rc = vad_step_host(e, sr, B, host_pcm, 2, dev_pcm, ctx, state, NULL, host_prob, NULL);
+            if (rc == VAD_OK && hipStreamSynchronize(NULL) != 0) return 1;
+        }
         if (rc != VAD_OK) {
             fprintf(stderr, "vad_step_host: %s\n", vad_last_error(e));
             return 1;
         }
-        if (hipStreamSynchronize(NULL) != 0) return 1;
         printf("P %ld", t);
         for (int b = 0; b < B; ++b) printf(" %.9g", host_prob[b]);
         printf("\n");

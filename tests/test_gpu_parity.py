@@ -525,12 +525,12 @@ def test_stream_pool_host_int16_chunks_in_events_out(model, golden, tag):
         again.tick(torch.zeros((cap, n)))                 # a float chunk handed to an int16 pool
 
 
-@pytest.mark.parametrize("route", ["step_host", "pump"])
+@pytest.mark.parametrize("route", ["step_host", "sync", "pump"])
 @pytest.mark.parametrize("tag", ["16k", "8k"])
 def test_plain_c_client_streams_chunks_to_events(model, golden, tag, route, tmp_path):
     """A non-Python client (tests/c_client/client.c: C99 against include/silero_vad_hip.h, the shape of the reference's ONNX Runtime
-    clients, examples/cpp/silero-vad-onnx.cpp:103-142) streams the fixture through vad_step_host + vad_iterator_feed -- or, route
-    "pump", through the native pump (vad_pump_*: ring slot writes, submit, poll; two ticks in flight, no HIP call in the client):
+    clients, examples/cpp/silero-vad-onnx.cpp:103-142) streams the fixture through vad_step_host + vad_iterator_feed -- or, route "sync",
+    through the blocking vad_step_host_sync (no staging buffer, no HIP call in the client); or, route "pump", through the native pump (vad_pump_*: ring slot writes, submit, poll; two ticks in flight, no HIP call in the client):
     stream 0's probabilities equal the reference model's (golden) and its events EQUAL the reference VADIterator's; the other
     streams equal the Python path bit for bit."""
     import subprocess
@@ -544,7 +544,7 @@ def test_plain_c_client_streams_chunks_to_events(model, golden, tag, route, tmp_
     pcm.tofile(raw)
     exe = build_c_client(tmp_path)
     full = len(pcm) // n
-    r = subprocess.run([str(exe), str(_lib.WEIGHTS_PATH), str(raw), str(sr), "3"] + (["pump"] if route == "pump" else []),
+    r = subprocess.run([str(exe), str(_lib.WEIGHTS_PATH), str(raw), str(sr), "3"] + ([route] if route != "step_host" else []),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-500:]
     probs = np.array([[float(v) for v in l.split()[2:]] for l in r.stdout.splitlines() if l.startswith("P ")], dtype=np.float32)
