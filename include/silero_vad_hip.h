@@ -335,6 +335,12 @@ int  vad_pump_submit(vad_pump *p, int r);
  * the tick's first operation was queued poisons the pump (every later call fails): the carried state is half-advanced.          */
 uint8_t *vad_pump_present(vad_pump *p, int r);
 int  vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present);
+/* The same tick from a COMPACT slot: the sources wrote only the chunks of the streams that deliver, back to back -- row i of
+ * vad_pump_slot(p, r) is the chunk of the i-th stream (ascending) whose flag is set -- and only the flags, a position table and those
+ * rows cross the link (one copy); a row-expansion pass on the device puts every chunk where the step kernels read it.  Results are
+ * those of vad_pump_submit_present with the same flags, bit for bit; the link cost of a tick falls with the delivery rate.  present
+ * must not be NULL.  Compact, masked and full ticks may be mixed freely.                                                         */
+int  vad_pump_submit_compact(vad_pump *p, int r, const uint8_t *present);
 /* Retire the OLDEST submitted tick: wait for it (block != 0) or return VAD_PUMP_BUSY, run the iterator logic of every open
  * stream over its probabilities and write the tick's events (stream order; at most `cap`, the return value is how many there
  * were, <= streams).  *slot = the ring slot that is free again.  The probabilities stay readable in vad_pump_probs(p, slot)
@@ -368,6 +374,10 @@ long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long 
  * vad_pump_play.                                                                                                            */
 long vad_pump_play_gaps(vad_pump *p, const int16_t *rows, long ld, long period, const uint8_t *pattern, long pattern_ticks, long first_tick,
                         long n_ticks, int depth, int fill_threads, vad_iter_event *out, long cap, vad_pump_stats *st);
+/* vad_pump_play_gaps with compact slots: the sources write the delivering streams' chunks back to back (a source thread's first row is
+ * the number of delivering streams in front of its range) and every tick is a vad_pump_submit_compact.  Same events, same state.    */
+long vad_pump_play_compact(vad_pump *p, const int16_t *rows, long ld, long period, const uint8_t *pattern, long pattern_ticks, long first_tick,
+                           long n_ticks, int depth, int fill_threads, vad_iter_event *out, long cap, vad_pump_stats *st);
 
 /* ---- host-side ingest ---------------------------------------------------------------------------------
  * Pack n recordings of different lengths (lens[i] samples of elem_size 2 = int16 or 4 = float32 at

@@ -77,6 +77,9 @@ SYMBOLS = {
     "vad_pump_submit_present": (c_int, [c_void_p, c_int, c_void_p]),
     "vad_pump_play_gaps": (c_long, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_long, c_int, c_int, c_void_p, c_long,
                                     POINTER(PumpStats)]),
+    "vad_pump_submit_compact": (c_int, [c_void_p, c_int, c_void_p]),
+    "vad_pump_play_compact": (c_long, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_long, c_int, c_int, c_void_p, c_long,
+                                       POINTER(PumpStats)]),
     "vad_pump_poll": (c_long, [c_void_p, c_int, c_void_p, c_long, POINTER(c_int)]),
     "vad_pump_probs": (c_void_p, [c_void_p, c_int]),
     "vad_pump_open": (c_int, [c_void_p, c_int]),

@@ -115,6 +115,9 @@ hipError_t launch_rec(int sr, const RecArgs &a, hipStream_t s);
 // the probability slot gets the sentinel VAD_PROB_ABSENT.  The step kernels themselves left the row's (h, c) unwritten.
 hipError_t launch_carry_absent(const uint8_t *present, const float *ctx_in, float *ctx_out, int C, float *probs, long ldp, int B,
                                hipStream_t s);
+// A compact tick of the pump (vad_pump_submit_compact): row pos[b] of `src` (the delivering streams' chunks back to back, row_bytes each,
+// a multiple of 16) -> row b of `dst` for every b with present[b] != 0; rows of absent streams are not touched.  HBM to HBM.
+hipError_t launch_expand_rows(const uint8_t *present, const int32_t *pos, const uint8_t *src, void *dst, long row_bytes, int B, hipStream_t s);
 // The same recurrence, bit for bit, for at most kRecSmallMaxB streams (1, 2 or 4 per workgroup): W_hh * h as matrix-vector products on the VALU (kernel_rec_small.hip);
 // `whh` points at the row image (layout.hpp "whh_rows").
 constexpr int kRecSmallMaxB = 1024;

@@ -12,6 +12,9 @@
 // absent row's ctx_out holds the tail of whatever its PCM slot held.  This pass runs behind them on the same stream and finishes the
 // absent rows: ctx_out[b] = ctx_in[b] (bit copy), probs[b] = VAD_PROB_ABSENT.  HBM-bound byte work: B * C * 4 bytes at most (2 MiB for
 // 8 192 streams), one 16-byte vector per lane, rows of present streams are not touched.
+//
+// expand_rows (compact ticks of the pump, pump.hip): the delivering streams' chunks crossed the link back to back; this pass copies row
+// pos[b] of that block to row b of the batch buffer the step kernels read -- HBM-bound byte work, 2 x B x N x 2 bytes at most.
 #include <hip/hip_runtime.h>
 
 #include "device_api.hpp"
@@ -33,7 +36,28 @@ __global__ void __launch_bounds__(256) carry_absent_kernel(const uint8_t *__rest
     if (v == 0) probs[(size_t)b * ldp] = VAD_PROB_ABSENT;
 }
 
+// one thread per 16 bytes of a row: dst[b] <- src[pos[b]] for the rows that deliver (a compact tick of the pump: the link carried only
+// those rows, back to back; the step kernels read row b of the batch buffer)
+__global__ void __launch_bounds__(256) expand_rows_kernel(const uint8_t *__restrict__ present, const int32_t *__restrict__ pos,
+                                                          const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int vec_per_row, int B) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long b = i / vec_per_row;
+    const int v = (int)(i - b * vec_per_row);
+    if (b >= B || !present[b]) return;
+    dst[(size_t)b * vec_per_row + v] = __builtin_nontemporal_load(src + (size_t)pos[b] * vec_per_row + v);
+}
+
 }  // namespace
+
+hipError_t launch_expand_rows(const uint8_t *present, const int32_t *pos, const uint8_t *src, void *dst, long row_bytes, int B, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (!present || !pos || row_bytes <= 0 || row_bytes % 16) return hipErrorInvalidValue;
+    const int vec = (int)(row_bytes / 16);
+    const long threads = (long)B * vec;
+    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, present, pos,
+                       reinterpret_cast<const f32x4 *>(src), static_cast<f32x4 *>(dst), vec, B);
+    return hipGetLastError();
+}
 
 hipError_t launch_carry_absent(const uint8_t *present, const float *ctx_in, float *ctx_out, int C, float *probs, long ldp, int B,
                                hipStream_t s) {

@@ -15,8 +15,11 @@
 //   * a tick may be cut into `parts` sub-batches of whole 16-stream tiles.  Part k's kernel waits for part k's copy BY EVENT
 //     (h2d_done[buffer][k]); part k + 1's copy is already running beside it.  One part is the default: a second copy costs another
 //     setup gap and buys ~15 us of latency;
-//   * the device batch is double-buffered ([2][streams][N] int16): tick t + 2's copies wait BY EVENT for tick t's kernels
-//     (batch_free[buffer]) before they overwrite what those read;
+//   * the device batch has THREE buffers ([3][streams][N] int16): tick t + 3's copies wait BY EVENT for tick t's kernels
+//     (batch_free[buffer]) before they overwrite what those read.  Three, not two: with two, tick t + 2's copy hangs on tick t's kernel,
+//     and when the host submits it only after retiring tick t (two ticks in flight) the chain copy -> kernel -> host -> next copy of a
+//     buffer is 219 + 80 + 70 us for two ticks (rocprofv3 copy trace, profiles/r06_pump_three_buffers.md): the link idles 70 us in
+//     every 370.  With three buffers and three ticks in flight no copy has a dependency that is still open when it is issued;
 //   * the context is ping-ponged between two device buffers (vad_step_split: the kernel writes the next context beside the one it
 //     reads), so a tick is exactly `parts` copies and `parts` kernels -- no D2D blit of the context, no D2H operation;
 //   * a ring slot may be rewritten by its sources as soon as the tick that read it has been retired (vad_pump_poll), and is refused
@@ -28,6 +31,12 @@
 // so that flags + audio are ONE H2D copy); a masked tick copies the header along, the step kernels skip the absent rows' (h, c) and
 // probability, kernel_present.hip carries their contexts over (vad_step_present), and vad_pump_poll leaves their iterator counters
 // alone.  An unmasked tick copies no header and runs exactly the kernels it always ran.
+//
+// COMPACT ticks (vad_pump_submit_compact): the absent streams' rows need not cross the link at all.  The sources write the chunks of
+// the streams that deliver back to back at the start of the slot (row i = the i-th delivering stream, ascending); the tick copies
+// [position table | flags | those rows] in ONE copy into a second pair of device buffers, and a row-expansion pass on the compute
+// stream (kernel_present.hip expand_rows: HBM to HBM, ~8 MB at most, a few us) puts every row where the step kernels read it.  The
+// link cost of a tick then falls with the delivery rate; everything behind the expansion is the masked tick, bit for bit.
 //
 // Waits block.  A source thread of a real server sleeps in its socket; the source threads of vad_pump_play, and its server loop, spin
 // for at most 20 us on the counter they wait for and then sleep on it (futex), whatever the CPU budget: one of eight ranks under a
@@ -53,6 +62,7 @@
 #include <vector>
 
 #include "../../include/silero_vad_hip.h"
+#include "device_api.hpp"
 #include "host_threads.hpp"
 
 struct vad_pump {
@@ -62,20 +72,25 @@ struct vad_pump {
     std::vector<int> lo, hi;                     // part k = streams [lo[k], hi[k])
     double threshold = 0.5, min_silence = 1600, pad = 480;
 
-    size_t hdr = 0, slot_bytes = 0;              // a ring slot / a device batch buffer: [hdr bytes: present[streams], padded][streams][N] int16
+    // a ring slot / a device batch buffer: [hpos bytes: int32 pos[streams], padded][hdr bytes: present[streams], padded][streams][N] int16
+    // (the position table is written and copied by compact ticks only: it lies in FRONT of the flags so that a masked tick's one copy
+    //  starts at the flags and a compact tick's one copy at the table)
+    size_t hpos = 0, hdr = 0, slot_bytes = 0;
     uint8_t *h_ring = nullptr;                   // [R] slots, page-locked ingest ring
     float *h_prob = nullptr;                     // [R][streams]      page-locked, mapped: the kernels store here
     float *d_prob = nullptr;                     // device alias of h_prob
-    uint8_t *d_batch = nullptr;                  // [2] device batch buffers (same layout as a ring slot), double-buffered
+    static constexpr int NB = 3;                 // device batch buffers
+    uint8_t *d_batch = nullptr;                  // [NB] device batch buffers (same layout as a ring slot)
+    uint8_t *d_compact = nullptr;                // [NB] the same again: where a compact tick's copy lands
     float *d_ctx[2] = {nullptr, nullptr};        // [streams][C]      ping-pong
     std::vector<float *> d_state;                // per part: [2][hi - lo][128]
     hipStream_t copy[2] = {nullptr, nullptr}, compute = nullptr;    // copy[t & 1]: the copies of tick t
-    std::vector<hipEvent_t> h2d_done[2];         // [buffer][part]
-    hipEvent_t batch_free[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> h2d_done[NB];        // [buffer][part]
+    hipEvent_t batch_free[NB] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> tick_done;           // [R]
-    bool batch_used[2] = {false, false};
+    bool batch_used[NB] = {false, false, false};
 
-    long ticks = 0;                              // ticks submitted so far (tick t: batch buffer t & 1, context t & 1 -> (t + 1) & 1)
+    long ticks = 0;                              // ticks submitted so far (tick t: batch buffer t % NB, copy stream t & 1, context t & 1 -> (t + 1) & 1)
     long retired = 0;                            // ticks retired so far (vad_pump_poll)
     struct Flight { int r; bool masked; };
     std::deque<Flight> inflight;                 // the submitted, not yet retired ticks, oldest first
@@ -91,8 +106,9 @@ struct vad_pump {
     bool poisoned = false;                       // a tick failed half-way: the carried state is no longer what any caller expects
     std::string err;
 
-    uint8_t *slot_present(int r) const { return h_ring + (size_t)r * slot_bytes; }
-    int16_t *slot_pcm(int r) const { return reinterpret_cast<int16_t *>(h_ring + (size_t)r * slot_bytes + hdr); }
+    int32_t *slot_pos(int r) const { return reinterpret_cast<int32_t *>(h_ring + (size_t)r * slot_bytes); }
+    uint8_t *slot_present(int r) const { return h_ring + (size_t)r * slot_bytes + hpos; }
+    int16_t *slot_pcm(int r) const { return reinterpret_cast<int16_t *>(h_ring + (size_t)r * slot_bytes + hpos + hdr); }
 };
 
 namespace {
@@ -241,14 +257,16 @@ void vad_pump_destroy(vad_pump *p) {
     for (hipStream_t cs : p->copy)
         if (cs) (void)hipStreamSynchronize(cs);
     if (p->compute) (void)hipStreamSynchronize(p->compute);
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < vad_pump::NB; ++b) {
         for (hipEvent_t ev : p->h2d_done[b]) (void)hipEventDestroy(ev);
         if (p->batch_free[b]) (void)hipEventDestroy(p->batch_free[b]);
-        if (p->d_ctx[b]) (void)hipFree(p->d_ctx[b]);
     }
+    for (int b = 0; b < 2; ++b)
+        if (p->d_ctx[b]) (void)hipFree(p->d_ctx[b]);
     for (hipEvent_t ev : p->tick_done) (void)hipEventDestroy(ev);
     for (float *s : p->d_state) (void)hipFree(s);
     if (p->d_batch) (void)hipFree(p->d_batch);
+    if (p->d_compact) (void)hipFree(p->d_compact);
     if (p->h_ring) (void)hipHostFree(p->h_ring);
     if (p->h_prob) (void)hipHostFree(p->h_prob);
     for (hipStream_t cs : p->copy)
@@ -297,7 +315,8 @@ int vad_pump_create(vad_engine *e, const vad_pump_params *prm, vad_pump **out) {
     if (hipSetDevice(p->device) != hipSuccess) return bail(VAD_ERR_HIP);
     const size_t S = (size_t)p->streams;
     p->hdr = (S + 4095) / 4096 * 4096;
-    p->slot_bytes = p->hdr + S * N * sizeof(int16_t);
+    p->hpos = (S * sizeof(int32_t) + 4095) / 4096 * 4096;
+    p->slot_bytes = p->hpos + p->hdr + S * N * sizeof(int16_t);
     if (hipHostMalloc((void **)&p->h_ring, (size_t)p->R * p->slot_bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&p->h_prob, (size_t)p->R * S * sizeof(float), hipHostMallocMapped) != hipSuccess)
         return bail(VAD_ERR_ALLOC);
@@ -307,7 +326,11 @@ int vad_pump_create(vad_engine *e, const vad_pump_params *prm, vad_pump **out) {
     void *dv = nullptr;
     if (hipHostGetDevicePointer(&dv, p->h_prob, 0) != hipSuccess || !dv) return bail(VAD_ERR_HIP);
     p->d_prob = static_cast<float *>(dv);
-    if (hipMalloc((void **)&p->d_batch, 2 * p->slot_bytes) != hipSuccess) return bail(VAD_ERR_ALLOC);
+    if (hipMalloc((void **)&p->d_batch, vad_pump::NB * p->slot_bytes) != hipSuccess ||
+        hipMalloc((void **)&p->d_compact, vad_pump::NB * p->slot_bytes) != hipSuccess)
+        return bail(VAD_ERR_ALLOC);
+    // (compact ticks fill only the delivering streams' rows; rows no tick has filled yet are computed too: let them be silence)
+    if (hipMemset(p->d_batch, 0, vad_pump::NB * p->slot_bytes) != hipSuccess) return bail(VAD_ERR_HIP);
     for (int b = 0; b < 2; ++b) {
         if (hipMalloc((void **)&p->d_ctx[b], S * C * sizeof(float)) != hipSuccess) return bail(VAD_ERR_ALLOC);
         if (hipMemset(p->d_ctx[b], 0, S * C * sizeof(float)) != hipSuccess) return bail(VAD_ERR_HIP);
@@ -326,7 +349,7 @@ int vad_pump_create(vad_engine *e, const vad_pump_params *prm, vad_pump **out) {
         hipStreamCreateWithFlags(&p->compute, hipStreamNonBlocking) != hipSuccess)
         return bail(VAD_ERR_HIP);
     auto mk = [&](hipEvent_t *ev) { return hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess; };
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < vad_pump::NB; ++b) {
         p->h2d_done[b].resize(p->parts);
         for (auto &ev : p->h2d_done[b])
             if (!mk(&ev)) return bail(VAD_ERR_HIP);
@@ -368,23 +391,41 @@ const float *vad_pump_probs(const vad_pump *p, int r) {
     return (p && r >= 0 && r < p->R) ? p->h_prob + (size_t)r * p->streams : nullptr;
 }
 
-int vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present) {
+}  // extern "C"
+
+namespace {
+
+int submit_tick(vad_pump *p, int r, const uint8_t *present, bool compact) {
     if (!p) return VAD_ERR_ARG;
     if (p->poisoned) return pfail(p, VAD_ERR_HIP, "the pump failed half-way through an earlier tick; destroy it (" + p->err + ")");
     if (r < 0 || r >= p->R) return pfail(p, VAD_ERR_ARG, "vad_pump_submit: no such ring slot");
     if (p->slot_busy[r]) return pfail(p, VAD_ERR_ARG, "vad_pump_submit: the slot's previous tick has not been retired (vad_pump_poll)");
     PUMP_TRY(p, hipSetDevice(p->device));
-    const int buf = (int)(p->ticks & 1);
+    const int buf = (int)(p->ticks % vad_pump::NB), pp = (int)(p->ticks & 1);
     const size_t S = (size_t)p->streams, N = (size_t)p->N, C = (size_t)p->C;
     const bool masked = present != nullptr;
+    if (compact && !masked) return pfail(p, VAD_ERR_ARG, "vad_pump_submit_compact: a compact tick needs its flags");
     if (masked && present != p->slot_present(r)) std::memcpy(p->slot_present(r), present, S);
     uint8_t *dbuf = p->d_batch + (size_t)buf * p->slot_bytes;
-    int16_t *batch = reinterpret_cast<int16_t *>(dbuf + p->hdr);
-    const uint8_t *d_present = masked ? dbuf : nullptr;
+    int16_t *batch = reinterpret_cast<int16_t *>(dbuf + p->hpos + p->hdr);
+    const uint8_t *d_present = masked ? dbuf + p->hpos : nullptr;
+    uint8_t *cbuf = nullptr;                     // compact tick: where its one copy lands
+    size_t n_present = 0;
+    if (compact) {
+        cbuf = p->d_compact + (size_t)buf * p->slot_bytes;
+        d_present = cbuf + p->hpos;
+        // the position table: row of the slot that holds stream b's chunk (the i-th delivering stream's chunk is row i)
+        const uint8_t *fl = p->slot_present(r);
+        int32_t *pos = p->slot_pos(r);
+        for (size_t b = 0; b < S; ++b) {
+            pos[b] = (int32_t)n_present;
+            n_present += fl[b] != 0;
+        }
+    }
     const int16_t *src = p->slot_pcm(r);
-    const float *ctx_in = p->d_ctx[buf];
-    float *ctx_out = p->d_ctx[buf ^ 1];
-    hipStream_t copy = p->copy[buf];
+    const float *ctx_in = p->d_ctx[pp];
+    float *ctx_out = p->d_ctx[pp ^ 1];
+    hipStream_t copy = p->copy[pp];
     // from the first queued operation on, a failure leaves the tick half-done: (h, c) of some parts advanced, the context ping-pong out
     // of step.  There is no retry that is right; the pump says so from then on.
     auto broken = [&](int code, const std::string &msg) {
@@ -398,10 +439,19 @@ int vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present) {
     } while (0)
     // the copies may not overwrite the batch buffer before the kernels of two ticks ago have read it
     if (p->batch_used[buf]) TICK_TRY(hipStreamWaitEvent(copy, p->batch_free[buf], 0));
-    for (int k = 0; k < p->parts; ++k) {
+    if (compact) {
+        // ONE copy whatever `parts` says: table + flags + the delivering streams' rows; the expansion pass on the compute stream puts
+        // every row where the kernels read it (the batch buffer's previous readers are earlier on that stream)
+        TICK_TRY(hipMemcpyAsync(cbuf, p->slot_pos(r), p->hpos + p->hdr + n_present * N * sizeof(int16_t), hipMemcpyHostToDevice, copy));
+        TICK_TRY(hipEventRecord(p->h2d_done[buf][0], copy));
+        TICK_TRY(hipStreamWaitEvent(p->compute, p->h2d_done[buf][0], 0));
+        TICK_TRY(vad::launch_expand_rows(d_present, reinterpret_cast<const int32_t *>(cbuf), cbuf + p->hpos + p->hdr, batch,
+                                         (long)(N * sizeof(int16_t)), p->streams, p->compute));
+    }
+    for (int k = 0; k < p->parts && !compact; ++k) {
         const size_t a = (size_t)p->lo[k], n = (size_t)(p->hi[k] - p->lo[k]);
         if (k == 0 && masked)        // the flags of ALL streams ride in front of part 0's audio: one copy (part 0 starts at stream 0)
-            TICK_TRY(hipMemcpyAsync(dbuf, p->slot_present(r), p->hdr + n * N * sizeof(int16_t), hipMemcpyHostToDevice, copy));
+            TICK_TRY(hipMemcpyAsync(dbuf + p->hpos, p->slot_present(r), p->hdr + n * N * sizeof(int16_t), hipMemcpyHostToDevice, copy));
         else
             TICK_TRY(hipMemcpyAsync(batch + a * N, src + a * N, n * N * sizeof(int16_t), hipMemcpyHostToDevice, copy));
         TICK_TRY(hipEventRecord(p->h2d_done[buf][k], copy));
@@ -409,8 +459,8 @@ int vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present) {
     for (int k = 0; k < p->parts; ++k) {
         const size_t a = (size_t)p->lo[k];
         const int n = p->hi[k] - p->lo[k];
-        TICK_TRY(hipStreamWaitEvent(p->compute, p->h2d_done[buf][k], 0));
-        if (k > 0 && masked) TICK_TRY(hipStreamWaitEvent(p->compute, p->h2d_done[buf][0], 0));     // (the flags came with part 0)
+        if (!compact) TICK_TRY(hipStreamWaitEvent(p->compute, p->h2d_done[buf][k], 0));
+        if (k > 0 && masked && !compact) TICK_TRY(hipStreamWaitEvent(p->compute, p->h2d_done[buf][0], 0));     // (the flags came with part 0)
         const int rc = vad_step_present(p->eng, p->sr, n, batch + a * N, sizeof(int16_t), (long)N, ctx_in + a * C, ctx_out + a * C, p->d_state[k],
                                         p->d_prob + (size_t)r * S + a, masked ? d_present + a : nullptr, p->compute);
         if (rc != VAD_OK) return broken(rc, std::string("vad_step_present: ") + vad_last_error(p->eng));
@@ -425,7 +475,15 @@ int vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present) {
     return VAD_OK;
 }
 
-int vad_pump_submit(vad_pump *p, int r) { return vad_pump_submit_present(p, r, nullptr); }
+}  // namespace
+
+extern "C" {
+
+int vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present) { return submit_tick(p, r, present, false); }
+
+int vad_pump_submit_compact(vad_pump *p, int r, const uint8_t *present) { return submit_tick(p, r, present, true); }
+
+int vad_pump_submit(vad_pump *p, int r) { return submit_tick(p, r, nullptr, false); }
 
 long vad_pump_poll(vad_pump *p, int block, vad_iter_event *out, long cap, int *slot) {
     if (!p || cap < 0 || (cap > 0 && !out)) return VAD_PUMP_ERROR;
@@ -522,8 +580,12 @@ int vad_pump_state(vad_pump *p, int stream, float *h, float *c, float *ctx) {
 // tick that comes next while `depth` ticks are in flight (they run depth + 1 ticks ahead of the retired ones).
 // Both sides BLOCK when they have to wait (Gate: 20 us of spinning, then a futex): the sources on the count of retired ticks, the
 // server on the count of sources that have written the slot.
-long vad_pump_play_gaps(vad_pump *p, const int16_t *rows, long ld, long period, const uint8_t *pattern, long pattern_ticks, long first_tick,
-                        long n_ticks, int depth, int fill_threads, vad_iter_event *out, long cap, vad_pump_stats *st) {
+}  // extern "C"
+
+namespace {
+
+long play_loop(vad_pump *p, const int16_t *rows, long ld, long period, const uint8_t *pattern, long pattern_ticks, long first_tick,
+               long n_ticks, int depth, int fill_threads, vad_iter_event *out, long cap, vad_pump_stats *st, bool compact) {
     if (!p) return VAD_PUMP_ERROR;
     const long N = p->N;
     if (!rows || ld < period || period < N || period % N || first_tick < 0 || n_ticks < 0 || cap < 0 || (cap > 0 && !out) ||
@@ -568,11 +630,16 @@ long vad_pump_play_gaps(vad_pump *p, const int16_t *rows, long ld, long period, 
                     // stream's own next chunk, it does not skip audio)
                     const uint8_t *pat = pattern + (size_t)(t % pattern_ticks) * p->streams;
                     uint8_t *flags = p->slot_present(r);
+                    // compact: the delivering streams' chunks lie back to back (vad_pump_submit_compact) -- this thread's first row
+                    // is the number of streams before its range that deliver this tick
+                    long row = 0;
+                    if (compact)
+                        for (long b = 0; b < b0; ++b) row += pat[b] != 0;
                     for (long b = b0; b < b1; ++b) {
                         flags[b] = pat[b];
                         if (!pat[b]) continue;
                         const long off = (p->src_pos[b]++ * N) % period;
-                        stream_copy(slot + b * N, rows + b * ld + off, (size_t)N * sizeof(int16_t));
+                        stream_copy(slot + (compact ? row++ : b) * N, rows + b * ld + off, (size_t)N * sizeof(int16_t));
                         ++mine;
                     }
                 }
@@ -613,7 +680,7 @@ long vad_pump_play_gaps(vad_pump *p, const int16_t *rows, long ld, long period, 
         written[r].store(0, std::memory_order_relaxed);          // (the slot's next writers wait for this tick's retirement)
         const double s0 = now_ms();
         t_written[r] = s0;
-        ok = vad_pump_submit_present(p, r, pattern && !silent ? p->slot_present(r) : nullptr) == VAD_OK;
+        ok = submit_tick(p, r, pattern && !silent ? p->slot_present(r) : nullptr, compact && pattern && !silent) == VAD_OK;
         submit_ms += now_ms() - s0;
         if (ok && (int)p->inflight.size() >= depth) ok = retire();
     }
@@ -649,9 +716,23 @@ long vad_pump_play_gaps(vad_pump *p, const int16_t *rows, long ld, long period, 
     return n_events;
 }
 
+}  // namespace
+
+extern "C" {
+
+long vad_pump_play_gaps(vad_pump *p, const int16_t *rows, long ld, long period, const uint8_t *pattern, long pattern_ticks, long first_tick,
+                        long n_ticks, int depth, int fill_threads, vad_iter_event *out, long cap, vad_pump_stats *st) {
+    return play_loop(p, rows, ld, period, pattern, pattern_ticks, first_tick, n_ticks, depth, fill_threads, out, cap, st, false);
+}
+
+long vad_pump_play_compact(vad_pump *p, const int16_t *rows, long ld, long period, const uint8_t *pattern, long pattern_ticks, long first_tick,
+                           long n_ticks, int depth, int fill_threads, vad_iter_event *out, long cap, vad_pump_stats *st) {
+    return play_loop(p, rows, ld, period, pattern, pattern_ticks, first_tick, n_ticks, depth, fill_threads, out, cap, st, true);
+}
+
 long vad_pump_play(vad_pump *p, const int16_t *rows, long ld, long period, long first_tick, long n_ticks, int depth, int fill_threads,
                    vad_iter_event *out, long cap, vad_pump_stats *st) {
-    return vad_pump_play_gaps(p, rows, ld, period, nullptr, 0, first_tick, n_ticks, depth, fill_threads, out, cap, st);
+    return play_loop(p, rows, ld, period, nullptr, 0, first_tick, n_ticks, depth, fill_threads, out, cap, st, false);
 }
 
 }  // extern "C"

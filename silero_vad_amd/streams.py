@@ -1527,10 +1527,14 @@ class StreamPump:
         """Slot r's flag row, [streams] uint8 (page-locked, in front of the slot's audio): 0 = the stream has no chunk this tick."""
         return self._present[r]
 
-    def submit(self, r: int, present=None):
+    def submit(self, r: int, present=None, compact: bool = False):
         """Start the tick over ring slot r.  present: None = every stream has a chunk; True = the flags the sources wrote into
         `present(r)`; an array of `streams` flags = copied there.  A stream whose flag is 0 is not stepped: its (h, c), context and
-        iterator counters stay as they are and `probs(r)[b]` reads -1.0 (vad_pump_submit_present)."""
+        iterator counters stay as they are and `probs(r)[b]` reads -1.0 (vad_pump_submit_present).
+        compact=True (vad_pump_submit_compact): `slot(r)` holds only the delivering streams' chunks, back to back -- row i is the chunk
+        of the i-th stream whose flag is set -- and only those rows cross the link; same results, bit for bit."""
+        if compact and present is None:
+            raise ValueError("a compact tick needs its present flags")
         if present is None:
             self._check(self._L.vad_pump_submit(self._h, int(r)))
             return
@@ -1539,7 +1543,8 @@ class StreamPump:
             if f.shape != (self.streams,):
                 raise ValueError(f"expected {self.streams} present flags, got shape {f.shape}")
             self._present[r][:] = f != 0
-        self._check(self._L.vad_pump_submit_present(self._h, int(r), self._present[r].ctypes.data))
+        fn = self._L.vad_pump_submit_compact if compact else self._L.vad_pump_submit_present
+        self._check(fn(self._h, int(r), self._present[r].ctypes.data))
 
     def poll(self, block: bool = True):
         """-> (events, ring slot) of the oldest submitted tick; (None, None) if nothing is in flight or (block=False) it has not finished."""
@@ -1565,10 +1570,11 @@ class StreamPump:
         return h, c, x
 
     def play(self, rows: np.ndarray, n_ticks: int, first_tick: int = 0, depth: int = 2, fill_threads: int = 0, max_events: int = 0,
-             pattern: np.ndarray = None):
+             pattern: np.ndarray = None, compact: bool = False):
         """vad_pump_play: stream b plays rows[b] (int16, length a multiple of the chunk) circularly, chunk by chunk.
         pattern [pattern_ticks, streams] uint8 (vad_pump_play_gaps): stream b delivers a chunk at tick t iff pattern[t % pattern_ticks, b];
-        its audio advances only when it delivers.
+        its audio advances only when it delivers.  compact=True (vad_pump_play_compact): the sources write compact slots, only the
+        delivering streams' rows cross the link.
         -> (events [(stream, {...}), ...] (the first max_events of them), stats dict)."""
         if rows.dtype != np.int16 or rows.ndim != 2 or rows.shape[0] != self.streams or not rows.flags.c_contiguous:
             raise ValueError(f"rows must be C-contiguous int16 [{self.streams}, period]")
@@ -1577,7 +1583,8 @@ class StreamPump:
         cap = int(max_events)
         buf = (_lib.IterEvent * max(cap, 1))()
         st = _lib.PumpStats()
-        m = self._L.vad_pump_play_gaps(self._h, rows.ctypes.data, rows.shape[1], rows.shape[1], None if pattern is None else pattern.ctypes.data,
+        fn = self._L.vad_pump_play_compact if compact and pattern is not None else self._L.vad_pump_play_gaps
+        m = fn(self._h, rows.ctypes.data, rows.shape[1], rows.shape[1], None if pattern is None else pattern.ctypes.data,
                                        0 if pattern is None else pattern.shape[0], int(first_tick), int(n_ticks), int(depth),
                                        int(fill_threads), buf if cap else None, cap, ctypes.byref(st))
         if m < 0:

@@ -4,13 +4,14 @@
  * header must be valid C and every entry point it uses must resolve); on a GPU box tests/test_gpu_parity.py also runs it: it streams
  * int16 chunks of `pcm_file` through vad_step_host (page-locked buffers from vad_host_register) and vad_iterator_feed and prints the
  * probabilities and events, which the test compares with the Python path's.
- *     client <weights> <pcm_int16_file> <sr> <streams> [sync | pump | gaps]
+ *     client <weights> <pcm_int16_file> <sr> <streams> [sync | pump | gaps | compact]
  * With `sync` every tick is ONE blocking vad_step_host_sync (chunks read in place, probabilities stored into the page-locked buffer).
  * With `pump` the same loop runs on the native pump (vad_pump_create / slot / submit / poll / probs): the client writes the chunks into
  * the pump's page-locked ring, keeps two ticks in flight and prints each tick's probabilities and events as it is retired -- no HIP
  * call of its own at all.  With `gaps` the streams do not arrive in lock step: stream b has no chunk at tick t when
  * (7 t + 13 b) % 10 == 0, the client sets its flag to 0 (vad_pump_present / vad_pump_submit_present) and the stream's audio waits for
- * its next tick -- what a caller of the reference does by not calling its model (src/silero_vad/utils_vad.py:507-549).            */
+ * its next tick -- what a caller of the reference does by not calling its model (src/silero_vad/utils_vad.py:507-549).  With `compact`
+ * the same streams write only the delivered chunks, back to back, and submit with vad_pump_submit_compact.                          */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -52,14 +53,19 @@ static int run_pump(vad_engine *e, const int16_t *pcm, long samples, int sr, int
         if (t < T) {
             int16_t *slot = vad_pump_slot(p, (int)(t % R));
             uint8_t *flags = vad_pump_present(p, (int)(t % R));
-            int b, i;
+            int b, i, row = 0;
             for (b = 0; b < B; ++b) {
                 flags[b] = (uint8_t)!(gaps && (7 * t + 13 * b) % 10 == 0);
                 if (!flags[b]) continue;                     /* no chunk this tick: the slot keeps whatever it holds */
-                for (i = 0; i < N; ++i) slot[(size_t)b * N + i] = pcm[((long)b * 7919 + delivered[b] * N + i) % samples];
+                /* gaps == 2: a compact slot -- the delivered chunks back to back, the i-th delivering stream's in row i */
+                for (i = 0; i < N; ++i) slot[(size_t)(gaps == 2 ? row : b) * N + i] = pcm[((long)b * 7919 + delivered[b] * N + i) % samples];
                 ++delivered[b];
+                ++row;
             }
-            if ((rc = gaps ? vad_pump_submit_present(p, (int)(t % R), flags) : vad_pump_submit(p, (int)(t % R))) != VAD_OK) {
+            rc = gaps == 2 ? vad_pump_submit_compact(p, (int)(t % R), flags)
+                 : gaps    ? vad_pump_submit_present(p, (int)(t % R), flags)
+                           : vad_pump_submit(p, (int)(t % R));
+            if (rc != VAD_OK) {
                 fprintf(stderr, "vad_pump_submit: %s\n", vad_pump_last_error(p));
                 return 1;
             }
@@ -121,8 +127,8 @@ int main(int argc, char **argv) {
     if (fread(pcm, 2, (size_t)samples, f) != (size_t)samples) return 66;
     fclose(f);
     const long T = samples / N;
-    if (argc > 5 && (strcmp(argv[5], "pump") == 0 || strcmp(argv[5], "gaps") == 0)) {
-        rc = run_pump(e, pcm, samples, sr, B, N, T, strcmp(argv[5], "gaps") == 0);
+    if (argc > 5 && (strcmp(argv[5], "pump") == 0 || strcmp(argv[5], "gaps") == 0 || strcmp(argv[5], "compact") == 0)) {
+        rc = run_pump(e, pcm, samples, sr, B, N, T, strcmp(argv[5], "gaps") == 0 ? 1 : strcmp(argv[5], "compact") == 0 ? 2 : 0);
         vad_destroy(e);
         return rc;
     }

@@ -563,9 +563,11 @@ def test_plain_c_client_streams_chunks_to_events(model, golden, tag, route, tmp_
         assert np.abs(probs[:T].T - want).max() < TIGHT
 
 
-def test_plain_c_client_with_streams_that_miss_ticks(model, golden, tmp_path):
+@pytest.mark.parametrize("how", ["gaps", "compact"])
+def test_plain_c_client_with_streams_that_miss_ticks(model, golden, tmp_path, how):
     """The same C99 client with `gaps`: stream b has no chunk at tick t when (7 t + 13 b) % 10 == 0 -- it clears the stream's flag in
-    vad_pump_present and submits with vad_pump_submit_present.  Every stream's delivered chunks give the probabilities of its own
+    vad_pump_present and submits with vad_pump_submit_present (`compact`: it writes only the delivered chunks, back to back, and
+    submits with vad_pump_submit_compact).  Every stream's delivered chunks give the probabilities of its own
     gap-free audio bit for bit (the engine's [B, T] entry on each stream's own chunk sequence), its slot reads -1 at the ticks it
     missed, and its events EQUAL a per-stream VADIterator over the B = 1 model fed only its own chunks."""
     import subprocess
@@ -578,7 +580,7 @@ def test_plain_c_client_with_streams_that_miss_ticks(model, golden, tmp_path):
     pcm.tofile(raw)
     exe = build_c_client(tmp_path)
     T = len(pcm) // n
-    r = subprocess.run([str(exe), str(_lib.WEIGHTS_PATH), str(raw), str(sr), str(B), "gaps"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([str(exe), str(_lib.WEIGHTS_PATH), str(raw), str(sr), str(B), how], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-500:]
     probs = np.array([[float(v) for v in l.split()[2:]] for l in r.stdout.splitlines() if l.startswith("P ")], dtype=np.float32)
     assert probs.shape == (T, B)
@@ -2486,7 +2488,8 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
     VAD_PROB_ABSENT, and for a handful of streams the events equal a per-stream VADIterator over the B = 1 model object fed only that
     stream's chunks; the probabilities agree with the CPU oracle on the stream's own audio.  vad_pump_play_gaps (the loop natively,
     flags written by the source threads) gives the same events.  (reference: utils_vad.py:507-549, JIT!/vad/model/vad_annotator.py:72,86-87,
-    examples/cpp/silero-vad-onnx.cpp:335-390)"""
+    examples/cpp/silero-vad-onnx.cpp:335-390)  COMPACT ticks (vad_pump_submit_compact / vad_pump_play_compact: only the delivering
+    streams' rows cross the link) give the same bits, alone and mixed with masked ticks."""
     from silero_vad_amd import StreamPump, VADIterator
     sr, g = SRS[tag], golden[tag]
     n = chunk_of(sr)
@@ -2500,7 +2503,7 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
     assert (pat.sum(0) == K).all() and 0.06 < missing < 0.15 and Tt > K + 5
     rec = golden["segments"][tag]["iterator"]["default"]
 
-    def run(pattern):
+    def run(pattern, compact=None):
         pump = StreamPump(model.engine, sr, streams=cap, parts=2, ring_slots=3, **rec["init"])
         events = {s: [] for s in range(cap)}
         got = np.full((cap, K), np.nan, np.float32)
@@ -2513,11 +2516,13 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
                 fl = np.ones(cap, np.uint8) if pattern is None else pattern[t]
                 slot = pump.slot(r)
                 slot[:] = 12345                                    # an absent stream's part of the slot holds whatever it holds
-                for s in np.flatnonzero(fl):
-                    slot[s] = rows[s, pos[s] * n:(pos[s] + 1) * n]
+                # compact ticks (vad_pump_submit_compact): the delivering streams' chunks back to back, nothing else crosses the link
+                packed = compact is not None and compact(t)
+                for i, s in enumerate(np.flatnonzero(fl)):
+                    slot[i if packed else s] = rows[s, pos[s] * n:(pos[s] + 1) * n]
                 sent.append((fl.copy(), pos.copy()))
                 pos += fl
-                pump.submit(r, present=None if pattern is None else fl)
+                pump.submit(r, present=None if pattern is None else fl, compact=packed)
             if t > 0:
                 ev, r = pump.poll()
                 fl, at = sent[t - 1]
@@ -2545,12 +2550,19 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
         one = VADIterator(model, sampling_rate=sr, **rec["init"])
         mine = [e for t in range(K) if (e := one(torch.from_numpy(rows[s, t * n:(t + 1) * n].astype(np.float32) / 32768.0)))]
         assert got_ev[s] == mine, s
+    # compact slots: every tick, and mixed with masked ticks on one pump -- the same bits
+    for which in (lambda t: True, lambda t: t % 3 != 1):
+        c_got, c_ev, c_st = run(pat, compact=which)
+        assert np.array_equal(c_got, want) and c_ev == want_ev
+        for s in range(cap):
+            for a, b in zip(c_st[s], want_st[s]):
+                assert np.array_equal(a, b), s
     flat = sorted((s, k, v) for s in range(cap) for e in got_ev[s] for k, v in e.items())
-    for depth in (1, 2):
+    for depth, compact in ((1, False), (2, False), (1, True), (2, True)):
         pump = StreamPump(model.engine, sr, streams=cap, parts=1, ring_slots=4, **rec["init"])
-        ev, stats = pump.play(rows, Tt, depth=depth, fill_threads=2, max_events=100000, pattern=pat)
+        ev, stats = pump.play(rows, Tt, depth=depth, fill_threads=2, max_events=100000, pattern=pat, compact=compact)
         assert stats["chunks"] == cap * K and stats["ticks"] == Tt
-        assert sorted((s, k, v) for s, e in ev for k, v in e.items()) == flat, depth
+        assert sorted((s, k, v) for s, e in ev for k, v in e.items()) == flat, (depth, compact)
         pump.close()
 
 
