@@ -684,6 +684,8 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000, gaps=0.0):
             if d not in trial or st["wall_ms"] < trial[d]["wall_ms"]:
                 trial[d] = st
     depth = min(trial, key=lambda d: trial[d]["wall_ms"])
+    if os.environ.get("VAD_BENCH_STREAM_DEPTH"):                # (A/B knob: profiles/r06_pump_three_buffers.md)
+        depth = int(os.environ["VAD_BENCH_STREAM_DEPTH"])
     runs = {f"depth{d}": {"ticks": 500, "wall_ms": round(st["wall_ms"], 2), "tick_ms_p50": round(st["tick_ms_p50"], 4),
                           "tick_ms_p95": round(st["tick_ms_p95"], 4)} for d, st in trial.items()}
     best = {}
