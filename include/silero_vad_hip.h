@@ -289,7 +289,7 @@ long vad_iterator_feed(const float *probs, const uint8_t *active, long n, int wi
  * their runtime, one session.run per chunk with explicit state and the iterator logic inline
  * (examples/cpp/silero-vad-onnx.cpp:335-390; Python: src/silero_vad/utils_vad.py:507-549 VADIterator.__call__), for thousands of
  * streams at once.  The pump owns: a page-locked ingest ring [ring_slots][streams][N] int16 that the audio sources write
- * into, the device batch (double-buffered), the carried (h, c) and context of every stream in HBM, the iterator state of every
+ * into, the device batch (three buffers), the carried (h, c) and context of every stream in HBM, the iterator state of every
  * stream, three HIP streams (copies of even / odd ticks, kernels) and the events that order them (csrc/pump.hip has the schedule:
  * tick t + 1's H2D runs beside tick t's kernel BY EVENT, nothing left to hardware-queue assignment).
  * One caller thread drives submit / poll; any thread may write a ring slot that is not in flight.                          */
