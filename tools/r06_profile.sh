@@ -1,7 +1,7 @@
 #!/bin/bash
-# rocprofv3 passes of the round-6 product: gpurun --timeout 1500 -- 'bash tools/r06_profile.sh r06x'
+# rocprofv3 passes of the round-6 product: gpurun --timeout 1500 -- 'bash tools/r06_profile.sh r06w'
 set -u
-tag=${1:-r06x}
+tag=${1:-r06w}
 bash tools/r03_profile.sh $tag
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_${tag}_stream_host

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU session: parity suite + the default bench line (+ optional extra commands).  gpurun --timeout 1500 -- 'bash tools/r06_round.sh <tag> [bench args]'
 set -u
-tag=${1:-r06x}; shift || true
+tag=${1:-r06w}; shift || true
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 python __graft_entry__.py > $out/build.log 2>&1 || tail -20 $out/build.log
