@@ -2533,6 +2533,14 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
                     assert fl[s], "an absent stream emitted an event"
                     events[s].append(e)
         state = [pump.state(s) for s in range(cap)]
+        if compact is not None:
+            # a compact tick in which NOBODY delivers (only the header crosses the link) changes nothing
+            pump.submit(0, present=np.zeros(cap, np.uint8), compact=True)
+            ev, r = pump.poll()
+            assert ev == [] and (pump.probs(r) == -1.0).all()
+            for s in (0, cap // 2, cap - 1):
+                for a, b in zip(pump.state(s), state[s]):
+                    assert np.array_equal(a, b)
         pump.close()
         return got, events, state
 
@@ -2557,6 +2565,20 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
         for s in range(cap):
             for a, b in zip(c_st[s], want_st[s]):
                 assert np.array_equal(a, b), s
+    # ... and one in which EVERYBODY delivers is the plain tick
+    both = []
+    for packed in (False, True):
+        pump = StreamPump(model.engine, sr, streams=cap, parts=1, ring_slots=2, **rec["init"])
+        for t in range(3):
+            pump.slot(t % 2)[:] = rows[:, t * n:(t + 1) * n]
+            pump.submit(t % 2, present=np.ones(cap, np.uint8) if packed else None, compact=packed)
+            pump.poll()
+        both.append((pump.probs(0).copy(), [pump.state(s) for s in (0, 17, cap - 1)]))
+        pump.close()
+    assert np.array_equal(both[0][0], both[1][0])
+    for x, y in zip(both[0][1], both[1][1]):
+        for a, b in zip(x, y):
+            assert np.array_equal(a, b)
     flat = sorted((s, k, v) for s in range(cap) for e in got_ev[s] for k, v in e.items())
     for depth, compact in ((1, False), (2, False), (1, True), (2, True)):
         pump = StreamPump(model.engine, sr, streams=cap, parts=1, ring_slots=4, **rec["init"])
