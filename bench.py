@@ -690,7 +690,9 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000, gaps=0.0):
             st = play(500, d)
             if d not in trial or st["wall_ms"] < trial[d]["wall_ms"]:
                 trial[d] = st
-    depth = min(trial, key=lambda d: trial[d]["wall_ms"])
+    # three ticks in flight unless two are clearly faster: with three batch buffers depth 3 is at least as fast in a same-lease A/B
+    # (tools/r06_pump_ab.py), and a 2 % difference between two 80 ms passes is noise
+    depth = 2 if trial[2]["wall_ms"] < 0.95 * trial[3]["wall_ms"] else 3
     if os.environ.get("VAD_BENCH_STREAM_DEPTH"):                # (A/B knob: profiles/r06_pump_three_buffers.md)
         depth = int(os.environ["VAD_BENCH_STREAM_DEPTH"])
     runs = {f"depth{d}": {"ticks": 500, "wall_ms": round(st["wall_ms"], 2), "tick_ms_p50": round(st["tick_ms_p50"], 4),

@@ -16,10 +16,10 @@
 //     (h2d_done[buffer][k]); part k + 1's copy is already running beside it.  One part is the default: a second copy costs another
 //     setup gap and buys ~15 us of latency;
 //   * the device batch has THREE buffers ([3][streams][N] int16): tick t + 3's copies wait BY EVENT for tick t's kernels
-//     (batch_free[buffer]) before they overwrite what those read.  Three, not two: with two, tick t + 2's copy hangs on tick t's kernel,
-//     and when the host submits it only after retiring tick t (two ticks in flight) the chain copy -> kernel -> host -> next copy of a
-//     buffer is 219 + 80 + 70 us for two ticks (rocprofv3 copy trace, profiles/r06_pump_three_buffers.md): the link idles 70 us in
-//     every 370.  With three buffers and three ticks in flight no copy has a dependency that is still open when it is issued;
+//     (batch_free[buffer]) before they overwrite what those read.  Three, not two: the link idles with only two ticks in flight (copy ->
+//     kernel -> host -> next copy: 70 us in every 370, rocprofv3 copy trace), and with two buffers the third tick's copy would wait on the
+//     device for an event that is still open when it is issued.  With three buffers and three ticks in flight no copy has an open
+//     dependency: same-lease A/B +13 % at 8 kHz, +0.5-1.3 % at 16 kHz, never slower (profiles/r06_pump_three_buffers.md);
 //   * the context is ping-ponged between two device buffers (vad_step_split: the kernel writes the next context beside the one it
 //     reads), so a tick is exactly `parts` copies and `parts` kernels -- no D2D blit of the context, no D2H operation;
 //   * a ring slot may be rewritten by its sources as soon as the tick that read it has been retired (vad_pump_poll), and is refused
@@ -80,6 +80,7 @@ struct vad_pump {
     float *h_prob = nullptr;                     // [R][streams]      page-locked, mapped: the kernels store here
     float *d_prob = nullptr;                     // device alias of h_prob
     static constexpr int NB = 3;                 // device batch buffers
+    int nb = NB;                                 // ... in use (A/B knob SILERO_VAD_AMD_PUMP_BUFFERS=2: profiles/r06_pump_three_buffers.md)
     uint8_t *d_batch = nullptr;                  // [NB] device batch buffers (same layout as a ring slot)
     uint8_t *d_compact = nullptr;                // [NB] the same again: where a compact tick's copy lands
     float *d_ctx[2] = {nullptr, nullptr};        // [streams][C]      ping-pong
@@ -296,6 +297,7 @@ int vad_pump_create(vad_engine *e, const vad_pump_params *prm, vad_pump **out) {
     p->threshold = prm->threshold;
     p->min_silence = (double)p->sr * prm->min_silence_duration_ms / 1000.0;     // Python floats (utils_vad.py:494-498)
     p->pad = (double)p->sr * prm->speech_pad_ms / 1000.0;
+    if (const char *v = std::getenv("SILERO_VAD_AMD_PUMP_BUFFERS")) p->nb = std::max(2, std::min(vad_pump::NB, std::atoi(v)));
     p->device = vad_device(e);
     if (p->device < 0 || vad_clone(e, &p->eng) != VAD_OK) return bail(VAD_ERR_NO_DEVICE);
     // the clone takes the caller's options with it; the pump steps through the product kernels whatever the caller's engine was set to
@@ -401,7 +403,7 @@ int submit_tick(vad_pump *p, int r, const uint8_t *present, bool compact) {
     if (r < 0 || r >= p->R) return pfail(p, VAD_ERR_ARG, "vad_pump_submit: no such ring slot");
     if (p->slot_busy[r]) return pfail(p, VAD_ERR_ARG, "vad_pump_submit: the slot's previous tick has not been retired (vad_pump_poll)");
     PUMP_TRY(p, hipSetDevice(p->device));
-    const int buf = (int)(p->ticks % vad_pump::NB), pp = (int)(p->ticks & 1);
+    const int buf = (int)(p->ticks % p->nb), pp = (int)(p->ticks & 1);
     const size_t S = (size_t)p->streams, N = (size_t)p->N, C = (size_t)p->C;
     const bool masked = present != nullptr;
     if (compact && !masked) return pfail(p, VAD_ERR_ARG, "vad_pump_submit_compact: a compact tick needs its flags");
