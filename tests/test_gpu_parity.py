@@ -2580,11 +2580,17 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
         for a, b in zip(x, y):
             assert np.array_equal(a, b)
     flat = sorted((s, k, v) for s in range(cap) for e in got_ev[s] for k, v in e.items())
-    for depth, compact in ((1, False), (2, False), (1, True), (2, True)):
-        pump = StreamPump(model.engine, sr, streams=cap, parts=1, ring_slots=4, **rec["init"])
+    # the native loop at 1, 2 and 3 ticks in flight, over three device batch buffers (default) and two (the A/B knob)
+    for depth, compact, nb in ((1, False, None), (2, False, None), (1, True, None), (2, True, None), (3, True, None), (3, False, "2"), (3, True, "2")):
+        if nb is not None:
+            os.environ["SILERO_VAD_AMD_PUMP_BUFFERS"] = nb
+        try:
+            pump = StreamPump(model.engine, sr, streams=cap, parts=1, ring_slots=4, **rec["init"])
+        finally:
+            os.environ.pop("SILERO_VAD_AMD_PUMP_BUFFERS", None)
         ev, stats = pump.play(rows, Tt, depth=depth, fill_threads=2, max_events=100000, pattern=pat, compact=compact)
         assert stats["chunks"] == cap * K and stats["ticks"] == Tt
-        assert sorted((s, k, v) for s, e in ev for k, v in e.items()) == flat, (depth, compact)
+        assert sorted((s, k, v) for s, e in ev for k, v in e.items()) == flat, (depth, compact, nb)
         pump.close()
 
 
