@@ -39,7 +39,7 @@ The same JSON line also carries, for the record (none of them is the headline `v
                    average launch duration (hipEvents recorded by the engine around that kernel on the launch
                    stream during the timed steps) against the dense fp32 MFMA peak; always <= 1
   legs             LAST key: every leg's value, its fraction of the bound that applies, its own parity figure and max probability
-  cpu_baseline     the reference's own ATen CPU operators (oracle/aten_port.py, kind "aten-port") timed on this
+  cpu_baseline     the reference's own ATen CPU operators (oracle/aten_port.py; kind "port", port "aten-operators") timed on this
                    box's host cores under BASELINE.md section 3 protocols R1-R5 (rank 0, before the process group forms; R5 =
                    get_speech_timestamps on the fixture through the per-chunk protocol, the CPU figure beside `plumbing`)
 What rank 0 prints on stdout is ONE line of at most 8 192 bytes (`compact_line`: the contract's keys, `parity`, `roofline`, `cpu_baseline`,
@@ -170,10 +170,10 @@ def cpu_baseline(sr, budget_s=24.0):
     except subprocess.TimeoutExpired as e:
         line, err = None, f"timed out: {e}"
     if line is None:
-        return {"value": None, "unit": "chunks/s", "kind": "aten-port", "error": err}
+        return {"value": None, "unit": "chunks/s", "kind": "port", "port": "aten-operators", "error": err}
     d = json.loads(line)
     return {"value": d["value"], "unit": "chunks/s", "cores": d["nproc"], "affinity_cpus": d["affinity_cpus"],
-            "kind": "aten-port", "best_protocol": d["best"], "cpu_model": d["cpu_model"], "torch": d["torch"],
+            "kind": "port", "port": "aten-operators", "best_protocol": d["best"], "cpu_model": d["cpu_model"], "torch": d["torch"],
             "runs": d["runs"],
             "sample": f"same {sr // 1000} kHz synthetic workload (0.03 N(0,1)), audio_forward over B streams x T chunks "
                       f"per run as listed under runs; warm-up {d['warmup']}, median of {d['trials']}; R1 = 1 thread B=1 "
@@ -1252,7 +1252,7 @@ def compact_line(out):
         line["roofline"] = r
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
-        c = {k: cb.get(k) for k in ("value", "unit", "cores", "cpu_model", "kind", "best_protocol", "torch", "cached_from") if k in cb}
+        c = {k: cb.get(k) for k in ("value", "unit", "cores", "cpu_model", "kind", "port", "best_protocol", "torch", "cached_from") if k in cb}
         if isinstance(cb.get("runs"), dict):
             c["runs"] = {k.split("_")[0]: _num(v.get("chunks_per_s") if isinstance(v, dict) else v, 1) for k, v in cb["runs"].items()}
         if "error" in cb:

@@ -12,7 +12,7 @@ those operators, in the same order, from the weights container the engine loads:
 
 so `AtenVAD` (a) is a second, independent checker next to the plain-C oracle (pinned to the same goldens
 in tests/test_oracle.py: bit-level agreement with the JIT is expected, it IS the same kernels), and (b) is
-what bench.py times as `cpu_baseline` (kind "aten-port"): the reference's CPU path on this box's host cores
+what bench.py times as `cpu_baseline` (kind "port", port "aten-operators"): the reference's CPU path on this box's host cores
 under the reference's own threading rules (src/silero_vad/model.py:3 `torch.set_num_threads(1)`) and timing
 protocol (examples/onnx_sequence/run.py:172-194: warm-up, then the median of 5 trials).
 

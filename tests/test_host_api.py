@@ -148,7 +148,7 @@ def _worst_case_bench_record(world=8):
            "per_rank": [{"rank": r, "local_rank": r, "host_threads": 2, "numa_node_bound": r // 4, "torch_pinned_peak_bytes": 10 << 30,
                          "native_pinned_bytes": 1 << 25, "device_peak_bytes_torch": 11 << 30, "max_rss_mb": 14000} for r in range(world)],
            "node_totals": {"pinned_bytes": 87 << 30, "host_threads": 16, "device_peak_bytes_torch": 94 << 30},
-           "cpu_baseline": {"value": 1289545.6, "unit": "chunks/s", "cores": 16, "affinity_cpus": 256, "kind": "aten-port",
+           "cpu_baseline": {"value": 1289545.6, "unit": "chunks/s", "cores": 16, "affinity_cpus": 256, "kind": "port", "port": "aten-operators",
                             "best_protocol": "R4_nproc_procs_1thread", "cpu_model": "AMD EPYC 9575F 64-Core Processor", "torch": "2.10.0+rocm7.0",
                             "runs": {f"R{i}_{'protocol_name_' * 2}": {"chunks_per_s": 1289545.6123, "B": 4096, "T": 41, "threads": 16, "what": prose[:150]}
                                      for i in range(1, 6)}, "sample": prose[:460]}}
