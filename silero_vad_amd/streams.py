@@ -57,6 +57,37 @@ def _rates(sr: int):
 
 
 # ---- offline: ragged corpora ------------------------------------------------------------------------
+def _bucket_cuts(L: np.ndarray, max_waste: float, max_bytes: int, itemsize: int):
+    """The greedy bucketing of RaggedPlan on arrays: -> (order, cuts) with order = the non-empty recordings by descending length (ties in
+    index order) and bucket k = order[cuts[k] : cuts[k + 1]].  A bucket takes recordings while the zero padding to its first (longest)
+    member wastes at most max_waste of its samples and its padded size stays within max_bytes; the waste grows with every (shorter)
+    member, so the first violation ends the bucket -- found block-wise on prefix sums instead of one Python iteration per recording
+    (151 552 recordings of a corpus shard: 85 ms of planning in front of the first upload before, ~10 after)."""
+    live = np.flatnonzero(L > 0)
+    order = live[np.argsort(-L[live], kind="stable")]
+    Ls = L[order]
+    cs = np.zeros(len(order) + 1, dtype=np.int64)
+    np.cumsum(Ls, out=cs[1:])
+    cuts = [0]
+    s, n = 0, len(order)
+    while s < n:
+        mx = int(Ls[s])
+        hi = min(n - s, max(1, max_bytes // (mx * itemsize)))     # the first member is always taken
+        cnt, k0, blk = hi, 2, 256
+        while k0 <= hi:
+            k = np.arange(k0, min(hi, k0 + blk - 1) + 1, dtype=np.int64)          # members the bucket would have
+            waste = 1.0 - (cs[s + k] - cs[s]) / (mx * k)
+            bad = np.flatnonzero(waste > max_waste)
+            if len(bad):
+                cnt = int(k[bad[0]]) - 1
+                break
+            k0 += blk
+            blk *= 2
+        s += cnt
+        cuts.append(s)
+    return order, cuts
+
+
 class RaggedPlan:
     """Buckets of recording indices, each processed as one lock-step batch.
 
@@ -66,26 +97,11 @@ class RaggedPlan:
 
     def __init__(self, lengths: Sequence[int], max_waste: float = 0.15, max_bytes: int = 1 << 30,
                  itemsize: int = 4):
-        self.lengths = [int(n) for n in lengths]
-        order = sorted((i for i, n in enumerate(self.lengths) if n > 0),
-                       key=lambda i: self.lengths[i], reverse=True)
-        self.empty = [i for i, n in enumerate(self.lengths) if n <= 0]
-        self.buckets: List[List[int]] = []
-        cur, cur_max, cur_sum = [], 0, 0
-        for i in order:                                   # descending: bucket max = its first member
-            n = self.lengths[i]
-            if cur:
-                padded = cur_max * (len(cur) + 1)
-                waste = 1.0 - (cur_sum + n) / padded
-                if waste > max_waste or padded * itemsize > max_bytes:
-                    self.buckets.append(cur)
-                    cur, cur_max, cur_sum = [], 0, 0
-            if not cur:
-                cur_max = n
-            cur.append(i)
-            cur_sum += n
-        if cur:
-            self.buckets.append(cur)
+        L = np.asarray(lengths, dtype=np.int64).reshape(-1)
+        self.lengths = L.tolist()
+        self.empty = np.flatnonzero(L <= 0).tolist()
+        order, cuts = _bucket_cuts(L, max_waste, max_bytes, itemsize)
+        self.buckets: List[List[int]] = [order[cuts[k]:cuts[k + 1]].tolist() for k in range(len(cuts) - 1)]
 
     def padded_samples(self) -> int:
         return sum(self.lengths[b[0]] * len(b) for b in self.buckets)
@@ -246,38 +262,44 @@ class WindowedPlan:
     `density` = live bytes / copied bytes: a sparse set (recordings scattered over a large arena) is better served by the
     gather kernel (streams.ragged_buckets)."""
 
-    def __init__(self, rec: PackedRecordings, max_waste, max_bytes, itemsize, window_bytes):
+    def __init__(self, rec: PackedRecordings, max_waste, max_bytes, itemsize, window_bytes, on_windows=None):
+        """on_windows(plan): called as soon as the windows, their spans and the density are known and BEFORE the buckets are planned --
+        the hook for starting the first windows' DMA while the rest of the planning runs."""
         self.lengths = rec.lengths.tolist()
-        self.empty = [i for i, m in enumerate(self.lengths) if m <= 0]
         offs, lens = rec.offsets, rec.lengths
+        self.empty = np.flatnonzero(lens <= 0).tolist()
         live = np.flatnonzero(lens > 0)
         by_offset = live[np.argsort(offs[live], kind="stable")]
         ends = offs[by_offset] + lens[by_offset]
         overlap_free = bool(np.all(offs[by_offset][1:] >= ends[:-1])) if len(by_offset) > 1 else True
         order = by_offset if overlap_free else live
-        self.windows, self.span = [], []                   # recording indices of each window (arena order), (first, last + 1) sample
-        cur, a0, a1 = [], 0, 0
-        for i in order.tolist():
-            o, e = int(offs[i]), int(offs[i] + lens[i])
-            if cur and (o < a1 or (e - a0) * itemsize > window_bytes):
-                self.windows.append(cur)
-                self.span.append((a0, a1))
-                cur = []
-            if not cur:
-                a0 = o
-            cur.append(i)
-            a1 = e
-        if cur:
-            self.windows.append(cur)
-            self.span.append((a0, a1))
-        self.buckets, self.window_of = [], []
-        for w, idx in enumerate(self.windows):
-            sub = RaggedPlan([self.lengths[i] for i in idx], max_waste, max_bytes, itemsize)
-            for b in sub.buckets:
-                self.buckets.append([idx[i] for i in b])
-                self.window_of.append(w)
+        # windows: runs of `order` in which the offsets do not turn back, cut greedily where the span would exceed window_bytes (a
+        # window always takes its first recording) -- on arrays: one searchsorted per window instead of one iteration per recording
+        o, e = offs[order], offs[order] + lens[order]
+        limit = window_bytes // itemsize                   # (e - a0) * itemsize > window_bytes  <=>  e - a0 > limit
+        turns = np.flatnonzero(o[1:] < e[:-1]) + 1 if len(order) > 1 else np.zeros(0, dtype=np.int64)
+        starts = np.concatenate([[0], turns, [len(order)]]).astype(np.int64) if len(order) else np.zeros(1, dtype=np.int64)
+        bounds = []
+        for r in range(len(starts) - 1):
+            lo, hi = int(starts[r]), int(starts[r + 1])
+            while lo < hi:
+                nxt = lo + max(1, int(np.searchsorted(e[lo:hi], o[lo] + limit, side="right")))
+                bounds.append((lo, nxt))
+                lo = nxt
+        self.windows = [order[a:b].tolist() for a, b in bounds]      # recording indices of each window (arena order)
+        self.span = [(int(o[a]), int(e[b - 1])) for a, b in bounds]  # (first, last + 1) sample
         copied = sum(b - a for a, b in self.span)
         self.density = float(lens[live].sum()) / copied if copied else 0.0
+        self.buckets, self.window_of = [], []
+        if on_windows is not None:
+            on_windows(self)
+        for w, (a, b) in enumerate(bounds):
+            idx = order[a:b]
+            sub_order, cuts = _bucket_cuts(lens[idx], max_waste, max_bytes, itemsize)
+            glob = idx[sub_order]
+            for k in range(len(cuts) - 1):
+                self.buckets.append(glob[cuts[k]:cuts[k + 1]].tolist())
+                self.window_of.append(w)
 
     def mean_window_fill(self):
         return float(np.mean([len(w) for w in self.windows])) if self.windows else 0.0
@@ -401,6 +423,48 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     dev = getattr(model, "device", None)
     on_gpu = dev is not None and torch.device(dev).type == "cuda"
     mode = _upload_mode()
+    lane_list = pool = cur = None
+    if on_gpu:                                            # (before the plan: the first windows' DMA starts while the buckets are planned)
+        lane_list = _compute_lanes(model, max(1, int(lanes)))
+        pool = getattr(model, "_stage_pool", None)
+        if pool is None or pool.slots != len(lane_list) + 1:
+            pool = model._stage_pool = _StagePool(dev, len(lane_list) + 1)
+            # the upload stream beside every compute lane, not in front of one of them
+            pool.stream = _distinct_queue_stream(getattr(model, "engine", None), dev, [st for _, st in lane_list])
+        cur = torch.cuda.current_stream(dev)
+    copies = []                                           # (start event, end event) of every H2D copy, for STATS
+    # One large H2D DMA per arena window (copy engines: no CU time, no host time, exactly the live bytes), two windows
+    # ahead of the kernels; the padded [rows][pitch] batches are then cut out of the window's device copy at HBM speed.
+    win = {"buf": [None, None, None], "free": [None, None, None], "ev": {}, "next": 0, "span": [], "base": None, "stream": None}
+
+    def ensure_window(w):
+        while win["next"] <= w and win["next"] < len(win["span"]):
+            v = win["next"]
+            a, b = win["span"][v]
+            j = v % 3
+            nb = (b - a) * esz
+            if win["buf"][j] is None or win["buf"][j].numel() < nb:
+                # (the old block goes back to the caching allocator: its cuts on pool.stream were recorded against it
+                #  -- record_stream below -- and the copy stream waits for the last of them before anything else)
+                if win["free"][j] is not None:
+                    win["stream"].wait_event(win["free"][j])
+                with torch.cuda.stream(win["stream"]):
+                    win["buf"][j] = torch.empty(max(nb, 1 << 20), dtype=torch.uint8, device=dev)
+                win["buf"][j].record_stream(pool.stream)  # allocated on the copy stream, read by the cut kernels on pool.stream
+                win["free"][j] = None
+            if win["free"][j] is not None:                # every bucket cut from the buffer's previous window is done
+                win["stream"].wait_event(win["free"][j])
+            with torch.cuda.stream(win["stream"]):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(win["stream"])
+                win["buf"][j][:nb].view(dtype).copy_(win["base"][a:b], non_blocking=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(win["stream"])
+            copies.append((e0, e1))
+            STATS["h2d_bytes"] += nb
+            win["ev"][v] = e1
+            win["next"] += 1
+
     if plan is None and on_gpu and mode in ("", "window") and hasattr(getattr(model, "engine", None), "upload_rows"):
         # recordings that lie in ONE pinned host buffer (a PackedRecordings, or a list of views of one pinned tensor) and cover
         # most of the range they span: one DMA per arena window, batches cut on the device
@@ -408,8 +472,23 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         if packed is not None and packed.base.is_pinned():
             import os
             wbytes = int(os.environ.get("SILERO_VAD_AMD_WINDOW_BYTES", 0)) or max(2 * max_bytes, 1 << 30)
-            wp = WindowedPlan(packed, max_waste, max_bytes, esz, window_bytes=wbytes)
-            if mode == "window" or (wp.density >= 0.6 and wp.mean_window_fill() >= 16):
+
+            def takes_windows(wp_):
+                return mode == "window" or (wp_.density >= 0.6 and wp_.mean_window_fill() >= 16)
+
+            def first_windows(wp_):
+                # the windows are known, the buckets are not yet: the first three windows' copies start NOW, the bucket planning (tens
+                # of ms for a corpus shard) runs beside them
+                if prepare_only or not takes_windows(wp_):
+                    return
+                win["span"], win["base"] = wp_.span, packed.base
+                win["stream"] = getattr(pool, "copy_stream", None) or torch.cuda.Stream(dev)
+                pool.copy_stream = win["stream"]
+                win["stream"].wait_stream(cur)            # (the arena was written before this call in stream order, if at all)
+                ensure_window(2)
+
+            wp = WindowedPlan(packed, max_waste, max_bytes, esz, window_bytes=wbytes, on_windows=first_windows)
+            if takes_windows(wp):
                 plan, audios = wp, packed
     plan = plan or RaggedPlan(lengths, max_waste, max_bytes, esz)
     src = _Sources(audios, dtype, check_pinned=on_gpu and mode != "stage" and hasattr(getattr(model, "engine", None), "upload_rows"))
@@ -422,54 +501,17 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             _stage_into(src, idxs, width, host)
             yield idxs, fast(host, sampling_rate).cpu()
         return
-    lane_list = _compute_lanes(model, max(1, int(lanes)))
-    pool = getattr(model, "_stage_pool", None)
-    if pool is None or pool.slots != len(lane_list) + 1:
-        pool = model._stage_pool = _StagePool(dev, len(lane_list) + 1)
-        # the upload stream beside every compute lane, not in front of one of them
-        pool.stream = _distinct_queue_stream(getattr(model, "engine", None), dev, [st for _, st in lane_list])
-    cur = torch.cuda.current_stream(dev)
     direct = src.pinned
     how = 0 if mode == "dma" else 1
     windowed = direct and isinstance(plan, WindowedPlan)
     if windowed:
-        # One large H2D DMA per arena window (copy engines: no CU time, no host time, exactly the live bytes), two windows
-        # ahead of the kernels; the padded [rows][pitch] batches are then cut out of the window's device copy at HBM speed.
-        win = {"buf": [None, None, None], "free": [None, None, None], "ev": {}, "next": 0,
-               "stream": getattr(pool, "copy_stream", None) or torch.cuda.Stream(dev)}
-        pool.copy_stream = win["stream"]
+        if win["stream"] is None:                          # (a plan handed in by the caller, or prepare_only: nothing was started early)
+            win["span"], win["base"] = plan.span, audios.base
+            win["stream"] = getattr(pool, "copy_stream", None) or torch.cuda.Stream(dev)
+            pool.copy_stream = win["stream"]
         last_bucket_of = {}
         for k, w in enumerate(plan.window_of):
             last_bucket_of[w] = k
-        base_t = audios.base
-
-        def ensure_window(w):
-            while win["next"] <= w and win["next"] < len(plan.span):
-                v = win["next"]
-                a, b = plan.span[v]
-                j = v % 3
-                nb = (b - a) * esz
-                if win["buf"][j] is None or win["buf"][j].numel() < nb:
-                    # (the old block goes back to the caching allocator: its cuts on pool.stream were recorded against it
-                    #  -- record_stream below -- and the copy stream waits for the last of them before anything else)
-                    if win["free"][j] is not None:
-                        win["stream"].wait_event(win["free"][j])
-                    with torch.cuda.stream(win["stream"]):
-                        win["buf"][j] = torch.empty(max(nb, 1 << 20), dtype=torch.uint8, device=dev)
-                    win["buf"][j].record_stream(pool.stream)  # allocated on the copy stream, read by the cut kernels on pool.stream
-                    win["free"][j] = None
-                if win["free"][j] is not None:                # every bucket cut from the buffer's previous window is done
-                    win["stream"].wait_event(win["free"][j])
-                with torch.cuda.stream(win["stream"]):
-                    e0 = torch.cuda.Event(enable_timing=True)
-                    e0.record(win["stream"])
-                    win["buf"][j][:nb].view(dtype).copy_(base_t[a:b], non_blocking=True)
-                    e1 = torch.cuda.Event(enable_timing=True)
-                    e1.record(win["stream"])
-                copies.append((e0, e1))
-                STATS["h2d_bytes"] += nb
-                win["ev"][v] = e1
-                win["next"] += 1
     align = 16 // esz                                      # device rows are 16-byte aligned: the kernels' vector loads
     # every lane's scratch is sized up front for the largest bucket it can meet: a growth inside the loop would
     # synchronise the device and stall all lanes (vad_reserve)
@@ -497,7 +539,6 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         return
     for _, st in lane_list[1:]:
         st.wait_stream(cur)                               # sibling lanes start behind whatever the caller has queued
-    copies = []                                           # (start event, end event) of every H2D copy, for STATS
     # Buckets on different lanes overlap because a bucket's recurrence sits on the few CUs its stream tiles need (16 streams per CU,
     # kernel_rec.hip) beside the other lane's frontend.  The matrix-vector form of the recurrence (kernel_rec_small.hip) finishes a
     # bucket of a few hundred recordings 2-3 x sooner but spreads it over the whole chip, with nothing left to overlap with: the
