@@ -34,6 +34,75 @@ def test_ragged_plan_covers_everything_once_and_bounds_waste():
     assert plan.padded_samples() <= plan.real_samples() / 0.9 + max(lens)
 
 
+def test_bucket_and_window_planners_equal_the_sequential_rules_fuzz():
+    """RaggedPlan / WindowedPlan plan on arrays (prefix sums, searchsorted); the rules they implement are sequential: recordings by
+    descending length, a bucket closes when the next member would push its padding waste above max_waste or its padded bytes above
+    max_bytes; a window closes where the arena order turns back or its span would exceed window_bytes.  Both restated here as plain
+    loops and compared on random sets (empty recordings, equal lengths, a ring that wraps, permuted hand-over order)."""
+    from silero_vad_amd import PackedRecordings, RaggedPlan
+    from silero_vad_amd.streams import WindowedPlan
+    rng = np.random.default_rng(11)
+
+    def buckets_loop(lens, max_waste, max_bytes, itemsize):
+        order = sorted((i for i, n in enumerate(lens) if n > 0), key=lambda i: -lens[i])      # stable: ties in index order
+        out, cur, tot = [], [], 0
+        for i in order:
+            if cur:
+                padded = lens[cur[0]] * (len(cur) + 1)
+                if 1.0 - (tot + lens[i]) / padded > max_waste or padded * itemsize > max_bytes:
+                    out.append(cur)
+                    cur, tot = [], 0
+            cur.append(i)
+            tot += lens[i]
+        return out + ([cur] if cur else [])
+
+    for trial in range(150):
+        n = int(rng.integers(0, 250))
+        kind = trial % 4
+        lens = (rng.integers(0, 200_000, size=n) if kind == 0 else rng.integers(500, 520, size=n) if kind == 1
+                else rng.choice([0, 512, 513, 16_000, 640_000], size=n) if kind == 2 else rng.integers(1, 40_000, size=n)).astype(np.int64)
+        mw, mb, isz = float(rng.choice([0.0, 0.05, 0.15, 0.5])), int(rng.choice([1 << 12, 1 << 16, 1 << 20, 1 << 30])), int(rng.choice([2, 4]))
+        ll = [int(v) for v in lens]
+        plan = RaggedPlan(ll, mw, mb, isz)
+        assert plan.buckets == buckets_loop(ll, mw, mb, isz), (trial, kind)
+        assert plan.empty == [i for i, v in enumerate(ll) if v <= 0] and plan.lengths == ll
+        if n == 0:
+            continue
+        # the same recordings in an arena: back to back with small gaps, as a ring that wraps, or handed over in another order
+        offs = np.concatenate([[0], np.cumsum(lens + rng.integers(0, 40, size=n))[:-1]]).astype(np.int64)
+        if kind == 1 and n > 6:
+            per = n // 3
+            offs = offs % int(offs[per - 1] + lens[per - 1] + 1)
+        elif kind == 2:
+            perm = rng.permutation(n)
+            offs, lens = offs[perm], lens[perm]
+        base = torch.zeros(int((offs + lens).max()) + 8, dtype=torch.int16)
+        wbytes = int(rng.choice([50_000, 200_000, 1 << 22]))
+        seen = {}
+        wp = WindowedPlan(PackedRecordings(base, offs, lens), mw, mb, 2, wbytes, on_windows=lambda p: seen.update(n=len(p.windows), b=len(p.buckets)))
+        live = [i for i in range(n) if lens[i] > 0]
+        by_off = sorted(live, key=lambda i: offs[i])
+        free = all(offs[b] >= offs[a] + lens[a] for a, b in zip(by_off, by_off[1:]))
+        windows, spans, cur, a0, a1 = [], [], [], 0, 0
+        for i in (by_off if free else live):
+            o, e = int(offs[i]), int(offs[i] + lens[i])
+            if cur and (o < a1 or (e - a0) * 2 > wbytes):
+                windows.append(cur)
+                spans.append((a0, a1))
+                cur = []
+            if not cur:
+                a0 = o
+            cur.append(i)
+            a1 = e
+        if cur:
+            windows.append(cur)
+            spans.append((a0, a1))
+        assert wp.windows == windows and wp.span == spans, (trial, kind)
+        want = [([w[j] for j in b], k) for k, w in enumerate(windows) for b in buckets_loop([int(lens[i]) for i in w], mw, mb, 2)]
+        assert wp.buckets == [b for b, _ in want] and wp.window_of == [k for _, k in want]
+        assert seen == {"n": len(windows), "b": 0}            # the hook fires once the windows are known, before any bucket is
+
+
 @pytest.mark.parametrize("as_i16", [False, True])
 def test_ragged_probs_equal_single_recording_runs(built, as_i16):
     """Zero padding to the bucket length must not change a recording's own probabilities."""
