@@ -25,7 +25,8 @@ The same JSON line also carries, for the record (none of them is the headline `v
                    stream_host  configs[4] END TO END through the native pump (vad_pump_*, csrc/pump.hip; no Python on the tick path):
                                 a source thread writes every tick's int16 chunks into a page-locked ring slot -> H2D copies and
                                 fused step kernels on two streams ordered by events -> VADIterator logic of every stream -> events:
-                                tick latency (slot written -> events) and sustained chunks/s against the int16 PCIe ceiling    [any N]
+                                tick latency (slot written -> events) and sustained chunks/s against the int16 PCIe ceiling
+                                (three ticks in flight unless two are clearly faster; median of three timed passes)            [any N]
                    corpus       configs[3]: every rank runs a FULL per-GPU shard of the 10 000 h corpus (1 250 h =
                                 151 552 ragged recordings, 37 passes of 4096 over fresh offsets) from pinned host
                                 memory -> device batch (no host copy) -> probs -> segmenter on the GPU -> segment
@@ -697,8 +698,16 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000, gaps=0.0):
         depth = int(os.environ["VAD_BENCH_STREAM_DEPTH"])
     runs = {f"depth{d}": {"ticks": 500, "wall_ms": round(st["wall_ms"], 2), "tick_ms_p50": round(st["tick_ms_p50"], 4),
                           "tick_ms_p95": round(st["tick_ms_p95"], 4)} for d, st in trial.items()}
-    best = {}
-    elapsed = timed(world, dist, dev, 1, lambda: best.update(play(ticks, depth)), gpu_sync)
+    # THREE timed passes of `ticks` ticks each, the median counts (all three are in the record): a leg that lasts 0.2-0.3 s on a shared
+    # host reads 10-20 % low when another tenant's burst falls into its one pass (r06K: 86.6 M where the untimed trial and four other
+    # leases read 104-110 M)
+    passes = []
+    for _ in range(3):
+        b_ = {}
+        passes.append((timed(world, dist, dev, 1, lambda: b_.update(play(ticks, depth)), gpu_sync), b_))
+    passes.sort(key=lambda x: x[0])
+    elapsed, best = passes[1]
+    timed_passes_s = [round(x[0], 4) for x in passes]
     full_rows = None
     if compact:
         fr = {}
@@ -762,7 +771,7 @@ def run_stream_host(args, rank, world, local, dist, ticks, sr=16000, gaps=0.0):
     out["sustained"] = {"depth": best["depth"], "fill_threads": best["fill_threads"], "tick_ms_p50": round(best["tick_ms_p50"], 4),
                         "tick_ms_p95": round(best["tick_ms_p95"], 4), "host_ms_per_tick": {"source_writes_slot": round(best["fill_ms_mean"], 4),
                         "submit": round(best["submit_ms_mean"], 4), "blocked_in_poll": round(best["wait_ms_mean"], 4)}, "untimed_depth_trials": runs,
-                        "native_wall_s": round(best["wall_ms"] / 1e3, 4)}
+                        "native_wall_s": round(best["wall_ms"] / 1e3, 4), "timed_passes_s": timed_passes_s, "value_is": "median of three timed passes"}
     ceiling = link * 1e9 / (n * 2) * world
     # (full-row ticks with gaps: the whole slot crosses the link every tick, so the link is held against the ticks; compact ticks carry
     #  the delivering streams' rows and a 5-byte-per-stream header, so it is held against the delivered chunks)
