@@ -341,6 +341,12 @@ int  vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present);
  * those of vad_pump_submit_present with the same flags, bit for bit; the link cost of a tick falls with the delivery rate.  present
  * must not be NULL.  Compact, masked and full ticks may be mixed freely.                                                         */
 int  vad_pump_submit_compact(vad_pump *p, int r, const uint8_t *present);
+/* A compact tick in ARRIVAL order -- what a receive path can fill without knowing who else will deliver: row i of vad_pump_slot(p, r)
+ * is the chunk of stream stream_of_row[i], i < n_rows (receive threads append with one atomic row counter per slot); every other stream
+ * is absent this tick.  A stream listed twice (two packets in one tick: keep the second for the next tick) or out of range is
+ * VAD_ERR_ARG and nothing is queued.  n_rows == 0: a tick in which nobody delivers.  Results as vad_pump_submit_present with the same
+ * set of streams, bit for bit.                                                                                                   */
+int  vad_pump_submit_rows(vad_pump *p, int r, const int32_t *stream_of_row, long n_rows);
 /* Retire the OLDEST submitted tick: wait for it (block != 0) or return VAD_PUMP_BUSY, run the iterator logic of every open
  * stream over its probabilities and write the tick's events (stream order; at most `cap`, the return value is how many there
  * were, <= streams).  *slot = the ring slot that is free again.  The probabilities stay readable in vad_pump_probs(p, slot)

@@ -78,6 +78,7 @@ SYMBOLS = {
     "vad_pump_play_gaps": (c_long, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_long, c_int, c_int, c_void_p, c_long,
                                     POINTER(PumpStats)]),
     "vad_pump_submit_compact": (c_int, [c_void_p, c_int, c_void_p]),
+    "vad_pump_submit_rows": (c_int, [c_void_p, c_int, c_void_p, c_long]),
     "vad_pump_play_compact": (c_long, [c_void_p, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_long, c_int, c_int, c_void_p, c_long,
                                        POINTER(PumpStats)]),
     "vad_pump_poll": (c_long, [c_void_p, c_int, c_void_p, c_long, POINTER(c_int)]),

@@ -397,7 +397,9 @@ const float *vad_pump_probs(const vad_pump *p, int r) {
 
 namespace {
 
-int submit_tick(vad_pump *p, int r, const uint8_t *present, bool compact) {
+// rows != nullptr: a compact tick whose rows lie in ARRIVAL order -- row i of the slot is the chunk of stream rows[i] (n_rows of them);
+// flags and positions are built here.  rows == nullptr && compact: row i is the i-th stream (ascending) whose flag is set.
+int submit_tick(vad_pump *p, int r, const uint8_t *present, bool compact, const int32_t *rows = nullptr, long n_rows = 0) {
     if (!p) return VAD_ERR_ARG;
     if (p->poisoned) return pfail(p, VAD_ERR_HIP, "the pump failed half-way through an earlier tick; destroy it (" + p->err + ")");
     if (r < 0 || r >= p->R) return pfail(p, VAD_ERR_ARG, "vad_pump_submit: no such ring slot");
@@ -405,6 +407,22 @@ int submit_tick(vad_pump *p, int r, const uint8_t *present, bool compact) {
     PUMP_TRY(p, hipSetDevice(p->device));
     const int buf = (int)(p->ticks % p->nb), pp = (int)(p->ticks & 1);
     const size_t S = (size_t)p->streams, N = (size_t)p->N, C = (size_t)p->C;
+    if (rows != nullptr || n_rows != 0) {
+        if (!rows || n_rows < 0 || n_rows > (long)S) return pfail(p, VAD_ERR_ARG, "vad_pump_submit_rows: bad row list");
+        uint8_t *fl = p->slot_present(r);
+        int32_t *pos = p->slot_pos(r);
+        std::memset(fl, 0, S);
+        for (long i = 0; i < n_rows; ++i) {
+            const int32_t b = rows[i];
+            if (b < 0 || (size_t)b >= S || fl[b]) {          // (validated before anything is queued: the slot's flags are scratch until then)
+                std::memset(fl, 0, S);
+                return pfail(p, VAD_ERR_ARG, "vad_pump_submit_rows: a stream out of range, or listed twice in one tick");
+            }
+            fl[b] = 1;
+            pos[b] = (int32_t)i;
+        }
+        present = fl;
+    }
     const bool masked = present != nullptr;
     if (compact && !masked) return pfail(p, VAD_ERR_ARG, "vad_pump_submit_compact: a compact tick needs its flags");
     if (masked && present != p->slot_present(r)) std::memcpy(p->slot_present(r), present, S);
@@ -419,9 +437,13 @@ int submit_tick(vad_pump *p, int r, const uint8_t *present, bool compact) {
         // the position table: row of the slot that holds stream b's chunk (the i-th delivering stream's chunk is row i)
         const uint8_t *fl = p->slot_present(r);
         int32_t *pos = p->slot_pos(r);
-        for (size_t b = 0; b < S; ++b) {
-            pos[b] = (int32_t)n_present;
-            n_present += fl[b] != 0;
+        if (rows != nullptr) {
+            n_present = (size_t)n_rows;                  // (positions were written with the flags)
+        } else {
+            for (size_t b = 0; b < S; ++b) {
+                pos[b] = (int32_t)n_present;
+                n_present += fl[b] != 0;
+            }
         }
     }
     const int16_t *src = p->slot_pcm(r);
@@ -484,6 +506,13 @@ extern "C" {
 int vad_pump_submit_present(vad_pump *p, int r, const uint8_t *present) { return submit_tick(p, r, present, false); }
 
 int vad_pump_submit_compact(vad_pump *p, int r, const uint8_t *present) { return submit_tick(p, r, present, true); }
+
+int vad_pump_submit_rows(vad_pump *p, int r, const int32_t *stream_of_row, long n_rows) {
+    if (!p) return VAD_ERR_ARG;
+    if (!stream_of_row && n_rows != 0) return pfail(p, VAD_ERR_ARG, "vad_pump_submit_rows: bad row list");
+    static const int32_t none = 0;
+    return submit_tick(p, r, nullptr, true, stream_of_row ? stream_of_row : &none, n_rows);
+}
 
 int vad_pump_submit(vad_pump *p, int r) { return submit_tick(p, r, nullptr, false); }
 

@@ -1587,6 +1587,12 @@ class StreamPump:
         fn = self._L.vad_pump_submit_compact if compact else self._L.vad_pump_submit_present
         self._check(fn(self._h, int(r), self._present[r].ctypes.data))
 
+    def submit_rows(self, r: int, stream_of_row):
+        """A compact tick in ARRIVAL order (vad_pump_submit_rows): row i of `slot(r)` holds the chunk of stream `stream_of_row[i]`; every
+        other stream is absent this tick.  A stream listed twice, or out of range, raises and queues nothing."""
+        rows = np.ascontiguousarray(stream_of_row, dtype=np.int32).reshape(-1)
+        self._check(self._L.vad_pump_submit_rows(self._h, int(r), rows.ctypes.data if len(rows) else None, len(rows)))
+
     def poll(self, block: bool = True):
         """-> (events, ring slot) of the oldest submitted tick; (None, None) if nothing is in flight or (block=False) it has not finished."""
         r = ctypes.c_int(-1)

@@ -98,6 +98,7 @@ def test_pump_and_split_step_refuse_without_a_device(built):
     assert L.vad_step_host_sync(h, 16000, 4, None, 2, None, None, None, None) == 4 and L.vad_step_host_sync(None, 16000, 4, None, 2, None, None, None, None) == 1
     assert L.vad_pump_present(None, 0) is None and L.vad_pump_submit_present(None, 0, None) == 1
     assert L.vad_pump_play_gaps(None, None, 0, 0, None, 0, 0, 0, 1, 0, None, 0, None) == -3
+    assert L.vad_pump_submit_rows(None, 0, None, 0) == 1
     assert L.vad_pump_submit_compact(None, 0, None) == 1 and L.vad_pump_play_compact(None, None, 0, 0, None, 0, 0, 0, 1, 0, None, 0, None) == -3
     assert L.vad_streams_overlap(None, None, None) == -1 and L.vad_streams_overlap(h, None, None) == -4
     L.vad_destroy(h)

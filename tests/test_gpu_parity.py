@@ -2489,7 +2489,7 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
     stream's chunks; the probabilities agree with the CPU oracle on the stream's own audio.  vad_pump_play_gaps (the loop natively,
     flags written by the source threads) gives the same events.  (reference: utils_vad.py:507-549, JIT!/vad/model/vad_annotator.py:72,86-87,
     examples/cpp/silero-vad-onnx.cpp:335-390)  COMPACT ticks (vad_pump_submit_compact / vad_pump_play_compact: only the delivering
-    streams' rows cross the link) give the same bits, alone and mixed with masked ticks."""
+    streams' rows cross the link; vad_pump_submit_rows: those rows in arrival order) give the same bits, alone and mixed with masked ticks."""
     from silero_vad_amd import StreamPump, VADIterator
     sr, g = SRS[tag], golden[tag]
     n = chunk_of(sr)
@@ -2503,7 +2503,7 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
     assert (pat.sum(0) == K).all() and 0.06 < missing < 0.15 and Tt > K + 5
     rec = golden["segments"][tag]["iterator"]["default"]
 
-    def run(pattern, compact=None):
+    def run(pattern, compact=None, arrival=None):
         pump = StreamPump(model.engine, sr, streams=cap, parts=2, ring_slots=3, **rec["init"])
         events = {s: [] for s in range(cap)}
         got = np.full((cap, K), np.nan, np.float32)
@@ -2518,11 +2518,17 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
                 slot[:] = 12345                                    # an absent stream's part of the slot holds whatever it holds
                 # compact ticks (vad_pump_submit_compact): the delivering streams' chunks back to back, nothing else crosses the link
                 packed = compact is not None and compact(t)
-                for i, s in enumerate(np.flatnonzero(fl)):
+                on = np.flatnonzero(fl)
+                if arrival is not None and packed:         # rows in ARRIVAL order (vad_pump_submit_rows): any order of the delivering streams
+                    on = arrival.permutation(on)
+                for i, s in enumerate(on):
                     slot[i if packed else s] = rows[s, pos[s] * n:(pos[s] + 1) * n]
                 sent.append((fl.copy(), pos.copy()))
                 pos += fl
-                pump.submit(r, present=None if pattern is None else fl, compact=packed)
+                if arrival is not None and packed:
+                    pump.submit_rows(r, on)
+                else:
+                    pump.submit(r, present=None if pattern is None else fl, compact=packed)
             if t > 0:
                 ev, r = pump.poll()
                 fl, at = sent[t - 1]
@@ -2558,13 +2564,28 @@ def test_pump_streams_with_gaps_equal_their_own_gap_free_runs(model, oracle, gol
         one = VADIterator(model, sampling_rate=sr, **rec["init"])
         mine = [e for t in range(K) if (e := one(torch.from_numpy(rows[s, t * n:(t + 1) * n].astype(np.float32) / 32768.0)))]
         assert got_ev[s] == mine, s
-    # compact slots: every tick, and mixed with masked ticks on one pump -- the same bits
-    for which in (lambda t: True, lambda t: t % 3 != 1):
-        c_got, c_ev, c_st = run(pat, compact=which)
+    # compact slots: every tick, mixed with masked ticks on one pump, and with the rows in arrival order -- the same bits
+    for which, arrival in ((lambda t: True, None), (lambda t: t % 3 != 1, None), (lambda t: t % 4 != 2, np.random.default_rng(9))):
+        c_got, c_ev, c_st = run(pat, compact=which, arrival=arrival)
         assert np.array_equal(c_got, want) and c_ev == want_ev
         for s in range(cap):
             for a, b in zip(c_st[s], want_st[s]):
                 assert np.array_equal(a, b), s
+    # a stream listed twice in one tick, or one that does not exist: refused, nothing queued, the pump goes on
+    pump = StreamPump(model.engine, sr, streams=cap, parts=1, ring_slots=2, **rec["init"])
+    for bad in ([3, 5, 3], [0, cap], [-1]):
+        with pytest.raises(Exception):
+            pump.submit_rows(0, bad)
+    assert pump.poll() == (None, None)
+    pump.slot(0)[:2] = rows[[7, 2], :n]
+    pump.submit_rows(0, [7, 2])
+    ev, r0 = pump.poll()
+    p0 = pump.probs(r0)
+    assert r0 == 0 and (p0[[2, 7]] >= 0).all() and (np.delete(p0, [2, 7]) == -1.0).all()
+    assert np.array_equal(p0[[7, 2]], want[[7, 2], 0])
+    pump.submit_rows(1, [])                                  # nobody delivers
+    assert pump.poll()[0] == [] and (pump.probs(1) == -1.0).all()
+    pump.close()
     # ... and one in which EVERYBODY delivers is the plain tick
     both = []
     for packed in (False, True):
