@@ -44,7 +44,7 @@ The same JSON line also carries, for the record (none of them is the headline `v
                    box's host cores under BASELINE.md section 3 protocols R1-R5 (rank 0, before the process group forms; R5 =
                    get_speech_timestamps on the fixture through the per-chunk protocol, the CPU figure beside `plumbing`)
 What rank 0 prints on stdout is ONE line of at most 8 192 bytes (`compact_line`: the contract's keys, `parity`, `roofline`, `cpu_baseline`,
-`legs`); the full record with every leg's prose and detail goes to gpurun_out/bench_detail.json and to stderr (`emit`).
+`legs`); the full record with every leg's prose and detail goes to gpurun_out/bench_detail.json (`emit`; stderr only names the file).
 `--config <name>` runs one of the other configs as the main leg instead.
 """
 import argparse
@@ -58,6 +58,9 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
+# c10d warns once per rank that the container's hostname does not resolve (the rendezvous is 127.0.0.1); the driver's record is a tail
+# of stdout + stderr, so stderr is kept quiet.  Read when torch's C++ side initialises: set before the first `import torch`.
+os.environ.setdefault("TORCH_CPP_LOG_LEVEL", "ERROR")
 sys.path.insert(0, str(ROOT))
 
 STREAMS = 4096           # per GPU (c2 / 8k)
@@ -1205,7 +1208,7 @@ def _num(x, nd=4):
 def compact_line(out):
     """THE line: everything the measurement contract names, in at most LINE_CAP bytes whatever the run held (9 legs, 8 ranks).  Per-leg
     workload prose, traffic detail, issue-pipe reading, untimed trials and per-rank records are NOT here: `emit` writes the full record to
-    DETAIL_FILE and to stderr.  Strings stay under 150 characters (the driver's parser clips there)."""
+    DETAIL_FILE (stderr only names it).  Strings stay under 150 characters (the driver's parser clips there)."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     line = {k: out[k] for k in keep if k in out}
     cfg = dict(out.get("config") or {})
@@ -1299,15 +1302,20 @@ def compact_line(out):
 
 
 def emit(out, stream=None):
-    """Rank 0's output: the full record to DETAIL_FILE (next to this file; `gpurun_out/` is what comes back from a GPU box) and to
-    stderr, then ONE line of at most LINE_CAP bytes on stdout, last."""
+    """Rank 0's output: the full record to DETAIL_FILE (next to this file; `gpurun_out/` is what comes back from a GPU box; stderr
+    only names it), then ONE line of at most LINE_CAP bytes on stdout, last."""
     try:
         path = ROOT / DETAIL_FILE
         path.parent.mkdir(parents=True, exist_ok=True)
         path.write_text(json.dumps(out, indent=1) + "\n")
     except OSError as e:
         print(f"bench: could not write {DETAIL_FILE}: {e}", file=sys.stderr)
-    print("bench detail: " + json.dumps(out), file=sys.stderr, flush=True)
+    # stderr stays SHORT: the driver's record is a tail of "stdout, then stderr" -- a 27 KB record dumped there would push the stdout
+    # line out of that tail (what made BENCH_r05 unparseable was size, not shape).  VAD_BENCH_STDERR_DETAIL=1 brings the dump back.
+    if os.environ.get("VAD_BENCH_STDERR_DETAIL"):
+        print("bench detail: " + json.dumps(out), file=sys.stderr, flush=True)
+    else:
+        print(f"bench detail: {DETAIL_FILE}", file=sys.stderr, flush=True)
     text = json.dumps(compact_line(out))
     assert len(text) <= LINE_CAP, len(text)
     print(text, file=stream or sys.stdout, flush=True)

@@ -159,7 +159,7 @@ def _worst_case_bench_record(world=8):
 def test_bench_line_fits_the_driver_tail(world, tmp_path, monkeypatch, capsys):
     """the driver keeps 8 KB of stdout and round 5's 21.7 KB line did not parse.  The REAL printing function
     (bench.emit) is given a worst-case record (nine legs with their prose, 8 ranks, an error leg): stdout is ONE line of at most 8192
-    bytes that strict json.loads accepts and that carries the keys the contract names; the full record goes to the detail file / stderr."""
+    bytes that strict json.loads accepts and that carries the keys the contract names; the full record goes to the detail file (stderr names it, nothing more)."""
     import json
     import bench
     monkeypatch.setattr(bench, "ROOT", tmp_path)
@@ -202,7 +202,10 @@ def test_bench_line_fits_the_driver_tail(world, tmp_path, monkeypatch, capsys):
     assert longest(d) <= 150                                      # the driver's parser clips strings there
     full = json.loads((tmp_path / d["detail"]).read_text())
     assert full["per_rank"] == out["per_rank"] and full["roofline"]["traffic_detail"] == out["roofline"]["traffic_detail"]
-    assert "bench detail: " in cap.err
+    # stderr only NAMES the detail file: the driver's record is a tail of "stdout, then stderr", so stdout + stderr together stay
+    # inside the 8 KB it keeps (a 27 KB dump on stderr would push the line out of that tail)
+    assert "bench detail: " in cap.err and len(cap.err.encode()) < 200
+    assert len(cap.out.encode()) + len(cap.err.encode()) <= 8192
 
 
 def test_bench_line_sheds_before_it_overflows(monkeypatch, tmp_path):
