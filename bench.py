@@ -115,7 +115,7 @@ def setup_dist(args):
     local = int(os.environ.get("LOCAL_RANK", 0))
     args.gpus = world
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or os.environ.get("VAD_BENCH_FORCE_RCCL"):          # (forced at world 1: the RCCL rehearsal a one-GPU box can run)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):   # single node: rendezvous over loopback

@@ -1620,6 +1620,46 @@ def test_bench_multi_rank_legs_run_on_shared_gpu(built):
     assert d["n_gpus"] == 2 and d["outputs_finite"] and d["value"] > 0
 
 
+def test_rccl_process_group_carries_the_bench_barrier_reduce_and_gather():
+    """The N > 1 launch talks through RCCL (backend "nccl"), which the shared-GPU rehearsals cannot take (gloo there: RCCL refuses two
+    ranks on one device).  What a one-GPU box CAN run is the same calls on a one-rank RCCL group: `bench.setup_dist` initialises it the way
+    the N = 8 launch does (device_id, loopback rendezvous, dmabuf IPC), `bench.timed` goes through its barrier + device-side float64
+    MAX-reduce branch, `sharding.gather_to_rank0` pickles a result through RCCL's gather -- the library loads, the communicator comes up
+    and every collective the bench issues is one RCCL accepts with these dtypes and placements."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = f"""
+import argparse, sys
+sys.path.insert(0, {str(root)!r})
+import numpy as np, torch, bench
+from silero_vad_amd.sharding import gather_to_rank0
+args = argparse.Namespace(dry=False, gpus=1)
+rank, world, local, dist = bench.setup_dist(args)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and (rank, world, local) == (0, 1, 0)
+dev = torch.device("cuda", local)
+x = torch.zeros(1 << 20, device=dev)
+elapsed = bench.timed(2, dist, dev, 5, lambda: x.add_(1.0), bench.gpu_sync)      # world = 2: the barrier / MAX-reduce branch
+assert 0.0 < elapsed < 5.0 and float(x[0]) == 5.0
+got = gather_to_rank0({{"rank": rank, "segments": np.arange(7, dtype=np.int64)}})
+assert len(got) == 1 and got[0]["rank"] == 0 and got[0]["segments"].tolist() == list(range(7))
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok", elapsed)
+"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               VAD_BENCH_FORCE_RCCL="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-500:] + r.stderr[-3000:]
+
+
 # ---- (18) edges of the new paths ----------------------------------------------------------------------------------------------------
 def test_corpus_edges_float_arena_empty_recordings_8k(model, oracle, golden):
     """The window route with a FLOAT32 arena, recordings of length 0 and shorter than one chunk inside it, at 8 kHz: every
