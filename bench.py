@@ -947,7 +947,7 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
              "host_ms": {k[:-2]: round(st.get(k, 0) * 1e3, 2) for k in ("setup_s", "reserve_s", "slot_wait_s", "slot_alloc_s", "result_wait_s")},
              "slot_allocs": int(st.get("slot_allocs", 0)), "stream_retries": int(st.get("stream_retries", 0)),
              "d2h_MB": round(st.get("d2h_bytes", 0) / 1e6, 3),
-             "buckets": int(st.get("buckets", 0)),
+             "buckets": int(st.get("buckets", 0)), "window_buffers": int(st.get("refill_window_buffers", 0)),
              "padded_over_real_samples": round(st.get("padded", 0) / max(st.get("real", 1), 1), 4)}
         if res.get("first_result_s") is not None:              # the refill scheduler hands results over as recordings retire
             d["first_result_at"] = round(res["first_result_s"] / elapsed, 4)     # fraction of the leg's wall time (planning included)
@@ -974,6 +974,9 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
         # (the whole shard: recordings are admitted longest first, so the first ones retire ten slabs in -- 2-3 % of a full shard's wall time,
         #  setup included; on six passes that would be 11 %)
         legs["pinned_refill_gather"], _ = run_leg(base_i, "refill", "gather", len(lens), False)
+        # the same scheduler fed from arena windows: recordings admitted in arena order, one DMA per 256 MB window a few slabs ahead of
+        # its readers, the slabs' rows cut from the windows' device copies (streams._refill_iter)
+        legs["pinned_refill_window"], _ = run_leg(base_i, "refill", "window", len(lens), False)
     os.environ.pop("SILERO_VAD_AMD_UPLOAD", None)
     # what the link allows: the H2D rate measured while copying / bytes per chunk -- a leg's value can approach it (fully
     # overlapped pipeline), never exceed it
@@ -1191,9 +1194,9 @@ def compact_legs(out):
             routes = {k: v.get("fraction_of_pcie_ceiling") for k, v in d["legs"].items() if k != "main"}
             if routes:
                 legs[name]["routes_of_link"] = routes
-            fr = d["legs"].get("pinned_refill_gather", {}).get("first_result_at")
-            if fr is not None:
-                legs[name]["refill_first_result_at"] = fr
+            fr = [d["legs"].get(k, {}).get("first_result_at") for k in ("pinned_refill_gather", "pinned_refill_window")]
+            if any(f is not None for f in fr):
+                legs[name]["refill_first_result_at"] = fr[0] if fr[1] is None else fr
     return legs
 
 

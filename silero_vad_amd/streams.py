@@ -250,6 +250,30 @@ class PackedRecordings:
         return out
 
 
+def _arena_windows(offs: np.ndarray, lens: np.ndarray, limit: int):
+    """The arena windows of a PackedRecordings (WindowedPlan's rules; also the refill route's window feed): (order, bounds, o, e) --
+    `order` = the live recordings in the order they are walked (by offset when nothing overlaps, else as handed over), `bounds` =
+    [(lo, hi)] index ranges of `order`, one per window: runs in which the offsets do not turn back, cut greedily where the span would
+    exceed `limit` samples (a window always takes its first recording); o / e = first / one-past-last sample of order's recordings.
+    On arrays: one searchsorted per window instead of one iteration per recording."""
+    live = np.flatnonzero(lens > 0)
+    by_offset = live[np.argsort(offs[live], kind="stable")]
+    ends = offs[by_offset] + lens[by_offset]
+    overlap_free = bool(np.all(offs[by_offset][1:] >= ends[:-1])) if len(by_offset) > 1 else True
+    order = by_offset if overlap_free else live
+    o, e = offs[order], offs[order] + lens[order]
+    turns = np.flatnonzero(o[1:] < e[:-1]) + 1 if len(order) > 1 else np.zeros(0, dtype=np.int64)
+    starts = np.concatenate([[0], turns, [len(order)]]).astype(np.int64) if len(order) else np.zeros(1, dtype=np.int64)
+    bounds = []
+    for r in range(len(starts) - 1):
+        lo, hi = int(starts[r]), int(starts[r + 1])
+        while lo < hi:
+            nxt = lo + max(1, int(np.searchsorted(e[lo:hi], o[lo] + limit, side="right")))   # (e - a0) > limit ends the window
+            bounds.append((lo, nxt))
+            lo = nxt
+    return order, bounds, o, e
+
+
 class WindowedPlan:
     """RaggedPlan per arena window.  A window is a set of recordings whose span -- first sample of the first .. last sample
     of the last -- is at most `window_bytes` and which lie in it in arena order without overlap, so that ONE DMA of the span
@@ -268,24 +292,8 @@ class WindowedPlan:
         self.lengths = rec.lengths.tolist()
         offs, lens = rec.offsets, rec.lengths
         self.empty = np.flatnonzero(lens <= 0).tolist()
-        live = np.flatnonzero(lens > 0)
-        by_offset = live[np.argsort(offs[live], kind="stable")]
-        ends = offs[by_offset] + lens[by_offset]
-        overlap_free = bool(np.all(offs[by_offset][1:] >= ends[:-1])) if len(by_offset) > 1 else True
-        order = by_offset if overlap_free else live
-        # windows: runs of `order` in which the offsets do not turn back, cut greedily where the span would exceed window_bytes (a
-        # window always takes its first recording) -- on arrays: one searchsorted per window instead of one iteration per recording
-        o, e = offs[order], offs[order] + lens[order]
-        limit = window_bytes // itemsize                   # (e - a0) * itemsize > window_bytes  <=>  e - a0 > limit
-        turns = np.flatnonzero(o[1:] < e[:-1]) + 1 if len(order) > 1 else np.zeros(0, dtype=np.int64)
-        starts = np.concatenate([[0], turns, [len(order)]]).astype(np.int64) if len(order) else np.zeros(1, dtype=np.int64)
-        bounds = []
-        for r in range(len(starts) - 1):
-            lo, hi = int(starts[r]), int(starts[r + 1])
-            while lo < hi:
-                nxt = lo + max(1, int(np.searchsorted(e[lo:hi], o[lo] + limit, side="right")))
-                bounds.append((lo, nxt))
-                lo = nxt
+        order, bounds, o, e = _arena_windows(offs, lens, window_bytes // itemsize)
+        live = order
         self.windows = [order[a:b].tolist() for a, b in bounds]      # recording indices of each window (arena order)
         self.span = [(int(o[a]), int(e[b - 1])) for a, b in bounds]  # (first, last + 1) sample
         copied = sum(b - a for a, b in self.span)
@@ -891,21 +899,29 @@ class RefillPlan:
     (slot, recording, first_sample, n_samples, reset) tuples per slab.  Recordings are admitted longest first, behind a few of the
     shortest (so that results start to flow at once)."""
 
-    def __init__(self, lengths: Sequence[int], slots: int, slab_chunks: int, chunk: int):
+    def __init__(self, lengths: Sequence[int], slots: int, slab_chunks: int, chunk: int, order=None):
+        """order: the admission order (recording indices; empty recordings are skipped) instead of longest-first -- the window feed
+        admits recordings in ARENA order, so that the bytes the slots need next are the bytes the next window DMA brings."""
         lens = self.lengths = np.ascontiguousarray(lengths, dtype=np.int64).reshape(-1)     # (an array: a shard has 10^5 recordings)
         self.slots, self.slab_chunks, self.chunk = int(slots), int(slab_chunks), int(chunk)
         if self.slots < 1 or self.slab_chunks < 1:
             raise ValueError("slots and slab_chunks must be positive")
         width = self.slab_chunks * self.chunk
         live = np.flatnonzero(lens > 0)
-        queue = live[np.argsort(-lens[live], kind="stable")]  # longest first, ties in input order
+        if order is not None:
+            queue = np.ascontiguousarray(order, dtype=np.int64).reshape(-1)
+            queue = queue[lens[queue] > 0]
+            if len(queue) != len(live) or len(np.unique(queue)) != len(queue):
+                raise ValueError("order must name every non-empty recording once")
+        else:
+            queue = live[np.argsort(-lens[live], kind="stable")]  # longest first, ties in input order
         # ... except that a sixteenth of the slots START with the shortest recordings: with the longest in every slot nothing retires
         # before the longest recording's last slab (a shard of 30 s recordings: 13 of 580 slabs, 5 % of the run, before the first result
         # reaches the host); the shortest retire after their own few slabs and the results flow from then on.  They are taken from the end
         # of the queue, where they would have filled the last slabs' gaps: a 1 / 16 of the slots' worth of the shortest does not move the
         # makespan of a shard.
         early = min(self.slots // 16, len(queue) - self.slots) if len(queue) > self.slots else 0
-        if early > 0:
+        if early > 0 and order is None:
             queue = np.concatenate([queue[len(queue) - early:][::-1], queue[:len(queue) - early]])
         self.empty = np.flatnonzero(lens <= 0).tolist()
         need = np.ascontiguousarray((lens[queue] + width - 1) // width)   # slabs each recording occupies its slot for
@@ -930,6 +946,11 @@ class RefillPlan:
             raise ValueError("vad_refill_table: bad arguments")
         # the schedule as arrays (slot, recording, first sample, samples, reset flag) per slab, for the vectorised stager
         self.slab_arrays = [rows[cuts[k]:cuts[k + 1]] for k in range(n_slabs)]
+        # first / last slab each recording is active in (-1: empty recording): what the window feed plans its device buffers on
+        self.first_slab = np.full(len(lens), -1, dtype=np.int64)
+        self.last_slab = np.full(len(lens), -1, dtype=np.int64)
+        self.first_slab[queue] = start
+        self.last_slab[queue] = start + need - 1
 
     @property
     def slabs(self) -> List[list]:
@@ -947,6 +968,33 @@ class RefillPlan:
         return int(((live + self.chunk - 1) // self.chunk).sum())
 
 
+def _assign_window_buffers(first: np.ndarray, last: np.ndarray, ahead: int):
+    """Device buffers for the refill route's arena windows, planned up front (the schedule is static).  Window w is first read by
+    the gather of slab first[w], last by the gather of slab last[w]; its DMA is ISSUED while slab issue[w] = max(0, first[w] - ahead)
+    is being staged, before that slab's gather.  A buffer may take window w if the window it held was last read by a slab BEFORE
+    issue[w] (its release event exists by then).  Windows are issued in index order (first[] is non-decreasing in arena order).
+    Returns (buffer index per window, number of buffers, issue slab per window)."""
+    first = np.asarray(first, dtype=np.int64)
+    last = np.asarray(last, dtype=np.int64)
+    issue = np.maximum(first - int(ahead), 0)
+    issue = np.maximum.accumulate(issue) if len(issue) else issue      # in-order issue: a window is never issued before its predecessor
+    buf = np.zeros(len(first), dtype=np.int64)
+    import heapq
+    busy = []                                                           # (last slab of the window held, buffer)
+    free = []
+    n_buf = 0
+    for w in range(len(first)):
+        while busy and busy[0][0] < issue[w]:
+            heapq.heappush(free, heapq.heappop(busy)[1])
+        if free:
+            j = heapq.heappop(free)
+        else:
+            j, n_buf = n_buf, n_buf + 1
+        buf[w] = j
+        heapq.heappush(busy, (int(last[w]), j))
+    return buf, n_buf, issue
+
+
 def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_chunks: int, plan: "RefillPlan" = None, on_slab=None):
     """The continuous-refill loop (RefillPlan) as a generator: stages slab k + 1 while the kernels of slab k run, scatters every slab's
     probabilities into one flat device tensor (recording i owns out_flat[base[i] : base[i + 1]]) and yields k once slab k has been
@@ -962,9 +1010,44 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
     dtype, esz = (torch.int16, 2) if as_i16 else (torch.float32, 4)
     lens_np = np.asarray(lengths, dtype=np.int64).reshape(-1)
     slots = max(1, min(int(slots), int((lens_np > 0).sum())))
+    mode = _upload_mode()
+    # The window feed (recordings that lie in ONE pinned arena, GPU engine, no plan handed in): recordings are admitted in ARENA order,
+    # the arena goes to the GPU by one DMA per window (copy engines: no CU time, exactly the live bytes) a few slabs ahead of the
+    # slots that read it, and a slab's rows are cut out of the windows' device copies at HBM speed -- instead of a gather kernel that
+    # reads 128 KB row pieces over PCIe beside the frontend (0.90 of the link).  The device buffers are planned up front
+    # (_assign_window_buffers: the schedule is static); a corpus whose long recordings would pin more than the budget of window
+    # buffers (SILERO_VAD_AMD_REFILL_WINDOW_BUDGET, 16 GiB of the 288) keeps the gather route.
+    wf = None
+    if plan is None and on_gpu and mode in ("", "window") and hasattr(eng, "upload_rows"):
+        import os
+        packed = audios if isinstance(audios, PackedRecordings) else _as_packed(audios)
+        if packed is not None and packed.base.is_pinned() and int((lens_np > 0).sum()):
+            slab_bytes = slots * slab_chunks * n * esz
+            wbytes = int(os.environ.get("SILERO_VAD_AMD_REFILL_WINDOW", 0)) or (1 << 30)        # (256 MiB windows: 0.92 of the link, 1 GiB: 0.95)
+            order, bounds, o_, e_ = _arena_windows(packed.offsets, packed.lengths, wbytes // esz)
+            spans = np.asarray([(o_[a], e_[b - 1]) for a, b in bounds], dtype=np.int64).reshape(-1, 2)
+            copied = int((spans[:, 1] - spans[:, 0]).sum())
+            dense = mode == "window" or float(lens_np[lens_np > 0].sum()) >= 0.6 * copied
+            if dense:
+                wplan = RefillPlan(lens_np, slots, slab_chunks, n, order=order)
+                win_of = np.full(len(lens_np), -1, dtype=np.int64)
+                for w, (a, b) in enumerate(bounds):
+                    win_of[order[a:b]] = w
+                w_first = np.asarray([wplan.first_slab[order[a:b]].min() for a, b in bounds], dtype=np.int64)
+                w_last = np.asarray([wplan.last_slab[order[a:b]].max() for a, b in bounds], dtype=np.int64)
+                wmax = int((spans[:, 1] - spans[:, 0]).max()) * esz
+                wmax = (wmax + 255) // 256 * 256
+                ahead = max(2, -(-2 * wmax // max(slab_bytes, 1))) + 1          # two windows' worth of slabs in front of the reader
+                buf_of, n_buf, issue = _assign_window_buffers(w_first, w_last, ahead)
+                budget = int(os.environ.get("SILERO_VAD_AMD_REFILL_WINDOW_BUDGET", 0)) or (16 << 30)
+                if n_buf * wmax <= budget:
+                    plan = wplan
+                    wf = {"packed": packed, "spans": spans, "win_of": win_of, "first": w_first, "last": w_last, "buf_of": buf_of,
+                          "n_buf": n_buf, "wmax": wmax, "issue": issue, "next": 0, "ev": {}, "release": {}, "holder": {}}
+                    STATS["refill_window_feed"] += 1
+                    STATS["refill_window_buffers"] = max(STATS["refill_window_buffers"], n_buf)
     plan = plan or RefillPlan(lens_np, slots, slab_chunks, n)
     B, S, width = plan.slots, plan.slab_chunks, plan.slab_chunks * n
-    mode = _upload_mode()
     src = _Sources(audios, dtype, check_pinned=on_gpu and mode != "stage" and hasattr(eng, "upload_rows"))
     direct = src.pinned                                # pinned recordings: one gather kernel per slab, no host copy
     how = 0 if mode == "dma" else 1
@@ -975,7 +1058,6 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
     ctx = torch.zeros((B, chunk_size(net_sr) // 8), dtype=torch.float32, device=dev)
     state = torch.zeros((2, B, 128), dtype=torch.float32, device=dev)
     done = np.zeros(len(audios), dtype=np.int64)       # chunks of each recording already produced
-    cols = np.arange(S, dtype=np.int64)[None, :]
     ctxm = contextlib.nullcontext() if not on_gpu else torch.cuda.device(dev)
     with ctxm:
         if on_gpu:
@@ -991,6 +1073,123 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
         ptr0 = src.ptr
         if on_gpu and hasattr(eng, "reserve"):
             eng.reserve(sampling_rate, B, S)
+        if wf is not None:
+            # the window buffers: one device block, kept on the staging pool from call to call; written by the copy stream, read by
+            # the cut kernels on pool.stream
+            need_b = wf["n_buf"] * wf["wmax"]
+            blk = getattr(pool, "refill_windows", None)
+            if blk is None or blk.numel() < need_b:
+                blk = pool.refill_windows = torch.empty(need_b, dtype=torch.uint8, device=dev)
+                STATS["slot_allocs"] += 1
+            # (the DMAs on a hardware queue that carries neither the slabs' kernels nor the cuts: a copy queued behind a kernel of
+            #  another stream on the same queue waits for it)
+            wf["stream"] = getattr(pool, "copy_stream", None) or _distinct_queue_stream(eng, dev, [cur, pool.stream])
+            pool.copy_stream = wf["stream"]
+            blk.record_stream(wf["stream"])
+            blk.record_stream(pool.stream)
+            wf["stream"].wait_stream(cur)                  # (the block's previous use, the arena's writer: both in front of this call)
+            wf["stream"].wait_stream(pool.stream)
+            wf["blk"] = blk
+            # every recording's device address, once: its window's buffer + its place in the window's span
+            w_ = wf["win_of"]
+            livem = w_ >= 0
+            dptr = np.zeros(len(lens_np), dtype=np.uint64)
+            dptr[livem] = (blk.data_ptr() + wf["buf_of"][w_[livem]] * wf["wmax"]
+                           + (wf["packed"].offsets[livem] - wf["spans"][w_[livem], 0]) * esz).astype(np.uint64)
+            ptr0 = dptr
+
+        def issue_windows(upto):
+            """start the DMA of every window whose issue slab is <= upto (in order; a buffer's previous window was released by an
+            earlier slab's cuts -- _assign_window_buffers)"""
+            while wf["next"] < len(wf["first"]) and wf["issue"][wf["next"]] <= upto:
+                v = wf["next"]
+                j = int(wf["buf_of"][v])
+                a, b = (int(x) for x in wf["spans"][v])
+                nb = (b - a) * esz
+                prev = wf["holder"].get(j)
+                if prev is not None:
+                    wf["stream"].wait_event(wf["release"].pop(prev))          # recorded behind the last cut that read window `prev`
+                with torch.cuda.stream(wf["stream"]):
+                    wf["blk"][j * wf["wmax"]: j * wf["wmax"] + nb].view(dtype).copy_(wf["packed"].base[a:b], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(wf["stream"])
+                wf["ev"][v] = ev
+                wf["holder"][j] = v
+                wf["by_first"].setdefault(int(wf["first"][v]), []).append(v)
+                STATS["h2d_bytes"] += nb
+                wf["next"] += 1
+
+        if wf is not None:
+            wf["by_first"] = {}
+            wf["by_last"] = {}
+            for v, l in enumerate(wf["last"]):
+                wf["by_last"].setdefault(int(l), []).append(v)
+
+        # The scatter indices and reset lists of G consecutive slabs cross the link in ONE copy (the schedule is static: a group's are
+        # known when its first slab is staged).  A small copy per slab costs the large transfers beside it far more than its bytes:
+        # the refill route's window DMAs ran at 0.907 of the link with a 2 MB copy per slab and the scans' three small ones, 0.949
+        # without them (profiles/r06_refill_window_feed.md).
+        import os as _os
+        G = max(1, int(_os.environ.get("SILERO_VAD_AMD_REFILL_GROUP", "8")))
+        n_slabs_all = len(plan.slab_arrays)
+        grp = {"g": -1, "host": [None, None], "ev": [None, None], "dev": None, "roff": {}, "next": 0}
+
+        def prepare(j):
+            """slab j's scatter description and reset list into its group's page-locked buffer: int64 [per slab: first output index of
+            every slot (B) | chunks every slot produces (B)] [resets of every slab] -- 48 KB per slab instead of the B S indices
+            themselves (2 MB: 0.75 % of the link's bytes on the gather route); the indices are formed on the device (scatter_index).
+            One slab per call: the host work stays spread over the slabs."""
+            g = j // G
+            lo, cnt = g * G, min(G, n_slabs_all - g * G)
+            q, b = j - lo, g % 2
+            cap = cnt * 3 * B
+            if q == 0:
+                if on_gpu and grp["ev"][b] is not None:
+                    grp["ev"][b].synchronize()                                 # the copy that last read this buffer (two groups ago)
+                if grp["host"][b] is None or grp["host"][b].numel() < cap:
+                    grp["host"][b] = torch.empty(max(cap, 1024), dtype=torch.int64, pin_memory=on_gpu)
+                grp["roff"][g] = [cnt * 2 * B]
+            e = plan.slab_arrays[j]                                        # [entries, 5], vectorised bookkeeping
+            sl, rec, take = e[:, 0], e[:, 1], e[:, 3]
+            nck = (take + n - 1) // n
+            hb = grp["host"][b].numpy()
+            v = hb[q * 2 * B:(q + 1) * 2 * B]
+            v[:] = 0                                                       # a slot without a recording produces nothing
+            v[sl] = base[rec] + done[rec]
+            v[B + sl] = nck
+            done[rec] += nck
+            rs = sl[e[:, 4] != 0]
+            r0 = grp["roff"][g][-1]
+            hb[r0:r0 + len(rs)] = rs
+            grp["roff"][g].append(r0 + len(rs))
+
+        def slab_meta(k):
+            """(first index per slot, chunks per slot, resets) of slab k as tensors where the kernels run; a group's ONE copy is issued
+            (on pool.stream) with its first slab"""
+            while grp["next"] < n_slabs_all and grp["next"] <= k + G:    # this slab's group is complete, the next one grows by a slab
+                prepare(grp["next"])
+                grp["next"] += 1
+            g = k // G
+            if g != grp["g"]:
+                b, roff = g % 2, grp["roff"][g]
+                grp["g"] = g
+                grp["roff"].pop(g - 1, None)
+                if not on_gpu:
+                    grp["dev"] = grp["host"][b][: roff[-1]].clone()
+                else:
+                    with torch.cuda.stream(pool.stream):
+                        grp["dev"] = grp["host"][b][: roff[-1]].to(dev, non_blocking=True)
+                        grp["ev"][b] = torch.cuda.Event()
+                        grp["ev"][b].record(pool.stream)
+            q, roff = k - g * G, grp["roff"][g]
+            return grp["dev"][q * 2 * B:(q + 1) * 2 * B], grp["dev"][roff[q]:roff[q + 1]]
+
+        cols_d = torch.arange(S, dtype=torch.int64, device=dev)[None, :]
+
+        def scatter_index(sn):
+            """[B S] output positions of a slab: slot b's chunk c goes to first[b] + c while c < chunks[b], to the sink otherwise"""
+            first, count = sn[:B, None], sn[B:, None]
+            return torch.where(cols_d < count, first + cols_d, total).reshape(-1)
 
         def stage(k):
             e = plan.slab_arrays[k]                                        # [entries, 5], vectorised bookkeeping
@@ -999,11 +1198,6 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
             lens = np.zeros(B, dtype=np.int64)
             rows[sl] = ptr0[rec] + (at * esz).astype(np.uint64)
             lens[sl] = take
-            nck = (take + n - 1) // n
-            dst = np.full((B, S), total, dtype=np.int64)                  # default: the sink
-            dst[sl] = np.where(cols < nck[:, None], (base[rec] + done[rec])[:, None] + cols, total)
-            done[rec] += nck
-            resets = sl[e[:, 4] != 0]
             rows_p = rows.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))
             lens_p = lens.ctypes.data_as(ctypes.POINTER(ctypes.c_long))
             nbytes = B * width * esz
@@ -1020,26 +1214,35 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
                 STATS["stage_s"] += time.perf_counter() - t0
             STATS["buckets"] += 1
             if not on_gpu:
-                return host, None, i, torch.from_numpy(dst.reshape(-1)), torch.from_numpy(np.ascontiguousarray(resets))
-            STATS["h2d_bytes"] += nbytes
+                idx_k, rs_k = slab_meta(k)
+                return host, None, i, idx_k, rs_k
+            if wf is None:
+                STATS["h2d_bytes"] += nbytes
+            else:
+                issue_windows(k)
+                for v in wf["by_first"].pop(k, ()):                         # the windows this slab is the first to read
+                    pool.stream.wait_event(wf["ev"].pop(v))
             d = pool.dev[i][:nbytes].view(dtype).view(B, width)
-            # scatter indices and reset list ride in the slot's own pinned scratch (no pinned allocation per slab)
-            m = pool.meta_buffer(i, B * S + len(resets))
-            m.numpy()[: B * S] = dst.reshape(-1)
-            m.numpy()[B * S:] = resets
+            idx_k, rs_k = slab_meta(k)                                      # (the group's one copy goes out with its first slab)
             if pool.consumed[i] is not None:
                 pool.stream.wait_event(pool.consumed[i])
             with torch.cuda.stream(pool.stream):
-                if direct:
+                if wf is not None:
+                    eng.upload_rows(rows_p, lens_p, B, width, esz, d, 2)      # (2: the rows are device addresses)
+                    STATS["upload_call_s"] += time.perf_counter() - t0
+                    for v in wf["by_last"].pop(k, ()):                         # the windows this slab is the last to read: released
+                        rel = torch.cuda.Event()
+                        rel.record(pool.stream)
+                        wf["release"][v] = rel
+                elif direct:
                     eng.upload_rows(rows_p, lens_p, B, width, esz, d, how)
                     STATS["upload_call_s"] += time.perf_counter() - t0
                 else:
                     d.copy_(host, non_blocking=True)
-                m_d = m.to(dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(pool.stream)
             pool.done[i] = ev
-            return d, ev, i, m_d[: B * S], m_d[B * S:]
+            return d, ev, i, idx_k, rs_k
 
         n_slabs = len(plan.slab_arrays)
         STATS["setup_s"] += time.perf_counter() - t_setup
@@ -1054,7 +1257,7 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
                 ctx.index_fill_(0, rs, 0.0)
                 state.index_fill_(1, rs, 0.0)
             probs = eng.forward_audio(x, sampling_rate, ctx, state)     # [B, S], carried ctx/state updated in place
-            out_flat.index_put_((idx,), probs.reshape(-1))
+            out_flat.index_put_((scatter_index(idx),), probs.reshape(-1))
             if on_gpu:
                 pool.consumed[slot] = torch.cuda.Event()
                 pool.consumed[slot].record(cur)
@@ -1149,7 +1352,25 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
                     torch.empty((cap, cap0, 2), dtype=torch.int64, pin_memory=True))
         return bufs
 
+    import os as _os
+    G = max(1, int(_os.environ.get("SILERO_VAD_AMD_REFILL_GROUP", "8")))
+    acc = {"lists": [], "since": 0, "first": True, "args": None}
+
     def on_slab(k, finished, out_flat, base):
+        # the recordings that retire are scanned G slabs at a time (the very first ones at once: results start to flow with the first
+        # retirement): a scan is three small copies, and small copies cost the large transfers beside them (see _refill_iter)
+        acc["args"] = (out_flat, base)
+        if len(finished):
+            acc["lists"].append(finished)
+        acc["since"] += 1
+        if acc["lists"] and (acc["first"] or acc["since"] >= G):
+            flush(k)
+        collect(False)
+
+    def flush(k):
+        out_flat, base = acc["args"]
+        finished = np.concatenate(acc["lists"]) if len(acc["lists"]) > 1 else acc["lists"][0]
+        acc["lists"], acc["since"], acc["first"] = [], 0, False
         if len(finished):
             # The scan of the recordings that retired in this slab runs on a SIDE stream, behind the slab's kernels by event: one lane per
             # recording walks ~1 000 probabilities one after the other (2-5 ms for the few dozen recordings of a slab) -- on the
@@ -1163,7 +1384,10 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
                 #  -- measured as 3.4 ms holes in the upload stream every time a wave of recordings retires, 0.79 instead of 0.90 of
                 #  the link, depending on which streams the process happened to create before)
                 pool = getattr(model, "_stage_pool", None)
-                side["stream"] = _distinct_queue_stream(eng, dev, [cur] + ([pool.stream] if pool is not None else []))
+                others = [cur] + ([pool.stream] if pool is not None else [])
+                if getattr(pool, "copy_stream", None) is not None:            # (the window feed's DMA queue)
+                    others.append(pool.copy_stream)
+                side["stream"] = _distinct_queue_stream(eng, dev, others)
             done_k = torch.cuda.Event()
             done_k.record(cur)
             side["stream"].wait_event(done_k)
@@ -1181,11 +1405,12 @@ def refill_segments_stream(audios: Sequence, model, sampling_rate: int = 16000, 
                 ev.record(side["stream"])
             pending.append((finished.copy(), bufs, m, ev, out_flat, meta))
             STATS["scan_s"] += time.perf_counter() - t0
-        collect(False)
 
     for _ in _refill_iter(audios, model, sampling_rate, slots, slab_chunks, None, on_slab):
         while ready:
             yield ready.pop(0)
+    if acc["lists"]:
+        flush(-1)
     collect(True)
     while ready:
         yield ready.pop(0)

@@ -2971,13 +2971,16 @@ def test_batch_speech_timestamps_on_raw_48k_recordings(model, golden, monkeypatc
 
 # ---- (33) the refill scheduler hands results over as recordings retire ------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["16k", "8k"])
-def test_refill_results_arrive_as_recordings_retire(model, golden, tag):
+def test_refill_results_arrive_as_recordings_retire(model, golden, tag, monkeypatch):
     """refill_segments_stream (the reference's pool returns each file's timestamps when that file is done,
     examples/parallel_example.ipynb cell 7): every recording is scanned on the GPU behind the slab it retires in.  The batches that
     come out cover every recording exactly once, the first one arrives long before the run is over (before a third of the batches of
     a 60-recording run through 6 slots), the segments EQUAL ragged_speech_segments' (the bucket scheduler's), with the list and the
     array form of refill_speech_segments agreeing, a recording with more segments than the optimistic copy holds (cap 32) included."""
     from silero_vad_amd import ragged_speech_segments, refill_segments_stream, refill_speech_segments
+    # (scans and index uploads go out once per SILERO_VAD_AMD_REFILL_GROUP slabs, 8 by default -- small copies cost the large transfers
+    #  beside them; slab by slab here, so that the batch count says something about a 40-slab run; the default is compared below)
+    monkeypatch.setenv("SILERO_VAD_AMD_REFILL_GROUP", "1")
     sr, g = SRS[tag], golden[tag]
     n = chunk_of(sr)
     wav = g["wav"]
@@ -3005,6 +3008,94 @@ def test_refill_results_arrive_as_recordings_retire(model, golden, tag):
     counts, flat = refill_speech_segments(audios, model, sr, slots=6, slab_chunks=8, as_arrays=True, **kw)
     assert lists == want and counts.tolist() == [len(w) for w in want]
     assert flat.tolist() == [[d["start"], d["end"]] for w in want for d in w]
+    for group in ("3", "8", "1000"):                               # grouped: fewer, larger batches, the same results, the first still early
+        monkeypatch.setenv("SILERO_VAD_AMD_REFILL_GROUP", group)
+        got, batches = {}, []
+        for idx, cnt, segs in refill_segments_stream(audios, model, sr, slots=6, slab_chunks=8, **kw):
+            batches.append(len(idx))
+            for i, c, sg in zip(idx.tolist(), cnt.tolist(), segs):
+                assert i not in got
+                got[i] = [{"start": int(a), "end": int(b)} for a, b in sg[:c]]
+        assert [got[i] for i in range(60)] == want and len(batches) < n_batches and batches[0] < 10
+
+
+# ---- (33b) the refill scheduler fed from arena windows ------------------------------------------------------------------------------------
+def test_refill_window_feed_equals_the_gather_route(model, golden, monkeypatch):
+    """The refill route's window feed: recordings back to back in ONE pinned arena are admitted in arena
+    order, the arena crosses the link by one DMA per window a few slabs ahead of its readers, the slabs' rows are cut from the windows'
+    device copies.  Probabilities and segments EQUAL the gather route's, bit for bit -- with windows of about three recordings (dozens of
+    windows, planned buffers reused), empty recordings, one recording that outlives its neighbours and pins its window's buffer, a float32
+    arena, a ring handed over twice (equal offsets, two passes), a permuted list of views, raw 48 kHz recordings; exactly the
+    windows' bytes cross the link; and a buffer budget too small for the plan falls back to the gather route."""
+    from silero_vad_amd import PackedRecordings, refill_probs, refill_speech_segments
+    from silero_vad_amd import streams as S
+    sr, n = 16000, 512
+    pcm = (golden["16k"]["wav"] * 32768.0).clip(-32768, 32767).astype(np.int16)
+    rng = np.random.default_rng(33)
+    lens = rng.integers(3 * n, 70 * n, 90)
+    lens[[5, 40]] = 0
+    lens[17] = 200 * n                                               # outlives its neighbours by far: pins its window's buffer
+    src_o = rng.integers(0, len(pcm) - 70 * n, 90)
+    src_o[17] = 0
+    offs = np.concatenate([[0], np.cumsum((lens + 7) // 8 * 8)[:-1]])
+    arena = torch.zeros(int(offs[-1] + lens[-1]) + 64, dtype=torch.int16).pin_memory()
+    for o, m, so in zip(offs, lens, src_o):
+        arena[o:o + m] = torch.from_numpy(np.resize(pcm[so:], m) if m > len(pcm) - so else pcm[so:so + m])
+    packed = PackedRecordings(arena, offs, lens)
+    kw = dict(slots=8, slab_chunks=8)
+    monkeypatch.setenv("SILERO_VAD_AMD_UPLOAD", "gather")
+    want = refill_probs(packed, model, sr, **kw)
+    want_seg = refill_speech_segments(packed, model, sr, threshold=0.4, **kw)
+    assert S.STATS["refill_window_feed"] == 0
+    monkeypatch.setenv("SILERO_VAD_AMD_REFILL_WINDOW", "120000")
+    n_windows = len(S._arena_windows(packed.offsets, packed.lengths, 120000 // 2)[1])
+    assert n_windows > 25
+    for mode in ("window", ""):                                      # (the default takes the window feed for a dense arena too)
+        monkeypatch.setenv("SILERO_VAD_AMD_UPLOAD", mode)
+        S.STATS.clear()
+        got = refill_probs(packed, model, sr, **kw)
+        assert all(torch.equal(g, w) for g, w in zip(got, want))
+        assert S.STATS["refill_window_feed"] == 1 and S.STATS["stage_s"] == 0
+        live_bytes = int(lens.sum()) * 2
+        assert live_bytes <= S.STATS["h2d_bytes"] <= live_bytes + 16 * len(lens)      # the arena once: live bytes + alignment gaps
+        assert 2 <= S.STATS["refill_window_buffers"] < n_windows // 2                   # the windows share the planned buffers
+        assert refill_speech_segments(packed, model, sr, threshold=0.4, **kw) == want_seg
+    # a ring handed over twice: equal offsets in the two passes, windows end where the order turns back
+    twice = PackedRecordings(arena, np.concatenate([offs, offs]), np.concatenate([lens, lens]))
+    S.STATS.clear()
+    got2 = refill_probs(twice, model, sr, **kw)
+    assert S.STATS["refill_window_feed"] == 1 and all(torch.equal(g, w) for g, w in zip(got2, want + want))
+    # a permuted list of views of the arena (streams._as_packed): walked in arena order
+    perm = np.random.default_rng(2).permutation(len(lens))
+    views = [arena[offs[i]:offs[i] + lens[i]] for i in perm]
+    S.STATS.clear()
+    gotv = refill_probs(views, model, sr, **kw)
+    assert S.STATS["refill_window_feed"] == 1 and all(torch.equal(g, want[j]) for g, j in zip(gotv, perm))
+    # a budget the plan does not fit in: the gather route, same bits
+    monkeypatch.setenv("SILERO_VAD_AMD_REFILL_WINDOW_BUDGET", "300000")
+    S.STATS.clear()
+    gotb = refill_probs(packed, model, sr, **kw)
+    assert S.STATS["refill_window_feed"] == 0 and all(torch.equal(g, w) for g, w in zip(gotb, want))
+    monkeypatch.delenv("SILERO_VAD_AMD_REFILL_WINDOW_BUDGET")
+    # float32 arena
+    arena_f = (arena.to(torch.float32) / 32768.0).pin_memory()
+    pf = PackedRecordings(arena_f, offs, lens)
+    monkeypatch.setenv("SILERO_VAD_AMD_UPLOAD", "gather")
+    want_f = refill_probs(pf, model, sr, **kw)
+    monkeypatch.setenv("SILERO_VAD_AMD_UPLOAD", "window")
+    S.STATS.clear()
+    got_f = refill_probs(pf, model, sr, **kw)
+    assert S.STATS["refill_window_feed"] == 1 and all(torch.equal(g, w) for g, w in zip(got_f, want_f))
+    # raw 48 kHz recordings: a chunk is 1 536 raw samples, the frontend's loads take every third
+    lens3 = (lens[:30] // 3) * 3 + 3 * n
+    offs3 = np.concatenate([[0], np.cumsum((lens3 + 7) // 8 * 8)[:-1]])
+    p3 = PackedRecordings(arena, offs3, lens3)
+    monkeypatch.setenv("SILERO_VAD_AMD_UPLOAD", "gather")
+    want3 = refill_probs(p3, model, 48000, **kw)
+    monkeypatch.setenv("SILERO_VAD_AMD_UPLOAD", "window")
+    S.STATS.clear()
+    got3 = refill_probs(p3, model, 48000, **kw)
+    assert S.STATS["refill_window_feed"] == 1 and all(torch.equal(g, w) for g, w in zip(got3, want3))
 
 
 # ---- (34) the one-workgroup-per-stream step (kernel_step_one.hip) against the tile kernels, bit for bit -------------------------------------

@@ -209,6 +209,59 @@ def test_refill_plan_covers_every_sample_once():
         assert plan.padded_chunks() >= plan.real_chunks()
 
 
+def test_refill_plan_in_a_given_order_admits_first_come_first_served():
+    """RefillPlan(order=): what the window feed plans on.  Every sample once, in order, like the default plan; recordings are ADMITTED in
+    the given order (start slabs never decrease along it), empty recordings are skipped, and an order that misses or repeats a recording
+    is refused."""
+    from silero_vad_amd import RefillPlan
+    rng = np.random.default_rng(9)
+    lengths = np.concatenate([rng.integers(1, 30000, size=41), [0, 512, 0, 513]])
+    order = rng.permutation(len(lengths))
+    for slots, slab in ((1, 3), (4, 4), (7, 16), (64, 2)):
+        plan = RefillPlan(lengths, slots, slab, 512, order=order)
+        seen = np.zeros(len(lengths), dtype=np.int64)
+        for k, entries in enumerate(plan.slabs):
+            for sl, rec, at, take, reset in entries:
+                assert at == seen[rec] and plan.first_slab[rec] <= k <= plan.last_slab[rec]
+                seen[rec] += take
+        assert np.array_equal(seen, lengths)
+        live = order[lengths[order] > 0]
+        assert np.all(np.diff(plan.first_slab[live]) >= 0)                           # first come, first served
+        assert np.all(plan.first_slab[lengths == 0] == -1) and np.all(plan.last_slab[live] >= plan.first_slab[live])
+        width = slab * 512
+        assert np.array_equal(plan.last_slab[live] - plan.first_slab[live] + 1, (lengths[live] + width - 1) // width)
+    with pytest.raises(ValueError):
+        RefillPlan(lengths, 4, 4, 512, order=order[:-1] if lengths[order[-1]] > 0 else order[1:])
+    with pytest.raises(ValueError):
+        RefillPlan(lengths, 4, 4, 512, order=np.concatenate([order, order[:1]]))
+
+
+def test_window_buffers_are_never_shared_by_two_live_windows_fuzz():
+    """_assign_window_buffers (the refill route's window feed): a buffer takes a new window only if the window it held was last read by a
+    slab BEFORE the slab at which the new window's DMA is issued; windows are issued in order, each at or before its first reader; and
+    the count is what a greedy interval colouring needs (the largest number of windows alive at once)."""
+    from silero_vad_amd.streams import _assign_window_buffers
+    rng = np.random.default_rng(21)
+    for trial in range(200):
+        nw = int(rng.integers(1, 60))
+        first = np.sort(rng.integers(0, 80, nw))
+        last = first + rng.integers(0, 1 + int(rng.integers(1, 50)), nw)
+        if trial % 10 == 0:
+            last[int(rng.integers(0, nw))] += 500                                   # one window pinned by a very long recording
+        ahead = int(rng.integers(0, 9))
+        buf, n_buf, issue = _assign_window_buffers(first, last, ahead)
+        assert np.all(issue <= first) and np.all(np.diff(issue) >= 0) and np.all(issue >= 0)
+        assert buf.min() == 0 and buf.max() == n_buf - 1
+        for j in range(n_buf):
+            ws = np.flatnonzero(buf == j)
+            for a, b in zip(ws[:-1], ws[1:]):
+                assert last[a] < issue[b]                                           # released before the next DMA into it is issued
+        alive = max(int(np.sum((issue <= t) & (last >= t))) for t in range(int(last.max()) + 1))
+        assert n_buf == alive
+    buf, n_buf, issue = _assign_window_buffers(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), 3)
+    assert n_buf == 0 and len(buf) == 0
+
+
 def test_refill_table_equals_its_numpy_definition():
     """vad_refill_table (native, two counting passes) against the definition it replaced: repeat every queue entry over its slabs, sort
     the rows by (slab, slot)."""
