@@ -186,6 +186,17 @@ def _distinct_queue_stream(engine, device, others, tries=12, priority=0):
     return best
 
 
+def _copy_stream(pool, model, device, others):
+    """The staging pool's stream for the arena windows' DMAs, on a hardware queue that carries none of `others` (compute lanes, the
+    cut / upload stream): the runtime orders a copy inside its stream's queue, so a 37 ms window DMA on a lane's queue stands in front
+    of that lane's kernels (the raw 48 kHz corpus leg read 0.71 instead of 0.96 of the link when an unprobed stream landed there
+    after other legs had created streams of their own).  Made once per pool."""
+    st = getattr(pool, "copy_stream", None)
+    if st is None:
+        st = pool.copy_stream = _distinct_queue_stream(getattr(model, "engine", None), device, list(others))
+    return st
+
+
 def _compute_lanes(model, want):
     """[(model, stream)]: lane 0 is the caller's model on the caller's stream; further lanes are CLONES of its engine
     (vad_clone: the same weight images and options, their own scratch -- no second weight copy, no option drift) on
@@ -490,8 +501,7 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
                 if prepare_only or not takes_windows(wp_):
                     return
                 win["span"], win["base"] = wp_.span, packed.base
-                win["stream"] = getattr(pool, "copy_stream", None) or torch.cuda.Stream(dev)
-                pool.copy_stream = win["stream"]
+                win["stream"] = _copy_stream(pool, model, dev, [st for _, st in lane_list] + [pool.stream])
                 win["stream"].wait_stream(cur)            # (the arena was written before this call in stream order, if at all)
                 ensure_window(2)
 
@@ -515,8 +525,7 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
     if windowed:
         if win["stream"] is None:                          # (a plan handed in by the caller, or prepare_only: nothing was started early)
             win["span"], win["base"] = plan.span, audios.base
-            win["stream"] = getattr(pool, "copy_stream", None) or torch.cuda.Stream(dev)
-            pool.copy_stream = win["stream"]
+            win["stream"] = _copy_stream(pool, model, dev, [st for _, st in lane_list] + [pool.stream])
         last_bucket_of = {}
         for k, w in enumerate(plan.window_of):
             last_bucket_of[w] = k
@@ -1083,8 +1092,7 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
                 STATS["slot_allocs"] += 1
             # (the DMAs on a hardware queue that carries neither the slabs' kernels nor the cuts: a copy queued behind a kernel of
             #  another stream on the same queue waits for it)
-            wf["stream"] = getattr(pool, "copy_stream", None) or _distinct_queue_stream(eng, dev, [cur, pool.stream])
-            pool.copy_stream = wf["stream"]
+            wf["stream"] = _copy_stream(pool, model, dev, [cur, pool.stream])
             blk.record_stream(wf["stream"])
             blk.record_stream(pool.stream)
             wf["stream"].wait_stream(cur)                  # (the block's previous use, the arena's writer: both in front of this call)
