@@ -1394,7 +1394,17 @@ def main():
                         ("stream_host_8k", lambda: run_stream_host(args, rank, world, local, dist, 2000, 8000)),
                         ("plumbing", lambda: {"config": {"workload": "configs[0]"}, **run_plumbing(args, local)}),
                         ("plumbing_8k", lambda: {"config": {"workload": "configs[0], 8 kHz"}, **run_plumbing(args, local, 8000)})]
+            def hand_back():
+                """between legs: the finished leg's device blocks (window buffers, staging slots, GiBs) go back to the driver instead of
+                sitting in torch's cache beside the next leg's own -- eight ranks rehearsed on ONE GPU ran out of memory that way"""
+                import gc
+                gc.collect()
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+
             for name, fn in legs:
+                if not args.dry:
+                    hand_back()
                 if world > 1:                           # every rank takes part in a leg's barriers: no swallowing of errors there
                     r = fn()
                     if rank == 0:

@@ -18,6 +18,7 @@ LIB_AB_PATH = PKG / "libsilero_vad_hip_ab.so"
 WEIGHTS_PATH = PKG / "data" / "silero_vad_v6.weights"
 
 VAD_OK = 0
+VAD_ERR_ALLOC = 6
 STATUS_NAMES = {1: "ARG", 2: "SAMPLE_RATE", 3: "WEIGHTS", 4: "NO_DEVICE", 5: "HIP", 6: "ALLOC",
                 7: "CAPTURE", 8: "OPTION"}
 

@@ -98,8 +98,19 @@ class Engine:
         """The engine computes in fp32 only; kept so that callers may state it."""
         self.set_option("precision", precision)
 
+    def _retry_alloc(self, call):
+        """The library's scratch is allocated outside torch's caching allocator: when it does not fit (VAD_ERR_ALLOC, returned before
+        anything was launched) while torch sits on freed blocks -- earlier calls' window buffers and staging slots, other ranks on the
+        same device -- those go back to the driver and the call is made once more."""
+        status = call()
+        if status == _lib.VAD_ERR_ALLOC and torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            status = call()
+        return status
+
     def reserve(self, sr, B, T):
-        self._check(self._L.vad_reserve(self._h, sr, B, T))
+        self._check(self._retry_alloc(lambda: self._L.vad_reserve(self._h, sr, B, T)))
 
     def scratch_generation(self):
         """Changes whenever the engine reallocated scratch: captured hipGraphs must then be re-captured."""
@@ -130,8 +141,8 @@ class Engine:
         fn = self._L.vad_forward_audio if pcm.dtype == torch.float32 else self._L.vad_forward_audio_i16
         ld = pcm.stride(0) if B > 1 else L          # a size-1 dim may carry any stride (e.g. 0)
         ldp = probs.stride(0) if B > 1 else T
-        self._check(fn(self._h, sr, B, L, pcm.data_ptr(), ld, ctx.data_ptr(),
-                       state.data_ptr(), probs.data_ptr(), ldp, self._stream()))
+        self._check(self._retry_alloc(lambda: fn(self._h, sr, B, L, pcm.data_ptr(), ld, ctx.data_ptr(),
+                                                 state.data_ptr(), probs.data_ptr(), ldp, self._stream())))
         return probs
 
     def step(self, pcm, sr, ctx, state, prob):

@@ -1048,7 +1048,11 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
                 wmax = (wmax + 255) // 256 * 256
                 ahead = max(2, -(-2 * wmax // max(slab_bytes, 1))) + 1          # two windows' worth of slabs in front of the reader
                 buf_of, n_buf, issue = _assign_window_buffers(w_first, w_last, ahead)
-                budget = int(os.environ.get("SILERO_VAD_AMD_REFILL_WINDOW_BUDGET", 0)) or (16 << 30)
+                budget = int(os.environ.get("SILERO_VAD_AMD_REFILL_WINDOW_BUDGET", 0))
+                if not budget:                                               # 16 GiB of the 288, less on a device that others fill
+                    held = getattr(getattr(model, "_stage_pool", None), "refill_windows", None)
+                    free = torch.cuda.mem_get_info(dev)[0] + (held.numel() if held is not None else 0)
+                    budget = min(16 << 30, free // 4)
                 if n_buf * wmax <= budget:
                     plan = wplan
                     wf = {"packed": packed, "spans": spans, "win_of": win_of, "first": w_first, "last": w_last, "buf_of": buf_of,
@@ -1088,6 +1092,10 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
             need_b = wf["n_buf"] * wf["wmax"]
             blk = getattr(pool, "refill_windows", None)
             if blk is None or blk.numel() < need_b:
+                if blk is not None:                        # a larger plan than the last call's: the old block goes back to the DRIVER
+                    blk = pool.refill_windows = None       # first (GiBs that torch's cache would keep beside the new one)
+                    torch.cuda.synchronize(dev)
+                    torch.cuda.empty_cache()
                 blk = pool.refill_windows = torch.empty(need_b, dtype=torch.uint8, device=dev)
                 STATS["slot_allocs"] += 1
             # (the DMAs on a hardware queue that carries neither the slabs' kernels nor the cuts: a copy queued behind a kernel of

@@ -219,3 +219,23 @@ def test_bench_line_sheds_before_it_overflows(monkeypatch, tmp_path):
     line = bench.compact_line(out)
     assert len(json.dumps(line)) <= bench.LINE_CAP and "legs" in line["shed"] and "roofline" in line and "cpu_baseline" in line
 
+
+
+def test_scratch_allocation_is_retried_once_after_torch_returned_its_cache(monkeypatch):
+    """The library allocates its scratch outside torch's caching allocator: a VAD_ERR_ALLOC (returned before anything is launched) makes
+    the host side hand torch's freed blocks back to the driver and call once more -- once; other statuses and a second failure pass
+    through.  (Found by the eight-ranks-on-one-GPU rehearsal: 8 x the corpus legs' cached window buffers left no room for a lane's gx.)"""
+    import torch
+    from silero_vad_amd import _lib
+    from silero_vad_amd.engine import Engine
+    log = []
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: log.append("sync"))
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: log.append("empty"))
+    answers = iter([_lib.VAD_ERR_ALLOC, _lib.VAD_OK])
+    assert Engine._retry_alloc(None, lambda: next(answers)) == _lib.VAD_OK and log == ["sync", "empty"]
+    answers = iter([_lib.VAD_ERR_ALLOC, _lib.VAD_ERR_ALLOC, _lib.VAD_OK])
+    assert Engine._retry_alloc(None, lambda: next(answers)) == _lib.VAD_ERR_ALLOC and len(log) == 4
+    answers = iter([5, _lib.VAD_OK])
+    assert Engine._retry_alloc(None, lambda: next(answers)) == 5 and len(log) == 4
+    assert Engine._retry_alloc(None, lambda: _lib.VAD_OK) == _lib.VAD_OK and len(log) == 4
