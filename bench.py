@@ -914,6 +914,9 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
             # multi-GB hipFree / hipMalloc, 1 ms on most boxes and 120-180 ms on others (profiles/r05_ingest_routes.md)
             S.ragged_reserve(PackedRecordings(src, (offs if src is base_i else offs_rand)[:nrec], lens[:nrec]), model, sr, max_waste=0.1,
                              max_bytes=int(os.environ.get("VAD_BENCH_BUCKET_BYTES", 1 << 30)))
+        else:                                                    # ... the refill route's: window buffers, slots, scratch (refill_reserve)
+            rs, rc_ = (int(v) for v in os.environ.get("VAD_BENCH_REFILL", "2048,128").split(","))
+            S.refill_reserve(PackedRecordings(src, (offs if src is base_i else offs_rand)[:nrec], lens[:nrec]), model, sr, slots=rs, slab_chunks=rc_)
         S.STATS.clear()
         nseg = []
 

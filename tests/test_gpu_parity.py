@@ -3060,6 +3060,15 @@ def test_refill_window_feed_equals_the_gather_route(model, golden, monkeypatch):
         assert live_bytes <= S.STATS["h2d_bytes"] <= live_bytes + 16 * len(lens)      # the arena once: live bytes + alignment gaps
         assert 2 <= S.STATS["refill_window_buffers"] < n_windows // 2                   # the windows share the planned buffers
         assert refill_speech_segments(packed, model, sr, threshold=0.4, **kw) == want_seg
+    # refill_reserve: everything the run allocates is allocated up front -- the run itself asks the allocator for no staging slot
+    # and no window block (slot_allocs counts both)
+    from silero_vad_amd import refill_reserve
+    bigger = PackedRecordings(arena, np.concatenate([offs, offs, offs]), np.concatenate([lens, lens, lens]))
+    refill_reserve(bigger, model, sr, slots=12, slab_chunks=16)
+    S.STATS.clear()
+    got3x = refill_probs(bigger, model, sr, slots=12, slab_chunks=16)
+    assert S.STATS["slot_allocs"] == 0 and S.STATS["refill_window_feed"] == 1
+    assert all(torch.equal(g, w) for g, w in zip(got3x, want + want + want))
     # a ring handed over twice: equal offsets in the two passes, windows end where the order turns back
     twice = PackedRecordings(arena, np.concatenate([offs, offs]), np.concatenate([lens, lens]))
     S.STATS.clear()

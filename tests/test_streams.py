@@ -339,6 +339,10 @@ def test_refill_equals_one_recording_at_a_time(oracle, sr):
                 continue
             want = oracle.audio_forward(np.pad(a.numpy(), (0, max(0, n - len(a))))[None], sr)[0]
             assert p.shape == want.shape and np.abs(p.numpy() - want).max() < 1e-6
+    from silero_vad_amd import RefillPlan, refill_reserve
+    from silero_vad_amd.streams import chunk_size
+    plan = refill_reserve(audios, model, sr, slots=5, slab_chunks=4)          # plans (and, on a GPU, allocates); runs nothing
+    assert isinstance(plan, RefillPlan) and plan.slots == 5 and plan.real_chunks() == sum((len(a) + chunk_size(sr) - 1) // chunk_size(sr) for a in audios)
     segs = refill_speech_segments(audios, model, sr, slots=5, slab_chunks=4, threshold=0.4, min_speech_duration_ms=64)
     for a, sg, p in zip(audios, segs, got):
         assert sg == (segment_probs(p, len(a), sr, threshold=0.4, min_speech_duration_ms=64) if len(a) else [])
