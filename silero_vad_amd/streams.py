@@ -261,12 +261,14 @@ class PackedRecordings:
         return out
 
 
-def _arena_windows(offs: np.ndarray, lens: np.ndarray, limit: int):
+def _arena_windows(offs: np.ndarray, lens: np.ndarray, limit: int, lead_limit: int = 0):
     """The arena windows of a PackedRecordings (WindowedPlan's rules; also the refill route's window feed): (order, bounds, o, e) --
     `order` = the live recordings in the order they are walked (by offset when nothing overlaps, else as handed over), `bounds` =
     [(lo, hi)] index ranges of `order`, one per window: runs in which the offsets do not turn back, cut greedily where the span would
     exceed `limit` samples (a window always takes its first recording); o / e = first / one-past-last sample of order's recordings.
-    On arrays: one searchsorted per window instead of one iteration per recording."""
+    On arrays: one searchsorted per window instead of one iteration per recording.  lead_limit: the FIRST windows are cut at lead_limit,
+    2 lead_limit, 4 lead_limit ... samples until `limit` is reached (the refill route's first slabs read little and should not wait
+    for a whole window)."""
     live = np.flatnonzero(lens > 0)
     by_offset = live[np.argsort(offs[live], kind="stable")]
     ends = offs[by_offset] + lens[by_offset]
@@ -279,7 +281,8 @@ def _arena_windows(offs: np.ndarray, lens: np.ndarray, limit: int):
     for r in range(len(starts) - 1):
         lo, hi = int(starts[r]), int(starts[r + 1])
         while lo < hi:
-            nxt = lo + max(1, int(np.searchsorted(e[lo:hi], o[lo] + limit, side="right")))   # (e - a0) > limit ends the window
+            lim = min(limit, lead_limit << min(len(bounds), 40)) if lead_limit else limit
+            nxt = lo + max(1, int(np.searchsorted(e[lo:hi], o[lo] + lim, side="right")))     # (e - a0) > limit ends the window
             bounds.append((lo, nxt))
             lo = nxt
     return order, bounds, o, e
@@ -908,9 +911,12 @@ class RefillPlan:
     (slot, recording, first_sample, n_samples, reset) tuples per slab.  Recordings are admitted longest first, behind a few of the
     shortest (so that results start to flow at once)."""
 
-    def __init__(self, lengths: Sequence[int], slots: int, slab_chunks: int, chunk: int, order=None):
+    def __init__(self, lengths: Sequence[int], slots: int, slab_chunks: int, chunk: int, order=None, ramp: int = 1):
         """order: the admission order (recording indices; empty recordings are skipped) instead of longest-first -- the window feed
-        admits recordings in ARENA order, so that the bytes the slots need next are the bytes the next window DMA brings."""
+        admits recordings in ARENA order, so that the bytes the slots need next are the bytes the next window DMA brings.
+        ramp (with order): the slots START over `ramp` slabs, a 1 / ramp of them per slab, lowest slots first -- the first slab then
+        needs the audio of slots / ramp recordings instead of all slots' (2 GiB for 2 048 slots of 30 s recordings: 37 ms of link
+        time in front of the first kernel), and the first recordings retire that much earlier."""
         lens = self.lengths = np.ascontiguousarray(lengths, dtype=np.int64).reshape(-1)     # (an array: a shard has 10^5 recordings)
         self.slots, self.slab_chunks, self.chunk = int(slots), int(slab_chunks), int(chunk)
         if self.slots < 1 or self.slab_chunks < 1:
@@ -936,11 +942,27 @@ class RefillPlan:
         need = np.ascontiguousarray((lens[queue] + width - 1) // width)   # slabs each recording occupies its slot for
         # event-driven form of "at every slab boundary, every free slot (in slot order) takes the next recording": a heap of (slab at
         # which the slot becomes free, slot) -- native (vad_refill_schedule: a corpus shard has 10^5 recordings)
-        start = np.zeros(len(queue), dtype=np.int64)
-        slot = np.zeros(len(queue), dtype=np.int64)
         lp = ctypes.POINTER(ctypes.c_long)
-        if lib().vad_refill_schedule(need.ctypes.data_as(lp), len(queue), self.slots, start.ctypes.data_as(lp), slot.ctypes.data_as(lp)):
-            raise ValueError("vad_refill_schedule: bad arguments")
+        ramp = int(ramp) if order is not None else 1
+        g = self.slots // ramp if ramp > 1 else 0
+        if ramp > 1 and g >= 1 and len(queue) > self.slots:
+            # the staggered start, expressed in the scheduler's own terms: behind the first g recordings (slots 0 .. g - 1 at slab 0)
+            # the queue holds one PLACEHOLDER per remaining slot that keeps it busy for its delay (slot s starts at slab s // g, the
+            # last slots at ramp - 1); the recordings behind them take the slots as the placeholders end, in queue order
+            delay = np.minimum(np.arange(g, self.slots, dtype=np.int64) // g, ramp - 1)
+            need_q = np.ascontiguousarray(np.concatenate([need[:g], delay, need[g:]]))
+            start_q = np.zeros(len(need_q), dtype=np.int64)
+            slot_q = np.zeros(len(need_q), dtype=np.int64)
+            if lib().vad_refill_schedule(need_q.ctypes.data_as(lp), len(need_q), self.slots, start_q.ctypes.data_as(lp), slot_q.ctypes.data_as(lp)):
+                raise ValueError("vad_refill_schedule: bad arguments")
+            real = np.ones(len(need_q), dtype=bool)
+            real[g:g + len(delay)] = False
+            start, slot = np.ascontiguousarray(start_q[real]), np.ascontiguousarray(slot_q[real])
+        else:
+            start = np.zeros(len(queue), dtype=np.int64)
+            slot = np.zeros(len(queue), dtype=np.int64)
+            if lib().vad_refill_schedule(need.ctypes.data_as(lp), len(queue), self.slots, start.ctypes.data_as(lp), slot.ctypes.data_as(lp)):
+                raise ValueError("vad_refill_schedule: bad arguments")
         # one row per (recording, slab it is active in): [slot, recording, first sample, samples, reset], by slab, then by slot (native:
         # 1.3 M rows for a shard -- vad_refill_table)
         n_slabs = int((start + need).max()) if len(queue) else 0
@@ -977,11 +999,15 @@ class RefillPlan:
         return int(((live + self.chunk - 1) // self.chunk).sum())
 
 
-def _assign_window_buffers(first: np.ndarray, last: np.ndarray, ahead: int):
+def _assign_window_buffers(first: np.ndarray, last: np.ndarray, ahead: int, slack: int = 1):
     """Device buffers for the refill route's arena windows, planned up front (the schedule is static).  Window w is first read by
     the gather of slab first[w], last by the gather of slab last[w]; its DMA is ISSUED while slab issue[w] = max(0, first[w] - ahead)
     is being staged, before that slab's gather.  A buffer may take window w if the window it held was last read by a slab BEFORE
     issue[w] (its release event exists by then).  Windows are issued in index order (first[] is non-decreasing in arena order).
+    `slack`: the previous window must have been last read at least `slack` slabs before the issue slab -- the refill loop knows, when it
+    stages slab k, that the uploads of slabs <= k - 2 are COMPLETE (it waited for that staging slot), so with slack 2 a window's DMA never
+    carries an open device-side dependency (a copy that does is taken off the copy engines' fast path: 35.6 instead of 19 ms per GiB for
+    hundreds of ms, profiles/r06_refill_window_feed.md).
     Returns (buffer index per window, number of buffers, issue slab per window)."""
     first = np.asarray(first, dtype=np.int64)
     last = np.asarray(last, dtype=np.int64)
@@ -993,7 +1019,7 @@ def _assign_window_buffers(first: np.ndarray, last: np.ndarray, ahead: int):
     free = []
     n_buf = 0
     for w in range(len(first)):
-        while busy and busy[0][0] < issue[w]:
+        while busy and busy[0][0] <= issue[w] - slack:
             heapq.heappush(free, heapq.heappop(busy)[1])
         if free:
             j = heapq.heappop(free)
@@ -1037,12 +1063,15 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
         if packed is not None and packed.base.is_pinned() and int((lens_np > 0).sum()):
             slab_bytes = slots * slab_chunks * n * esz
             wbytes = int(os.environ.get("SILERO_VAD_AMD_REFILL_WINDOW", 0)) or (1 << 30)        # (256 MiB windows: 0.92 of the link, 1 GiB: 0.95)
-            order, bounds, o_, e_ = _arena_windows(packed.offsets, packed.lengths, wbytes // esz)
+            # (the slots start over `ramp` slabs and the first windows are small -- 1/8, 1/4, 1/2 of a window: the first kernel runs
+            #  after 7 ms of link time instead of 37, the first recordings retire that much earlier)
+            ramp = max(1, int(os.environ.get("SILERO_VAD_AMD_REFILL_RAMP", "8")))
+            order, bounds, o_, e_ = _arena_windows(packed.offsets, packed.lengths, wbytes // esz, lead_limit=(wbytes // esz) // 8 if int(os.environ.get("SILERO_VAD_AMD_REFILL_LEAD", ramp > 1)) else 0)
             spans = np.asarray([(o_[a], e_[b - 1]) for a, b in bounds], dtype=np.int64).reshape(-1, 2)
             copied = int((spans[:, 1] - spans[:, 0]).sum())
             dense = mode == "window" or float(lens_np[lens_np > 0].sum()) >= 0.6 * copied
             if dense:
-                wplan = RefillPlan(lens_np, slots, slab_chunks, n, order=order)
+                wplan = RefillPlan(lens_np, slots, slab_chunks, n, order=order, ramp=ramp)
                 win_of = np.full(len(lens_np), -1, dtype=np.int64)
                 for w, (a, b) in enumerate(bounds):
                     win_of[order[a:b]] = w
@@ -1051,7 +1080,8 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
                 wmax = int((spans[:, 1] - spans[:, 0]).max()) * esz
                 wmax = (wmax + 255) // 256 * 256
                 ahead = max(2, -(-2 * wmax // max(slab_bytes, 1))) + 1          # two windows' worth of slabs in front of the reader
-                buf_of, n_buf, issue = _assign_window_buffers(w_first, w_last, ahead)
+                slack = int(os.environ.get("SILERO_VAD_AMD_REFILL_SLACK", "2"))      # (1: A/B -- the DMAs may then wait on the device)
+                buf_of, n_buf, issue = _assign_window_buffers(w_first, w_last, ahead, slack=slack)
                 budget = int(os.environ.get("SILERO_VAD_AMD_REFILL_WINDOW_BUDGET", 0))
                 if not budget:                                               # 16 GiB of the 288, less on a device that others fill
                     held = getattr(getattr(model, "_stage_pool", None), "refill_windows", None)
@@ -1060,7 +1090,7 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
                 if n_buf * wmax <= budget:
                     plan = wplan
                     wf = {"packed": packed, "spans": spans, "win_of": win_of, "first": w_first, "last": w_last, "buf_of": buf_of,
-                          "n_buf": n_buf, "wmax": wmax, "issue": issue, "next": 0, "ev": {}, "release": {}, "holder": {}}
+                          "n_buf": n_buf, "wmax": wmax, "issue": issue, "next": 0, "ev": {}, "release": {}, "holder": {}, "slack": slack}
                     STATS["refill_window_feed"] += 1
                     STATS["refill_window_buffers"] = max(STATS["refill_window_buffers"], n_buf)
     plan = plan or RefillPlan(lens_np, slots, slab_chunks, n)
@@ -1128,7 +1158,13 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
                 nb = (b - a) * esz
                 prev = wf["holder"].get(j)
                 if prev is not None:
-                    wf["stream"].wait_event(wf["release"].pop(prev))          # recorded behind the last cut that read window `prev`
+                    # recorded behind the last cut that read window `prev`, at least two slabs ago: complete by now (stage() has waited
+                    # for the upload of slab k - 2), so this returns at once and the DMA below is issued WITHOUT a device-side dependency
+                    rel = wf["release"].pop(prev)
+                    if wf["slack"] >= 2:
+                        rel.synchronize()
+                    else:
+                        wf["stream"].wait_event(rel)
                 with torch.cuda.stream(wf["stream"]):
                     wf["blk"][j * wf["wmax"]: j * wf["wmax"] + nb].view(dtype).copy_(wf["packed"].base[a:b], non_blocking=True)
                     ev = torch.cuda.Event()

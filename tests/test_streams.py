@@ -230,10 +230,47 @@ def test_refill_plan_in_a_given_order_admits_first_come_first_served():
         assert np.all(plan.first_slab[lengths == 0] == -1) and np.all(plan.last_slab[live] >= plan.first_slab[live])
         width = slab * 512
         assert np.array_equal(plan.last_slab[live] - plan.first_slab[live] + 1, (lengths[live] + width - 1) // width)
+    # ramp: the slots start over `ramp` slabs, a 1 / ramp of them per slab, lowest slots first; still every sample once, in the given order
+    for slots, slab, ramp in ((8, 4, 4), (16, 2, 8), (7, 4, 3), (4, 4, 8)):
+        plan = RefillPlan(lengths, slots, slab, 512, order=order, ramp=ramp)
+        seen = np.zeros(len(lengths), dtype=np.int64)
+        for k, entries in enumerate(plan.slabs):
+            for sl, rec, at, take, reset in entries:
+                assert at == seen[rec]
+                seen[rec] += take
+        assert np.array_equal(seen, lengths)
+        live = order[lengths[order] > 0]
+        assert np.all(np.diff(plan.first_slab[live]) >= 0)
+        g = slots // ramp
+        if g >= 1:
+            for k in range(ramp - 1):
+                used = {e[0] for e in plan.slabs[k]}
+                assert used <= set(range((k + 1) * g)) and len(used) > 0        # slab k: only the first (k + 1) g slots have started
+            assert len(plan.slabs[0]) == g
+        else:                                                                    # fewer slots than ramp steps: no stagger
+            assert len(plan.slabs[0]) == slots
     with pytest.raises(ValueError):
         RefillPlan(lengths, 4, 4, 512, order=order[:-1] if lengths[order[-1]] > 0 else order[1:])
     with pytest.raises(ValueError):
         RefillPlan(lengths, 4, 4, 512, order=np.concatenate([order, order[:1]]))
+
+
+def test_arena_windows_with_small_leading_windows():
+    """_arena_windows(lead_limit=): the first windows are cut at lead_limit, 2 lead_limit, 4 lead_limit ... until the full limit -- the same
+    recordings, in the same order, every one in exactly one window, no window above its limit unless it is a single recording."""
+    from silero_vad_amd.streams import _arena_windows
+    rng = np.random.default_rng(3)
+    lens = rng.integers(1, 5000, 400)
+    lens[::37] = 0
+    offs = np.concatenate([[0], np.cumsum(lens + rng.integers(0, 9, 400))[:-1]])
+    order0, b0, o0, e0 = _arena_windows(offs, lens, 40000)
+    order1, b1, o1, e1 = _arena_windows(offs, lens, 40000, lead_limit=5000)
+    assert np.array_equal(order0, order1) and len(b1) > len(b0)
+    assert [a for a, _ in b1] == [0] + [b for _, b in b1[:-1]] and b1[-1][1] == len(order1)      # a partition, in order
+    for i, (a, b) in enumerate(b1):
+        lim = min(40000, 5000 << i)
+        assert e1[b - 1] - o1[a] <= lim or b - a == 1
+    assert [(a, b) for a, b in b1[5:]] != [] and all(e1[b - 1] - o1[a] <= 40000 for a, b in b1)
 
 
 def test_window_buffers_are_never_shared_by_two_live_windows_fuzz():
@@ -249,14 +286,15 @@ def test_window_buffers_are_never_shared_by_two_live_windows_fuzz():
         if trial % 10 == 0:
             last[int(rng.integers(0, nw))] += 500                                   # one window pinned by a very long recording
         ahead = int(rng.integers(0, 9))
-        buf, n_buf, issue = _assign_window_buffers(first, last, ahead)
+        slack = int(rng.integers(1, 4))
+        buf, n_buf, issue = _assign_window_buffers(first, last, ahead, slack=slack)
         assert np.all(issue <= first) and np.all(np.diff(issue) >= 0) and np.all(issue >= 0)
         assert buf.min() == 0 and buf.max() == n_buf - 1
         for j in range(n_buf):
             ws = np.flatnonzero(buf == j)
             for a, b in zip(ws[:-1], ws[1:]):
-                assert last[a] < issue[b]                                           # released before the next DMA into it is issued
-        alive = max(int(np.sum((issue <= t) & (last >= t))) for t in range(int(last.max()) + 1))
+                assert last[a] <= issue[b] - slack                                  # released `slack` slabs before the next DMA into it is issued
+        alive = max(int(np.sum((issue <= t) & (last + slack - 1 >= t))) for t in range(int(last.max()) + slack + 1))
         assert n_buf == alive
     buf, n_buf, issue = _assign_window_buffers(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), 3)
     assert n_buf == 0 and len(buf) == 0
