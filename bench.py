@@ -976,10 +976,12 @@ def run_corpus(args, rank, world, local, dist, passes, sr=16000, main_only=False
         legs["pageable_staged"], _ = run_leg(base_i_page, "buckets", "stage", short, False)
         # (the whole shard: recordings are admitted longest first, so the first ones retire ten slabs in -- 2-3 % of a full shard's wall time,
         #  setup included; on six passes that would be 11 %)
-        legs["pinned_refill_gather"], _ = run_leg(base_i, "refill", "gather", len(lens), False)
+        if not os.environ.get("VAD_BENCH_SKIP_REFILL"):           # (diagnostic knob: the bucket routes only)
+            legs["pinned_refill_gather"], _ = run_leg(base_i, "refill", "gather", len(lens), False)
         # the same scheduler fed from arena windows: recordings admitted in arena order, one DMA per 256 MB window a few slabs ahead of
         # its readers, the slabs' rows cut from the windows' device copies (streams._refill_iter)
-        legs["pinned_refill_window"], _ = run_leg(base_i, "refill", "window", len(lens), False)
+        if not os.environ.get("VAD_BENCH_SKIP_REFILL"):
+            legs["pinned_refill_window"], _ = run_leg(base_i, "refill", "window", len(lens), False)
     os.environ.pop("SILERO_VAD_AMD_UPLOAD", None)
     # what the link allows: the H2D rate measured while copying / bytes per chunk -- a leg's value can approach it (fully
     # overlapped pipeline), never exceed it

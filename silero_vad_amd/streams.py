@@ -22,6 +22,7 @@
 import collections
 import contextlib
 import ctypes
+import os
 import time
 from typing import List, Sequence
 
@@ -407,7 +408,6 @@ def _upload_mode():
     """How pinned recordings reach the GPU: "window" (a PackedRecordings whose recordings lie back to back: one DMA per arena
     window, batches cut on the device; the default where it applies), "gather" (one kernel that reads host memory; the default
     otherwise), "dma" (copy engines, one copy per row), "stage" (force the pageable path).  SILERO_VAD_AMD_UPLOAD overrides."""
-    import os
     return os.environ.get("SILERO_VAD_AMD_UPLOAD", "")
 
 
@@ -492,7 +492,6 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         # most of the range they span: one DMA per arena window, batches cut on the device
         packed = audios if isinstance(audios, PackedRecordings) else _as_packed(audios)
         if packed is not None and packed.base.is_pinned():
-            import os
             wbytes = int(os.environ.get("SILERO_VAD_AMD_WINDOW_BYTES", 0)) or max(2 * max_bytes, 1 << 30)
 
             def takes_windows(wp_):
@@ -585,6 +584,8 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
                     eng_l.set_transient("rec_form", before)
 
     pin_lanes(True)
+    import os as _os
+    stage_sync = _os.environ.get("SILERO_VAD_AMD_STAGE_SYNC", "1") != "0"      # (0: A/B -- the staged copies wait on the device)
 
     def stage(k):
         idxs = plan.buckets[k]
@@ -599,8 +600,12 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
         STATS["padded"] += len(idxs) * L
         STATS["real"] += sum(plan.lengths[j] for j in idxs)
         d = pool.dev[i][:nbytes].view(dtype).view(len(idxs), width)
+        late_wait = None
         if pool.consumed[i] is not None:                  # the device buffer's previous reader is done
-            pool.stream.wait_event(pool.consumed[i])
+            if windowed or (direct and how != 0) or not stage_sync:
+                pool.stream.wait_event(pool.consumed[i])
+            else:
+                late_wait = pool.consumed[i]              # (a DMA: waited for on the HOST, behind the staging -- see below)
         m_host = None
         if meta is not None:                              # in the slot's own pinned scratch (meta_buffer: why)
             mt = meta(idxs)
@@ -611,6 +616,11 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
             host = pool.host[i][:nbytes].view(dtype).view(len(idxs), width)
             _stage_into(src, idxs, width, host)
             STATS["stage_s"] += time.perf_counter() - t0
+            if late_wait is not None:
+                # the H2D copy below is a DMA: issued behind an OPEN device-side wait it leaves the copy engines' fast path (the refill
+                # window feed's finding, profiles/r06_refill_window_feed.md).  The reader of this slot's previous bucket started three
+                # buckets ago and is normally done by the time this one is staged: wait for it here, issue the copy without a dependency
+                late_wait.synchronize()
         if windowed:
             w = plan.window_of[k]
             ensure_window(w + 2)                          # this bucket's window and the two after it are on their way
@@ -629,6 +639,8 @@ def ragged_buckets(audios: Sequence, model, sampling_rate: int = 16000, max_wast
                     win["free"][w % 3].record(pool.stream)
                 STATS["upload_call_s"] += time.perf_counter() - t0
             elif direct:
+                if late_wait is not None:                 # (the per-row DMA route: the same rule)
+                    late_wait.synchronize()
                 tabs = src.tables(idxs)
                 model.engine.upload_rows(tabs[2], tabs[3], len(idxs), width, esz, d, how)
                 STATS["upload_call_s"] += time.perf_counter() - t0
@@ -1058,7 +1070,6 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
     # buffers (SILERO_VAD_AMD_REFILL_WINDOW_BUDGET, 16 GiB of the 288) keeps the gather route.
     wf = None
     if plan is None and on_gpu and mode in ("", "window") and hasattr(eng, "upload_rows"):
-        import os
         packed = audios if isinstance(audios, PackedRecordings) else _as_packed(audios)
         if packed is not None and packed.base.is_pinned() and int((lens_np > 0).sum()):
             slab_bytes = slots * slab_chunks * n * esz
@@ -1281,7 +1292,13 @@ def _refill_iter(audios: Sequence, model, sampling_rate: int, slots: int, slab_c
             d = pool.dev[i][:nbytes].view(dtype).view(B, width)
             idx_k, rs_k = slab_meta(k)                                      # (the group's one copy goes out with its first slab)
             if pool.consumed[i] is not None:
-                pool.stream.wait_event(pool.consumed[i])
+                # (a DMA -- the staged copy, the per-row copies -- is issued behind a COMPLETE event, waited for on the host: behind an
+                #  open device-side wait it leaves the copy engines' fast path, as in the bucket routes' stage(); the upload kernels wait
+                #  on the device)
+                if wf is None and (not direct or how == 0) and os.environ.get("SILERO_VAD_AMD_STAGE_SYNC", "1") != "0":
+                    pool.consumed[i].synchronize()
+                else:
+                    pool.stream.wait_event(pool.consumed[i])
             with torch.cuda.stream(pool.stream):
                 if wf is not None:
                     eng.upload_rows(rows_p, lens_p, B, width, esz, d, 2)      # (2: the rows are device addresses)
