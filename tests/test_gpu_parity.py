@@ -1332,6 +1332,37 @@ def test_ragged_corpus_from_pinned_memory(model, golden, monkeypatch, mode):
     assert all(torch.equal(g, want[order[i]]) for g, i in zip(got_v, perm))
 
 
+@pytest.mark.parametrize("mode", ["stage", "dma"])
+def test_copies_behind_a_host_side_wait_give_the_same_bits(model, golden, monkeypatch, mode):
+    """The staged and per-row DMA copies of both schedulers are issued behind COMPLETE events (the host waits for the device buffer's
+    previous reader; DESIGN 4.4, pageable sources) -- with enough buckets / slabs that every staging slot is reused several times, the
+    probabilities equal those of the device-side wait (SILERO_VAD_AMD_STAGE_SYNC=0, the form before), bit for bit."""
+    from silero_vad_amd import ragged_probs, refill_probs
+    from silero_vad_amd import streams as S
+    sr, n = 16000, 512
+    pcm = (golden["16k"]["wav"] * 32768.0).clip(-32768, 32767).astype(np.int16)
+    rng = np.random.default_rng(21)
+    lens = rng.integers(3 * n, 60 * n, 80)
+    offs = rng.integers(0, len(pcm) - 60 * n, 80) // 8 * 8
+    if mode == "stage":
+        audios = [torch.from_numpy(pcm[o:o + m].copy()) for o, m in zip(offs, lens)]
+    else:
+        pinned = torch.from_numpy(pcm).pin_memory()
+        audios = [pinned[o:o + m] for o, m in zip(offs, lens)]
+    monkeypatch.setenv("SILERO_VAD_AMD_UPLOAD", mode)
+    got = {}
+    for sync in ("0", "1"):
+        monkeypatch.setenv("SILERO_VAD_AMD_STAGE_SYNC", sync)
+        S.STATS.clear()
+        b = ragged_probs(audios, model, sr, max_waste=0.2, max_bytes=150_000)
+        assert S.STATS["buckets"] >= 12                                    # three staging slots: each reused at least four times
+        r = refill_probs(audios, model, sr, slots=8, slab_chunks=8)
+        got[sync] = (b, r)
+    for a, b in zip(got["0"], got["1"]):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert all(torch.equal(x, y) for x, y in zip(got["1"][0], got["1"][1]))  # and the two schedulers agree
+
+
 # ---- (14) the latency form of the frontend -----------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["16k", "8k"])
 def test_latency_frontend_is_bit_identical(model, oracle, golden, tag):
