@@ -822,7 +822,10 @@ def corpus_parity_sample(model, gids, lens, offs, base_page, counts, segs, sr, e
     first = np.concatenate([[0], np.cumsum(counts)])
     worst, checked, same = 0.0, 0, True
     k = sr // 16000 if sr > 16000 else 1                            # a raw 32 / 48 kHz corpus: the oracle gets x[::k], like the reference's front door
-    for j in np.flatnonzero(gids % every == 0):
+    sample = np.flatnonzero((gids % every == 0) & (lens > 0))
+    if not len(sample):                                             # a small shard that holds no 10 000th recording: its first one
+        sample = np.flatnonzero(lens > 0)[:1]
+    for j in sample:
         a = base_page[int(offs[j]):int(offs[j]) + int(lens[j])]      # (the arena the corpus run read)
         x = a.to(torch.float32) / 32768.0
         got = model.audio_forward(x[None], sr)[0].numpy()
@@ -832,7 +835,7 @@ def corpus_parity_sample(model, gids, lens, offs, base_page, counts, segs, sr, e
         mine = [{"start": int(p), "end": int(q)} for p, q in segs[first[j]:first[j + 1]]]
         same = same and mine == segment_probs(want, len(xd), sr // k)
         checked += 1
-    return {"recordings_checked": checked, "one_in": every, "parity_sample_max_abs_dp": worst,
+    return {"recordings_checked": checked, "one_in": every, "parity_sample_max_abs_dp": worst if checked else None,
             "segments_identical_to_oracle_scan": bool(same), "tolerance": 1e-4}
 
 
@@ -1174,7 +1177,7 @@ def compact_legs(out):
         if isinstance(par, dict):
             e["dp"] = float(f"{par.get('parity_max_abs_dp', 0):.2e}")
             e["max_prob"] = par.get("max_prob")
-        elif "parity_sample_max_abs_dp" in d:
+        elif d.get("parity_sample_max_abs_dp") is not None:
             e["dp"] = float(f"{d['parity_sample_max_abs_dp']:.2e}")
         if isinstance(d.get("gaps"), dict):              # live streams that miss ticks: the fraction of (stream, tick) pairs without a chunk
             e["missed"] = d["gaps"].get("missed_fraction")
@@ -1241,7 +1244,7 @@ def compact_line(out):
                           "tolerance": par.get("tolerance"), "checker": "oracle/vad_oracle.c on the timed PCM", "ok": par.get("ok")}
     ps = out.get("parity_sample")
     if isinstance(ps, dict):
-        line["parity"] = {"max_abs_dp": float(f"{ps.get('parity_sample_max_abs_dp', 0):.3e}"), "recordings_checked": ps.get("recordings_checked"),
+        line["parity"] = {"max_abs_dp": float(f"{(ps.get('parity_sample_max_abs_dp') or 0):.3e}"), "recordings_checked": ps.get("recordings_checked"),
                           "one_in": ps.get("one_in"), "segments_identical": ps.get("segments_identical_to_oracle_scan"), "tolerance": ps.get("tolerance")}
     rl = out.get("roofline")
     if isinstance(rl, dict):
